@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by running THE REFERENCE ITSELF.
+
+Runs only in the build container, where the reference checkout is mounted read-only at
+/root/reference.  It imports the reference's ``Generator`` (model.py:15), loads the
+deterministic synthetic weights of ``mocha_sigasia2023_amd.weights`` into it with
+``load_state_dict(strict=True)`` (which also pins the key schema and, through the buffer
+comparison below, the regenerated graph constants), runs the demo's call sequence
+(test_fullframework.py:190-193,301-302) and ``Generator.forward`` (model.py:82-106) on
+seeded synthetic windows, and stores inputs + outputs as ``.npz``.  The matching fixture
+runs scikit-learn's ``BallTree`` exactly as the demo does (test_fullframework.py:294-296).
+
+No reference source or bytecode is written anywhere; the fixtures are data only.
+
+    python tests/golden/make_golden.py            # regenerates every fixture
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("MOCHA_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REPO)
+
+from mocha_sigasia2023_amd import synthetic, weights  # noqa: E402
+from mocha_sigasia2023_amd.skeleton import skeleton_constants  # noqa: E402
+
+
+def build_reference_generator(layout):
+    """Instantiate the reference Generator; for 'mixamo' swap the two hard-coded 'mocha'
+    pool modules after construction."""
+    cwd = os.getcwd()
+    os.chdir(REF)  # model.py:7-8 appends './net', './motion' relative to cwd
+    try:
+        for p in (REF, os.path.join(REF, "net"), os.path.join(REF, "etc")):
+            if p not in sys.path:
+                sys.path.append(p)
+        from utils import get_config          # etc/utils.py:23-25
+        from model import Generator           # model.py:15
+        from graph import PoolJointToBodypart, UnpoolBodypartToJoint
+        from transformer import mean_variance_norm
+        cfg = get_config(os.path.join(REF, "configs/config.yaml"))["model"]
+        if layout != "mocha":
+            cfg["graph"]["joint"]["layout"] = layout
+            cfg["graph"]["bodypart"]["layout"] = layout
+        G = Generator(cfg)
+        if layout != "mocha":
+            G.mot_embedding[3] = PoolJointToBodypart(layout)
+            G.to_mot[3] = UnpoolBodypartToJoint(layout)
+    finally:
+        os.chdir(cwd)
+    return G.eval(), mean_variance_norm
+
+
+def run_variant(name, layout, seed, gain, B):
+    G, mvn = build_reference_generator(layout)
+    ref_buffers = {k: v.numpy().copy() for k, v in G.state_dict().items()
+                   if k.endswith("A_j") or k.endswith("A_b") or k in ("mot_embedding.3.weight", "to_mot.3.weight")}
+    sd = weights.synthetic_state_dict(seed=seed, gain=gain, layout=layout)
+    # a14: our regenerated graph constants must equal the reference's own buffers bit for bit
+    for k, v in ref_buffers.items():
+        assert v.shape == sd[k].shape and np.array_equal(v, sd[k]), f"graph constant mismatch: {k}"
+    G.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    V = skeleton_constants(layout).V
+    src = torch.from_numpy(synthetic.pose_windows(seed + 1, B, V))
+    cha = torch.from_numpy(synthetic.pose_windows(seed + 2, B, V))
+    out = {"src_X": src.numpy(), "cha_X": cha.numpy()}
+    with torch.no_grad():
+        # the demo's sequence, test_fullframework.py:190-193
+        for tag, X in (("src", src), ("cha", cha)):
+            tokens = G.mot_embedding(X)
+            out[f"{tag}_tokens"] = tokens.numpy()
+            tokens = tokens + G.pos_emb[:, :tokens.shape[1]]
+            encoded = G.encoder(tokens)
+            out[f"{tag}_encoded"] = encoded.numpy()
+            cnt = mvn(encoded.permute(0, 2, 1)).permute(0, 2, 1)
+            out[f"{tag}_cnt"] = cnt.numpy()
+        # sub-stage taps (module boundaries of model.py:42-50 and :71-80)
+        x = G.mot_embedding[:5](src)                       # after AvgPool2d: (B, 256, 15, 6)
+        out["src_emb_pooled"] = x.numpy()
+        enc_s = torch.from_numpy(out["src_encoded"])
+        enc_c = torch.from_numpy(out["cha_encoded"])
+        dec = G.decoder(enc_s, enc_c)                      # test_fullframework.py:301
+        out["decoded"] = dec.numpy()
+        out["mot_body"] = G.to_mot[:2](dec).numpy()        # after the body block: (B, 256, 15, 6)
+        Y = G.to_mot(dec)                                  # :302
+        out["Y"] = Y.numpy()
+        Yf = G(src, cha)                                   # model.py:82-106
+        assert torch.equal(Yf, Y) or float((Yf - Y).abs().max()) < 1e-6
+        out["Y_forward"] = Yf.numpy()
+    meta = dict(layout=layout, seed=seed, gain=gain, B=B, V=V,
+                torch=torch.__version__, numpy=np.__version__)
+    path = os.path.join(HERE, f"generator_{name}.npz")
+    np.savez(path, **out, meta=np.array(repr(meta)))
+    print(name, {k: (v.shape, float(np.abs(v).max())) for k, v in out.items()})
+    return path
+
+
+def run_graph_constants():
+    """Reference buffers for both layouts (row a14), stored so the CPU test needs no reference."""
+    out = {}
+    for layout in ("mocha", "mixamo"):
+        G, _ = build_reference_generator(layout)
+        sd = G.state_dict()
+        out[f"{layout}_A_j"] = sd["mot_embedding.2.A_j"].numpy()
+        out[f"{layout}_A_b"] = sd["mot_embedding.5.A_b"].numpy()
+        out[f"{layout}_pool"] = sd["mot_embedding.3.weight"].numpy()
+        out[f"{layout}_unpool"] = sd["to_mot.3.weight"].numpy()
+    np.savez(os.path.join(HERE, "graph_constants.npz"), **out)
+
+
+def run_match():
+    """BallTree k=1 exactly as test_fullframework.py:293-296,440-443, on seeded synthetic cnt."""
+    import sklearn
+    from sklearn.neighbors import BallTree
+    out = {}
+    mean, std = synthetic.cnt_norm(90)
+    for nb, q, seed in ((64, 16, 100), (585, 16, 200)):
+        cha_cnt = synthetic.token_features(seed, nb)
+        src_cnt = synthetic.token_features(seed + 1, q)
+        # make a few queries near-duplicates of bank rows so the answer is not arbitrary
+        src_cnt[:4] = cha_cnt[[3, nb - 1, nb // 2, 7]] + 0.05 * src_cnt[:4]
+        cha_nm = (cha_cnt - mean[np.newaxis]) / std[np.newaxis]
+        tree = BallTree(cha_nm.reshape(cha_nm.shape[0], -1))
+        src_nm = (src_cnt - mean[np.newaxis]) / std[np.newaxis]
+        dist, idx = tree.query(src_nm.reshape(src_nm.shape[0], -1), k=1, return_distance=True)
+        out[f"n{nb}_idx"] = idx[:, 0].astype(np.int64)
+        out[f"n{nb}_dist"] = dist[:, 0].astype(np.float64)
+        out[f"n{nb}_seed"] = np.array([seed, nb, q])
+    out["meta"] = np.array(repr(dict(sklearn=sklearn.__version__, cnt_norm_seed=90)))
+    np.savez(os.path.join(HERE, "match_balltree.npz"), **out)
+    print("match", {k: v for k, v in out.items() if k.endswith("idx")})
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    run_graph_constants()
+    run_variant("mocha24_g1", "mocha", seed=1777, gain=1.0, B=2)
+    run_variant("mocha24_g2", "mocha", seed=4242, gain=2.0, B=1)
+    run_variant("mixamo22_g1", "mixamo", seed=2222, gain=1.0, B=1)
+    run_match()
