@@ -1,0 +1,121 @@
+/*
+ * mocha_hip.h — C ABI of libmocha_hip.so: the MI355X (gfx950) implementation of the MOCHA
+ * Generator hot path (motion encoder -> context matching -> body-part decoder).
+ *
+ * The reference (DK-Jang/MOCHA_SIGASIA2023) is pure Python and has no FFI of its own; the
+ * boundary it offers is the attribute surface of its `Generator` module plus the
+ * `gen_ema` state_dict key schema.  Each entry point below names the
+ * reference interface it replaces (file:line relative to the reference repository root).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every tensor pointer is a DEVICE pointer to contiguous fp32 unless a comment says host;
+ *   - layouts are the reference's: poses (B, T, V, C_in) channel-last, tokens (B, 90, 256)
+ *     with token = t*6 + body_part (model.py:49), bank entries likewise;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing here
+ *     synchronises the device (no hidden syncs; graph-capture safe after mocha_reserve);
+ *   - functions return 0 on success, a negative mocha_status otherwise;
+ *     mocha_last_error(ctx) gives the message.  The caller owns every in/out buffer; the
+ *     context owns the device copies of the weights, the bank (unless borrowed) and the
+ *     workspaces.  One context per device per host thread.
+ */
+#ifndef MOCHA_HIP_H
+#define MOCHA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mocha_ctx mocha_ctx;
+
+typedef enum {
+    MOCHA_OK = 0,
+    MOCHA_ERR_ARG = -1,      /* bad argument / unsupported configuration */
+    MOCHA_ERR_HIP = -2,      /* a HIP runtime call failed */
+    MOCHA_ERR_STATE = -3,    /* call order violated (weights not finalised, no bank, ...) */
+    MOCHA_ERR_WEIGHT = -4    /* unknown weight name or wrong shape */
+} mocha_status;
+
+/* The 14 model dimensions Generator.__init__ reads (model.py:18-33, configs/config.yaml:13-31)
+ * plus the skeleton layout (0 = 'mocha' 24 joints, 1 = 'mixamo' 22 joints; net/graph.py). */
+typedef struct {
+    int T, V, C_in, patch, dim;
+    int enc_depth, enc_heads, enc_dim_head, enc_mlp;
+    int dec_depth, dec_heads, dec_dim_head, dec_mlp;
+    int layout;
+} mocha_cfg;
+
+/* Generator(cfg) construction, model.py:16-80 / trainer.py:22-23. */
+int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out);
+void mocha_destroy(mocha_ctx* ctx);
+const char* mocha_last_error(const mocha_ctx* ctx);   /* ctx may be NULL: last create error */
+
+/* load_state_dict, trainer.py:239-240: one call per state_dict entry, `host` is HOST fp32.
+ * Names are exactly the reference's ("mot_embedding.2.blk.gcn.conv.weight", ...).  The graph
+ * buffers (A_j, A_b, pool/unpool weights) are accepted and cross-checked against the
+ * regenerated constants. */
+int mocha_load_weight(mocha_ctx* ctx, const char* name, const float* host, const int64_t* shape, int ndim);
+/* After the last mocha_load_weight: checks completeness, repacks weights into kernel layouts. */
+int mocha_finalize_weights(mocha_ctx* ctx);
+
+/* Pre-allocate workspaces for up to `max_batch` windows per internal chunk (larger B is
+ * processed in chunks).  Optional; called lazily otherwise (not graph-capture safe then). */
+int mocha_reserve(mocha_ctx* ctx, int max_batch);
+
+/* model.pos_emb (model.py:40; test_fullframework.py:191): device pointer to (90, 256). */
+int mocha_pos_emb(mocha_ctx* ctx, const float** dev_ptr);
+
+/* model.mot_embedding(X), model.py:42-50 (test_fullframework.py:190).
+ * X (B,T,V,C_in) -> tokens (B,90,256); add_pos != 0 fuses `+ pos_emb` (test_fullframework.py:191). */
+int mocha_embed(mocha_ctx* ctx, const float* X, int B, float* tokens, int add_pos, void* stream);
+/* model.encoder(tokens), model.py:53-59, net/transformer.py:90-95 (test_fullframework.py:192). */
+int mocha_encoder(mocha_ctx* ctx, const float* tokens, int B, float* encoded, void* stream);
+/* mean_variance_norm(encoded.permute(0,2,1)).permute(0,2,1), net/transformer.py:13-20
+ * (test_fullframework.py:193).  If cnt_mean/cnt_std (90,256) and cnt_nm are non-NULL also
+ * writes cnt_nm = (cnt - cnt_mean) / cnt_std (test_fullframework.py:293,297,442). */
+int mocha_mvn(mocha_ctx* ctx, const float* encoded, int B, float* cnt,
+              const float* cnt_mean, const float* cnt_std, float* cnt_nm, void* stream);
+/* Fused demo encode sequence test_fullframework.py:190-193: embed, +pos_emb, encoder and
+ * (when cnt != NULL) the cnt feature; cnt_nm as in mocha_mvn. */
+int mocha_encode(mocha_ctx* ctx, const float* X, int B, float* encoded, float* cnt,
+                 const float* cnt_mean, const float* cnt_std, float* cnt_nm, void* stream);
+/* model.decoder(src_enc, cha_enc), model.py:62-68, net/transformer.py:90-121 (test_fullframework.py:301,455,465). */
+int mocha_decoder(mocha_ctx* ctx, const float* src_enc, const float* cha_enc, int B, float* out, void* stream);
+/* model.to_mot(tokens), model.py:71-80 (test_fullframework.py:302,456,466). */
+int mocha_to_mot(mocha_ctx* ctx, const float* tokens, int B, float* Y, void* stream);
+/* Generator.forward(src_X, cha_X), model.py:82-106. */
+int mocha_forward(mocha_ctx* ctx, const float* src_X, const float* cha_X, int B, float* Y, void* stream);
+/* Generator.forward(..., extract_feature=True), model.py:95-98. */
+int mocha_forward_features(mocha_ctx* ctx, const float* src_X, const float* cha_X, int B,
+                           float* src_enc, float* cha_enc, float* src_cnt, float* cha_cnt, void* stream);
+
+/* Character feature bank = what BallTree(cha_cnt_nm) + cha_encoded hold in the demo
+ * (test_fullframework.py:293-294, 298).  cnt_nm (N, 90*256) are the z-scored cnt features,
+ * encoded (N, 90, 256) the features gathered for the decoder.  flags bit 0: borrow the
+ * caller's buffers instead of copying (they must stay valid and unchanged). */
+#define MOCHA_BANK_BORROW 1
+int mocha_bank_set(mocha_ctx* ctx, const float* cnt_nm, const float* encoded, int64_t N, int flags, void* stream);
+/* tree.query(q, k=1), test_fullframework.py:296,443: exact Euclidean 1-NN of each z-scored
+ * query row (Q, 90*256) in the bank.  idx (Q,) int32; dist (Q,) fp32 Euclidean distance to the
+ * winner (may be NULL). */
+int mocha_match(mocha_ctx* ctx, const float* query_nm, int Q, int32_t* idx, float* dist, void* stream);
+/* cha_encoded[frame_index], test_fullframework.py:298,465: out (Q,90,256) = bank.encoded[idx[q]]. */
+int mocha_bank_gather(mocha_ctx* ctx, const int32_t* idx, int Q, float* out, void* stream);
+
+/* The NN ("cm_") branch of the demo, batched over all source windows
+ * (test_fullframework.py:188-194, 288-302, 438-443, 465-467): encode src, match against the
+ * current bank, gather, decode, to_mot.  Y (B,T,V,C_in); idx (B,) may be NULL. */
+int mocha_characterize(mocha_ctx* ctx, const float* src_X, int B, const float* cnt_mean, const float* cnt_std,
+                       float* Y, int32_t* idx, void* stream);
+
+/* Introspection for tests and tooling. */
+int mocha_abi_version(void);
+int mocha_graph_constants(mocha_ctx* ctx, float* A_j /*3*V*V host*/, float* A_b /*2*6*6 host*/,
+                          float* pool /*V*6 host*/, float* unpool /*6*V host*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOCHA_HIP_H */

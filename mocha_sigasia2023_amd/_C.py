@@ -1,0 +1,81 @@
+"""ctypes binding of libmocha_hip.so (include/mocha_hip.h).
+
+There is deliberately no fallback: if the HIP library is missing or a call fails, a
+RuntimeError is raised.  The product path never imports the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmocha_hip.so")
+
+ABI_VERSION = 1
+
+
+class mocha_cfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "T", "V", "C_in", "patch", "dim",
+        "enc_depth", "enc_heads", "enc_dim_head", "enc_mlp",
+        "dec_depth", "dec_heads", "dec_dim_head", "dec_mlp", "layout")]
+
+
+_vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
+
+# name -> (restype, argtypes); every symbol include/mocha_hip.h declares
+SIGNATURES = {
+    "mocha_abi_version": (_i, []),
+    "mocha_create": (_i, [C.POINTER(mocha_cfg), _i, C.POINTER(_vp)]),
+    "mocha_destroy": (None, [_vp]),
+    "mocha_last_error": (C.c_char_p, [_vp]),
+    "mocha_load_weight": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
+    "mocha_finalize_weights": (_i, [_vp]),
+    "mocha_reserve": (_i, [_vp, _i]),
+    "mocha_pos_emb": (_i, [_vp, C.POINTER(_vp)]),
+    "mocha_embed": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "mocha_encoder": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mocha_mvn": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mocha_encode": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocha_decoder": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "mocha_to_mot": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mocha_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "mocha_forward_features": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mocha_bank_set": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "mocha_match": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "mocha_bank_gather": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mocha_characterize": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mocha_graph_constants": (_i, [_vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen the library and bind every declared symbol; raises RuntimeError when absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"libmocha_hip.so not found at {path}: build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or `make -C mocha_sigasia2023_amd/csrc`. "
+            "There is no CPU fallback.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:  # missing ROCm runtime etc.
+        raise RuntimeError(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mocha_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libmocha_hip.so ABI {lib.mocha_abi_version()} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(lib, ctx, rc: int, what: str):
+    if rc != 0:
+        msg = lib.mocha_last_error(ctx)
+        raise RuntimeError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,160 @@
+// Multi-head softmax attention over <= 96 tokens on gfx950, exact-f32 MFMA
+// (reference: Attention.forward, net/transformer.py:65-76).
+//
+// One 192-thread workgroup (3 waves) per (window, head).  Wave w owns query block 32w..32w+31.
+//   1. S^T = K · Q^T  (keys on the MFMA rows, queries on the lanes): with the query on the
+//      lane, the softmax over keys is a per-lane reduction over the accumulator registers
+//      plus one cross-half shuffle — no LDS round trip, no 32-lane butterflies.
+//   2. softmax in registers (max-subtracted, exact expf, division by the row sum).
+//   3. O^T = V^T · P^T: the accumulator tile P^T (keys in registers, queries on lanes) IS
+//      the B operand of v_mfma_f32_32x32x2_f32 register by register (k = key), so P never
+//      leaves the register file.  V is staged through LDS 64 head-dims at a time.
+// Tokens are padded 90 -> 96 with zero rows; padded keys are masked to -inf.
+#include "kernels.h"
+
+namespace mocha {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int NT = 96;       // padded token count (3 tiles of 32)
+static constexpr int LK = 36;       // LDS row stride for the K/Q chunks (32 + 4 pad)
+static constexpr int DV = 64;       // head dims of V staged per pass
+
+template <int DH>
+__global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * NT * LK];   // 27,648 B; V pass reuses it (96*64 floats)
+    float* Ks = smem;
+    float* Qs = smem + NT * LK;
+    float* Vs = smem;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int head = blockIdx.x, b = blockIdx.y;
+    const int n = p.n;
+
+    const float* qg = p.q + (size_t)b * n * p.ldq + head * DH;
+    const float* kg = p.k + (size_t)b * n * p.ldk + head * DH;
+    const float* vg = p.v + (size_t)b * n * p.ldv + head * DH;
+
+    // ---------------- phase 1: S^T[key][query] over DH in chunks of 32
+    f32x16 st[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+
+    for (int c = 0; c < DH / 32; ++c) {
+        // 96 rows x 8 float4 per matrix = 768 float4; 192 threads x 4
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 192 * i;
+            const int row = f >> 3, c4 = (f & 7) * 4;
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
+            if (row < n) {
+                kv = *reinterpret_cast<const f32x4*>(kg + (size_t)row * p.ldk + c * 32 + c4);
+                qv = *reinterpret_cast<const f32x4*>(qg + (size_t)row * p.ldq + c * 32 + c4);
+            }
+            *reinterpret_cast<f32x4*>(Ks + row * LK + c4) = kv;
+            *reinterpret_cast<f32x4*>(Qs + row * LK + c4) = qv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kgp = 0; kgp < 4; ++kgp) {
+            f32x4 a[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[t] = *reinterpret_cast<const f32x4*>(Ks + (t * 32 + l31) * LK + kgp * 8 + 4 * hh);
+            const f32x4 bq = *reinterpret_cast<const f32x4*>(Qs + (wave * 32 + l31) * LK + kgp * 8 + 4 * hh);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+                    st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][ks], bq[ks], st[t], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---------------- phase 2: softmax over keys for this lane's query
+    // st[t][r] = S[query = 32*wave + l31][key = 32t + (r&3) + 8(r>>2) + 4hh]
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const float sv = key < n ? st[t][r] * p.scale : -INFINITY;
+            st[t][r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = expf(st[t][r] - mx);
+            st[t][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32);
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] / sum;
+
+    // ---------------- phase 3: O^T[d][query] = sum_key V[key][d] * P^T[key][query]
+    const int query = wave * 32 + l31;
+    float* og = p.out + ((size_t)b * n + query) * p.ldo + head * DH;
+    for (int dp = 0; dp < DH / DV; ++dp) {
+        // stage V[:, dp*64 .. +64] as Vs[96][64]: 96 x 16 float4 = 1536; 192 threads x 8
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = tid + 192 * i;
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            f32x4 vv = {0.f, 0.f, 0.f, 0.f};
+            if (row < n) vv = *reinterpret_cast<const f32x4*>(vg + (size_t)row * p.ldv + dp * DV + c4);
+            *reinterpret_cast<f32x4*>(Vs + row * DV + c4) = vv;
+        }
+        __syncthreads();
+        f32x16 o[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const float av = Vs[key * DV + d * 32 + l31];      // A[i = d-col][k = key]
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, st[t][r], o[d], 0, 0, 0);
+                }
+            }
+        // o[d][r] = O[query][dcol = dp*64 + d*32 + (r&3) + 8(r>>2) + 4hh]: regs 4g..4g+3 are 4 consecutive dims
+        if (query < n) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 w = {o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(og + dp * DV + d * 32 + 8 * g + 4 * hh) = w;
+                }
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
+    if (p.B <= 0) return hipSuccess;
+    if (p.n > NT || p.n < 1) return hipErrorInvalidValue;
+    dim3 grid(p.heads, p.B);
+    if (p.dh == 128) hipLaunchKernelGGL((mocha_attention_f32<128>), grid, dim3(192), 0, s, p);
+    else if (p.dh == 256) hipLaunchKernelGGL((mocha_attention_f32<256>), grid, dim3(192), 0, s, p);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace mocha

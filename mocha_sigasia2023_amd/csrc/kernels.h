@@ -1,0 +1,82 @@
+// Internal launcher interface between the host-side context (mocha_api.cpp) and the gfx950
+// kernels (*.hip).  Not part of the C ABI (include/mocha_hip.h is).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mocha {
+
+// ---------------------------------------------------------------------------------------
+// fp32 MFMA GEMM:  C[M,N] = epilogue( Aop[M,K] · W[N,K]^T )
+//
+// Aop is either the plain row-major matrix A (lda) or an on-the-fly gather of a
+// (batch, time, node, channel) activation tensor that realises a temporal convolution with
+// reflect padding as a GEMM (net/blocks.py:112-118): for output row (b, t, v) and
+// k = tap*Cc + c the operand is
+//      ascale * sum_{j<R} src[(b, refl(t*stride + j + tap - pad, T_full) >> tshift, v), c]
+// R = 4, stride = 4 additionally folds AvgPool2d((4,1)) (model.py:47) into the operand;
+// tshift = 2 reads a nearest-x4-upsampled tensor (model.py:74) without materialising it.
+// ---------------------------------------------------------------------------------------
+struct GemmParams {
+    const float* A = nullptr;     // source activations
+    const float* W = nullptr;     // [N][K], k contiguous (nn.Linear / repacked conv layout)
+    float* C = nullptr;
+    const float* bias = nullptr;      // [N] or null
+    const float* rowbias = nullptr;   // [rb_mod][N] or null, indexed by (row % rb_mod)
+    const float* residual = nullptr;  // [M][ldr] or null, added after the activation
+    int M = 0, N = 0, K = 0;
+    int lda = 0, ldc = 0, ldr = 0;
+    int rb_mod = 1;
+    int act = 0;          // 0 none, 1 exact-erf GELU, 2 LeakyReLU(0.2)
+    int a_lrelu = 0;      // LeakyReLU(0.2) applied to the A operand as it is loaded
+    int gather = 0;       // 0 plain rows, 1 temporal gather
+    int T_out = 1, V = 1, ntaps = 1, pad = 0, stride = 1, R = 1, T_full = 1, tshift = 0, Cc = 0, T_src = 1;
+    float ascale = 1.f;
+    int ksplit = 1;               // >1: split K over gridDim.z, raw partial sums to C + z*slab_stride
+    long long slab_stride = 0;
+};
+hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+hipError_t gemm_init();           // one-time function attributes (dynamic LDS size)
+
+// ---------------------------------------------------------------------------------------
+// Multi-head attention over n (<= 96) tokens, one workgroup per (window, head)
+// (net/transformer.py:65-76): out[b, i, h*DH + d] = softmax_j(q_i·k_j * scale) v_j
+// ---------------------------------------------------------------------------------------
+struct AttnParams {
+    const float* q; const float* k; const float* v; float* out;
+    int ldq, ldk, ldv, ldo;       // row strides in floats
+    int B, heads, dh, n;
+    float scale;
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
+// Small bandwidth-bound kernels
+// ---------------------------------------------------------------------------------------
+// X (B,T,V,Cin) -> 1x1 conv Cin->64 + bias -> LeakyReLU -> hop-partitioned adjacency -> joint->part pool,
+// written as rows (b,t,p) x (k*64+c)   [model.py:44-46 front half, net/blocks.py:57-66,131]
+hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP /*3*V*6*/,
+                              float* out, int nframes, int V, int Cin, hipStream_t s);
+// rows (b,t,p) x 256 -> LeakyReLU -> body-part adjacency (2 hops) -> rows (b,t,w) x (k*256+c)
+hipError_t launch_body_front(const float* x, const float* A_b /*2*6*6*/, float* out, int rows6 /*B*15*/, hipStream_t s);
+// g rows (b,t',p) x (k*64+c) -> y2c rows (b,t',w) x 64 : sum_k sum_p AU[k][p][w] g[...]
+hipError_t launch_joint_expand(const float* g, const float* AU /*3*6*V*/, float* out, int nframes15, int V, hipStream_t s);
+// z rows x 64 -> LeakyReLU -> 1x1 conv 64->Cout + bias -> Y rows x Cout   [model.py:77-79]
+hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, float* Y, int rows, int Cout, hipStream_t s);
+// per (b, channel) instance norm over n tokens (net/transformer.py:13-20).
+//   out = (x-mean)/(std+eps); mean_out (B,256) optional; zn = (out - gm)/gs optional
+hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
+                           int B, int n, hipStream_t s);
+// AdaIN + the attention's mapping norm (net/transformer.py:108-113, 49-56):
+//   xad = (1+gamma)*IN(x)+beta ; qin = IN(xad) ; gb (B,512) = [gamma | beta]
+hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin, int B, int n, hipStream_t s);
+// bank row squared norms
+hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, hipStream_t s);
+// per query: argmin_n (bnorm[n] - 2*sum_z S[z][q][n]); then exact distance to the winner
+hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm,
+                         const float* query, const float* bank, int Q, int64_t N, int D,
+                         int32_t* idx, float* dist, hipStream_t s);
+// out[q] = src[idx[q]] rows of `cols` floats
+hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, int Q, int cols, hipStream_t s);
+
+}  // namespace mocha

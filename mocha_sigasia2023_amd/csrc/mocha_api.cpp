@@ -1,0 +1,794 @@
+// Host side of libmocha_hip.so: context, weight loading / repacking, workspace management and
+// the C-ABI entry points of include/mocha_hip.h.  Every function only enqueues work on the
+// caller's stream.  Reference citations are relative to the reference repository root.
+#include "../../include/mocha_hip.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace mocha;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+// ------------------------------------------------------------------ skeleton constants (row a14)
+// closed form of net/graph.py:116-131,290-312, computed in double
+struct Skeleton {
+    int V = 0;
+    std::vector<int> parents, part_of;
+    std::vector<double> A_j;   // [3][V][V]
+    std::vector<double> A_b;   // [2][6][6]
+    std::vector<double> pool;  // [V][6]
+    std::vector<double> unpool;// [6][V]
+};
+
+static std::vector<double> distance_adjacency(const std::vector<int>& parents, int max_hop) {
+    const int n = (int)parents.size();
+    std::vector<std::vector<int>> nbr(n);
+    for (int i = 0; i < n; ++i)
+        if (parents[i] >= 0) { nbr[i].push_back(parents[i]); nbr[parents[i]].push_back(i); }
+    std::vector<int> hop(n * n, 1 << 20);
+    for (int s = 0; s < n; ++s) {
+        std::deque<std::pair<int, int>> q;
+        std::vector<char> seen(n, 0);
+        hop[s * n + s] = 0; seen[s] = 1; q.push_back({s, 0});
+        while (!q.empty()) {
+            auto [v, d] = q.front(); q.pop_front();
+            if (d == max_hop) continue;
+            for (int u : nbr[v]) if (!seen[u]) { seen[u] = 1; hop[s * n + u] = d + 1; q.push_back({u, d + 1}); }
+        }
+    }
+    std::vector<double> A((size_t)(max_hop + 1) * n * n, 0.0);
+    for (int w = 0; w < n; ++w) {
+        int cnt = 0;
+        for (int v = 0; v < n; ++v) cnt += hop[v * n + w] <= max_hop;
+        for (int v = 0; v < n; ++v) {
+            const int h = hop[v * n + w];
+            if (h <= max_hop) A[((size_t)h * n + v) * n + w] = 1.0 / (double)cnt;
+        }
+    }
+    return A;
+}
+
+static bool make_skeleton(int layout, Skeleton& sk) {
+    // net/graph.py:65-79,401-417 ('mocha'); :18-31,329-345 ('mixamo')
+    static const int mocha_par[24] = {-1, 0, 1, 2, 3, 0, 5, 6, 7, 8, 9, 10, 11, 8, 13, 14, 8, 16, 17, 18, 0, 20, 21, 22};
+    static const int mocha_part[24] = {0, 1, 1, 1, 1, 0, 0, 0, 0, 2, 2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5};
+    static const int mix_par[22] = {-1, 0, 1, 2, 3, 4, 3, 6, 7, 8, 3, 10, 11, 12, 0, 14, 15, 16, 0, 18, 19, 20};
+    static const int mix_part[22] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5};
+    if (layout == 0) { sk.V = 24; sk.parents.assign(mocha_par, mocha_par + 24); sk.part_of.assign(mocha_part, mocha_part + 24); }
+    else if (layout == 1) { sk.V = 22; sk.parents.assign(mix_par, mix_par + 22); sk.part_of.assign(mix_part, mix_part + 22); }
+    else return false;
+    sk.A_j = distance_adjacency(sk.parents, 2);
+    sk.A_b = distance_adjacency({-1, 0, 0, 0, 0, 0}, 1);
+    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    for (int v = 0; v < sk.V; ++v) cnt[sk.part_of[v]]++;
+    sk.pool.assign((size_t)sk.V * 6, 0.0);
+    sk.unpool.assign((size_t)6 * sk.V, 0.0);
+    for (int v = 0; v < sk.V; ++v) {
+        // the reference forms 1/|part| in float32 (net/graph.py:459-461): keep that rounding
+        sk.pool[(size_t)v * 6 + sk.part_of[v]] = (double)(1.0f / (float)cnt[sk.part_of[v]]);
+        sk.unpool[(size_t)sk.part_of[v] * sk.V + v] = 1.0;
+    }
+    return true;
+}
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t n = 0;
+};
+
+}  // namespace
+
+struct mocha_ctx {
+    mocha_cfg cfg{};
+    int device = 0;
+    std::string err;
+    Skeleton sk;
+    std::map<std::string, HostTensor> host_w;
+    std::map<std::string, std::vector<int64_t>> expect;
+    bool finalized = false;
+
+    std::vector<float*> owned;                 // every hipMalloc'ed pointer
+    std::map<std::string, float*> w;           // repacked device weights by short name
+    int ntok = 90, nT15 = 15, dim = 256, d4 = 64;
+
+    // workspaces: sized for `chunk` windows; larger batches are processed chunk by chunk
+    int chunk = 0;
+    int max_chunk = 256;
+    std::map<std::string, DevBuf> ws;
+    DevBuf match_S;
+    int32_t* idx_ws = nullptr; size_t idx_ws_n = 0;
+
+    // bank
+    const float* bank_cnt = nullptr;
+    const float* bank_enc = nullptr;
+    float* bank_cnt_own = nullptr; float* bank_enc_own = nullptr; size_t bank_cap = 0;
+    float* bank_norm = nullptr; size_t bank_norm_cap = 0;
+    int64_t bank_N = 0;
+};
+
+namespace {
+
+int fail(mocha_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return fail((c), MOCHA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+int dev_alloc(mocha_ctx* c, float** out, size_t nfloats) {
+    void* p = nullptr;
+    HIPCHK(c, hipMalloc(&p, std::max<size_t>(nfloats, 4) * sizeof(float)));
+    *out = (float*)p;
+    c->owned.push_back((float*)p);
+    return 0;
+}
+
+int upload(mocha_ctx* c, const std::string& name, const std::vector<float>& v) {
+    float* d = nullptr;
+    int rc = dev_alloc(c, &d, v.size());
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->w[name] = d;
+    return 0;
+}
+
+void build_expectations(mocha_ctx* c) {
+    const mocha_cfg& g = c->cfg;
+    const int64_t d = g.dim, d4 = g.dim / g.patch, cin = g.C_in, V = g.V;
+    auto& e = c->expect;
+    e["pos_emb"] = {1, (int64_t)c->ntok, d};
+    e["mot_embedding.1.weight"] = {d4, cin, 1, 1};
+    e["mot_embedding.1.bias"] = {d4};
+    e["mot_embedding.2.blk.gcn.conv.weight"] = {3 * d, d4, 1, 1};
+    e["mot_embedding.2.blk.gcn.conv.bias"] = {3 * d};
+    e["mot_embedding.2.blk.tcn.weight"] = {d, d, 5, 1};
+    e["mot_embedding.2.blk.tcn.bias"] = {d};
+    e["mot_embedding.5.blk.gcn.conv.weight"] = {2 * d, d, 1, 1};
+    e["mot_embedding.5.blk.gcn.conv.bias"] = {2 * d};
+    e["mot_embedding.5.blk.tcn.weight"] = {d, d, 3, 1};
+    e["mot_embedding.5.blk.tcn.bias"] = {d};
+    for (int dec = 0; dec < 2; ++dec) {
+        const char* nm = dec ? "decoder" : "encoder";
+        const int depth = dec ? g.dec_depth : g.enc_depth;
+        const int64_t inner = dec ? (int64_t)g.dec_heads * g.dec_dim_head : (int64_t)g.enc_heads * g.enc_dim_head;
+        const int64_t mlp = dec ? g.dec_mlp : g.enc_mlp;
+        for (int l = 0; l < depth; ++l) {
+            std::string p = std::string(nm) + ".layers." + std::to_string(l);
+            if (dec) {
+                e[p + ".0.style.2.weight"] = {2 * d, d};
+                e[p + ".0.style.2.bias"] = {2 * d};
+                e[p + ".0.style.4.weight"] = {2 * d, 2 * d};
+                e[p + ".0.style.4.bias"] = {2 * d};
+            }
+            e[p + ".1.to_q.1.weight"] = {inner, d};
+            e[p + ".1.to_k.1.weight"] = {inner, d};
+            e[p + ".1.to_v.weight"] = {inner, d};
+            e[p + ".1.to_out.0.weight"] = {d, inner};
+            e[p + ".1.to_out.0.bias"] = {d};
+            e[p + ".2.net.0.weight"] = {mlp, d};
+            e[p + ".2.net.0.bias"] = {mlp};
+            e[p + ".2.net.3.weight"] = {d, mlp};
+            e[p + ".2.net.3.bias"] = {d};
+        }
+    }
+    e["to_mot.1.blk.gcn.conv.weight"] = {2 * d, d, 1, 1};
+    e["to_mot.1.blk.gcn.conv.bias"] = {2 * d};
+    e["to_mot.1.blk.tcn.weight"] = {d, d, 3, 1};
+    e["to_mot.1.blk.tcn.bias"] = {d};
+    e["to_mot.4.blk.gcn.conv.weight"] = {3 * d4, d, 1, 1};
+    e["to_mot.4.blk.gcn.conv.bias"] = {3 * d4};
+    e["to_mot.4.blk.tcn.weight"] = {d4, d4, 5, 1};
+    e["to_mot.4.blk.tcn.bias"] = {d4};
+    e["to_mot.6.weight"] = {cin, d4, 1, 1};
+    e["to_mot.6.bias"] = {cin};
+    (void)V;
+}
+
+// registered buffers of the reference state_dict: accepted and cross-checked, never used
+bool is_graph_buffer(const std::string& n) {
+    return n == "mot_embedding.2.A_j" || n == "to_mot.4.A_j" || n == "mot_embedding.5.A_b" || n == "to_mot.1.A_b" ||
+           n == "mot_embedding.3.weight" || n == "to_mot.3.weight";
+}
+
+int check_graph_buffer(mocha_ctx* c, const std::string& n, const float* host, const int64_t* shape, int ndim) {
+    const Skeleton& sk = c->sk;
+    const std::vector<double>* ref = nullptr;
+    std::vector<int64_t> shp;
+    if (n.size() > 3 && n.compare(n.size() - 3, 3, "A_j") == 0) { ref = &sk.A_j; shp = {3, sk.V, sk.V}; }
+    else if (n.size() > 3 && n.compare(n.size() - 3, 3, "A_b") == 0) { ref = &sk.A_b; shp = {2, 6, 6}; }
+    else if (n == "mot_embedding.3.weight") { ref = &sk.pool; shp = {sk.V, 6}; }
+    else { ref = &sk.unpool; shp = {6, sk.V}; }
+    if ((int)shp.size() != ndim) return fail(c, MOCHA_ERR_WEIGHT, "%s: rank %d, expected %zu", n.c_str(), ndim, shp.size());
+    for (int i = 0; i < ndim; ++i)
+        if (shape[i] != shp[i]) return fail(c, MOCHA_ERR_WEIGHT, "%s: dim %d is %lld, expected %lld", n.c_str(), i, (long long)shape[i], (long long)shp[i]);
+    for (size_t i = 0; i < ref->size(); ++i)
+        if (std::fabs((double)host[i] - (*ref)[i]) > 1e-6)
+            return fail(c, MOCHA_ERR_WEIGHT, "%s: graph constant differs from the regenerated one at %zu (%g vs %g)", n.c_str(), i, host[i], (*ref)[i]);
+    return 0;
+}
+
+const std::vector<float>& W(mocha_ctx* c, const std::string& n) { return c->host_w.at(n).data; }
+
+// [co][tap*Cin + ci] <- conv weight (Cout, Cin, taps, 1)
+std::vector<float> repack_tcn(const std::vector<float>& w, int cout, int cin, int taps) {
+    std::vector<float> o((size_t)cout * taps * cin);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < taps; ++t) o[((size_t)co * taps + t) * cin + ci] = w[((size_t)co * cin + ci) * taps + t];
+    return o;
+}
+// adjacency-first form of SpatialConv (net/blocks.py:57-66): [co][k*Cin + ci] <- conv weight (K*Cout, Cin, 1, 1)
+std::vector<float> repack_gcn_adjfirst(const std::vector<float>& w, int K, int cout, int cin) {
+    std::vector<float> o((size_t)cout * K * cin);
+    for (int k = 0; k < K; ++k)
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci) o[(size_t)co * K * cin + (size_t)k * cin + ci] = w[((size_t)k * cout + co) * cin + ci];
+    return o;
+}
+
+int ensure_ws(mocha_ctx* c, int B) {
+    const int want = std::min(B, c->max_chunk);
+    if (c->chunk >= want && c->chunk > 0) return 0;
+    if (c->chunk > 0) HIPCHK(c, hipDeviceSynchronize());      // growing: earlier work may still read the old buffers
+    // per-window float counts
+    const int V = c->cfg.V;
+    const size_t T = 90 * 256;
+    const std::pair<const char*, size_t> plan[] = {
+        {"hbar", 360 * 192}, {"ybar", 360 * 256}, {"x5", T}, {"xA", 90 * 512}, {"t1", T}, {"xa", T}, {"xb", T},
+        {"qkv", 90 * 3072}, {"ao", 90 * 1024}, {"hff", 90 * 512}, {"kin", T}, {"xad", T}, {"qin", T},
+        {"smean", 256}, {"s1", 512}, {"gb", 512}, {"g", 90 * 192}, {"y2c", (size_t)15 * V * 64},
+        {"z", (size_t)60 * V * 64}, {"enc_s", T}, {"enc_c", T}, {"cnt", T}, {"qnm", T}, {"sel", T}, {"dec", T},
+    };
+    // free old workspace
+    for (auto& kv : c->ws) {
+        if (kv.second.p) {
+            (void)hipFree(kv.second.p);
+            c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), kv.second.p), c->owned.end());
+        }
+    }
+    c->ws.clear();
+    for (auto& pl : plan) {
+        DevBuf b; b.n = pl.second * (size_t)want;
+        int rc = dev_alloc(c, &b.p, b.n);
+        if (rc) return rc;
+        c->ws[pl.first] = b;
+    }
+    if (c->idx_ws) (void)hipFree(c->idx_ws);
+    void* ip = nullptr;
+    HIPCHK(c, hipMalloc(&ip, sizeof(int32_t) * (size_t)want));
+    c->idx_ws = (int32_t*)ip; c->idx_ws_n = want;
+    c->chunk = want;
+    return 0;
+}
+
+float* WS(mocha_ctx* c, const char* n) { return c->ws.at(n).p; }
+float* DW(mocha_ctx* c, const std::string& n) { return c->w.at(n); }
+
+#define KCHK(c, expr)                                                                                        \
+    do {                                                                                                     \
+        hipError_t e__ = (expr);                                                                             \
+        if (e__ != hipSuccess)                                                                               \
+            return fail((c), MOCHA_ERR_HIP, "launch %s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+
+GemmParams plain(const float* A, int lda, const float* Wt, float* C, int ldc, int M, int N, int K) {
+    GemmParams p;
+    p.A = A; p.lda = lda; p.W = Wt; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K;
+    return p;
+}
+
+// ---------------------------------------------------------------- stage pipelines on one chunk
+// mot_embedding (model.py:42-50) for b windows: X -> tokens (b*90, 256)
+int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, hipStream_t s) {
+    const int V = c->cfg.V;
+    // conv1 + lrelu + adjacency + joint->part pool (commuted)                  model.py:44-46
+    KCHK(c, launch_embed_front(X, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar"), b * 60, V, c->cfg.C_in, s));
+    // gcn 1x1 conv on the pooled operand: (b*360, 192) x (256,192)^T + pooled bias
+    GemmParams g1 = plain(WS(c, "hbar"), 192, DW(c, "emb.Wg"), WS(c, "ybar"), 256, b * 360, 256, 192);
+    g1.rowbias = DW(c, "emb.rbg"); g1.rb_mod = 6;
+    KCHK(c, launch_gemm(g1, s));
+    // temporal conv k=5 (reflect) fused with AvgPool2d((4,1)):  (b*90, 5*256) x (256, 1280)^T   blocks.py:112-118, model.py:47
+    GemmParams g2 = plain(WS(c, "ybar"), 256, DW(c, "emb.Wt"), WS(c, "x5"), 256, b * 90, 256, 1280);
+    g2.gather = 1; g2.T_out = 15; g2.V = 6; g2.ntaps = 5; g2.pad = 2; g2.stride = 4; g2.R = 4; g2.T_full = 60;
+    g2.tshift = 0; g2.Cc = 256; g2.T_src = 60; g2.ascale = 0.25f; g2.bias = DW(c, "emb.bt");
+    KCHK(c, launch_gemm(g2, s));
+    // body block                                                               model.py:48,137-162
+    KCHK(c, launch_body_front(WS(c, "x5"), DW(c, "A_b"), WS(c, "xA"), b * 15, s));
+    GemmParams g3 = plain(WS(c, "xA"), 512, DW(c, "emb.Wgb"), WS(c, "t1"), 256, b * 90, 256, 512);
+    g3.rowbias = DW(c, "emb.rbb"); g3.rb_mod = 6;
+    KCHK(c, launch_gemm(g3, s));
+    GemmParams g4 = plain(WS(c, "t1"), 256, DW(c, "emb.Wtb"), tokens, 256, b * 90, 256, 768);
+    g4.gather = 1; g4.T_out = 15; g4.V = 6; g4.ntaps = 3; g4.pad = 1; g4.stride = 1; g4.R = 1; g4.T_full = 15;
+    g4.tshift = 0; g4.Cc = 256; g4.T_src = 15; g4.bias = DW(c, "emb.btb");
+    if (add_pos) { g4.rowbias = DW(c, "pos_emb"); g4.rb_mod = 90; }           // model.py:88
+    KCHK(c, launch_gemm(g4, s));
+    return 0;
+}
+
+// one transformer layer's attention output projection + FF (net/transformer.py:91-94), shared by enc/dec
+int run_out_ff(mocha_ctx* c, const std::string& p, const float* ao, int inner, const float* resid, int M, int mlp,
+               float* out, hipStream_t s) {
+    GemmParams o = plain(ao, inner, DW(c, p + ".Wo"), WS(c, "xb"), 256, M, 256, inner);
+    o.bias = DW(c, p + ".bo"); o.residual = resid; o.ldr = 256;
+    KCHK(c, launch_gemm(o, s));
+    GemmParams f1 = plain(WS(c, "xb"), 256, DW(c, p + ".W1"), WS(c, "hff"), mlp, M, mlp, 256);
+    f1.bias = DW(c, p + ".b1"); f1.act = 1;
+    KCHK(c, launch_gemm(f1, s));
+    GemmParams f2 = plain(WS(c, "hff"), mlp, DW(c, p + ".W2"), out, 256, M, 256, mlp);
+    f2.bias = DW(c, p + ".b2"); f2.residual = WS(c, "xb"); f2.ldr = 256;
+    KCHK(c, launch_gemm(f2, s));
+    return 0;
+}
+
+// encoder (model.py:53-59; net/transformer.py:90-95 with adain=False)
+int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStream_t s) {
+    const int M = b * 90, H = c->cfg.enc_heads, DH = c->cfg.enc_dim_head, inner = H * DH;
+    const float* x = tokens;
+    for (int l = 0; l < c->cfg.enc_depth; ++l) {
+        const std::string p = "enc" + std::to_string(l);
+        GemmParams q = plain(x, 256, DW(c, p + ".Wqkv"), WS(c, "qkv"), 3 * inner, M, 3 * inner, 256);
+        KCHK(c, launch_gemm(q, s));
+        AttnParams a{WS(c, "qkv"), WS(c, "qkv") + inner, WS(c, "qkv") + 2 * inner, WS(c, "ao"),
+                     3 * inner, 3 * inner, 3 * inner, inner, b, H, DH, 90, (float)std::pow((double)DH, -0.5)};
+        KCHK(c, launch_attention(a, s));
+        float* out = (l == c->cfg.enc_depth - 1) ? encoded : WS(c, "xa");
+        int rc = run_out_ff(c, p, WS(c, "ao"), inner, x, M, c->cfg.enc_mlp, out, s);
+        if (rc) return rc;
+        x = out;
+    }
+    return 0;
+}
+
+// decoder (model.py:62-68; net/transformer.py:90-121 with adain=True)
+int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* outp, hipStream_t s) {
+    const int M = b * 90, H = c->cfg.dec_heads, DH = c->cfg.dec_dim_head, inner = H * DH;
+    // IN(cha) feeds every layer's keys; mean over tokens of cha feeds every layer's style MLP
+    KCHK(c, launch_instnorm(cha, WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s));
+    const float* x = src;
+    float* qb = WS(c, "qkv");
+    float* kb = qb + (size_t)M * inner;
+    float* vb = kb + (size_t)M * inner;
+    for (int l = 0; l < c->cfg.dec_depth; ++l) {
+        const std::string p = "dec" + std::to_string(l);
+        // style MLP: Linear 256->512, LeakyReLU, Linear 512->512           net/transformer.py:102-107
+        GemmParams s1 = plain(WS(c, "smean"), 256, DW(c, p + ".Ws1"), WS(c, "s1"), 512, b, 512, 256);
+        s1.bias = DW(c, p + ".bs1"); s1.act = 2;
+        KCHK(c, launch_gemm(s1, s));
+        GemmParams s2 = plain(WS(c, "s1"), 512, DW(c, p + ".Ws2"), WS(c, "gb"), 512, b, 512, 512);
+        s2.bias = DW(c, p + ".bs2");
+        KCHK(c, launch_gemm(s2, s));
+        KCHK(c, launch_adain(x, WS(c, "gb"), WS(c, "xad"), WS(c, "qin"), b, 90, s));
+        GemmParams gq = plain(WS(c, "qin"), 256, DW(c, p + ".Wq"), qb, inner, M, inner, 256);
+        KCHK(c, launch_gemm(gq, s));
+        GemmParams gk = plain(WS(c, "kin"), 256, DW(c, p + ".Wk"), kb, inner, M, inner, 256);
+        KCHK(c, launch_gemm(gk, s));
+        GemmParams gv = plain(cha, 256, DW(c, p + ".Wv"), vb, inner, M, inner, 256);
+        KCHK(c, launch_gemm(gv, s));
+        AttnParams a{qb, kb, vb, WS(c, "ao"), inner, inner, inner, inner, b, H, DH, 90, (float)std::pow((double)DH, -0.5)};
+        KCHK(c, launch_attention(a, s));
+        float* out = (l == c->cfg.dec_depth - 1) ? outp : WS(c, "xa");
+        int rc = run_out_ff(c, p, WS(c, "ao"), inner, WS(c, "xad"), M, c->cfg.dec_mlp, out, s);
+        if (rc) return rc;
+        x = out;
+    }
+    return 0;
+}
+
+// to_mot (model.py:71-80)
+int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s) {
+    const int V = c->cfg.V, M = b * 90;
+    KCHK(c, launch_body_front(tokens, DW(c, "A_b"), WS(c, "xA"), b * 15, s));
+    GemmParams g1 = plain(WS(c, "xA"), 512, DW(c, "mot.Wgb"), WS(c, "t1"), 256, M, 256, 512);
+    g1.rowbias = DW(c, "mot.rbb"); g1.rb_mod = 6;
+    KCHK(c, launch_gemm(g1, s));
+    GemmParams g2 = plain(WS(c, "t1"), 256, DW(c, "mot.Wtb"), WS(c, "x5"), 256, M, 256, 768);
+    g2.gather = 1; g2.T_out = 15; g2.V = 6; g2.ntaps = 3; g2.pad = 1; g2.stride = 1; g2.R = 1; g2.T_full = 15;
+    g2.tshift = 0; g2.Cc = 256; g2.T_src = 15; g2.bias = DW(c, "mot.btb");
+    KCHK(c, launch_gemm(g2, s));
+    // joint block gcn conv at body-part resolution (upsample + unpool only copy rows):  lrelu -> 256 -> 3*64
+    GemmParams g3 = plain(WS(c, "x5"), 256, DW(c, "mot.Wg2"), WS(c, "g"), 192, M, 192, 256);
+    g3.a_lrelu = 1; g3.bias = DW(c, "mot.bg2");
+    KCHK(c, launch_gemm(g3, s));
+    KCHK(c, launch_joint_expand(WS(c, "g"), DW(c, "AU"), WS(c, "y2c"), b * 15, V, s));
+    // temporal conv k=5 over the x4-upsampled frames, read through the gather (t >> 2)
+    GemmParams g4 = plain(WS(c, "y2c"), 64, DW(c, "mot.Wt2"), WS(c, "z"), 64, b * 60 * V, 64, 320);
+    g4.gather = 1; g4.T_out = 60; g4.V = V; g4.ntaps = 5; g4.pad = 2; g4.stride = 1; g4.R = 1; g4.T_full = 60;
+    g4.tshift = 2; g4.Cc = 64; g4.T_src = 15; g4.bias = DW(c, "mot.bt2");
+    KCHK(c, launch_gemm(g4, s));
+    KCHK(c, launch_final_proj(WS(c, "z"), DW(c, "mot.W6"), DW(c, "mot.b6"), Y, b * 60 * V, c->cfg.C_in, s));
+    return 0;
+}
+
+int ready(mocha_ctx* c, int B) {
+    if (!c) return MOCHA_ERR_ARG;
+    if (!c->finalized) return fail(c, MOCHA_ERR_STATE, "weights not finalised: call mocha_finalize_weights first");
+    if (B < 0) return fail(c, MOCHA_ERR_ARG, "negative batch");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (B > 0) return ensure_ws(c, B);
+    return 0;
+}
+
+int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, hipStream_t s) {
+    if (!c->bank_cnt || c->bank_N <= 0) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
+    const int D = 90 * 256;
+    const int64_t N = c->bank_N;
+    const long long tiles = (long long)((Q + 127) / 128) * ((N + 127) / 128);
+    int ksplit = (int)std::min<long long>(16, std::max<long long>(1, (768 + tiles - 1) / tiles));
+    const size_t need = (size_t)ksplit * Q * N;
+    if (c->match_S.n < need) {
+        if (c->match_S.p) { (void)hipFree(c->match_S.p); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), c->match_S.p), c->owned.end()); }
+        c->match_S = DevBuf{};
+        int rc = dev_alloc(c, &c->match_S.p, need);
+        if (rc) return rc;
+        c->match_S.n = need;
+    }
+    GemmParams g = plain(qnm, D, c->bank_cnt, c->match_S.p, (int)N, Q, (int)N, D);
+    g.ksplit = ksplit; g.slab_stride = (long long)Q * N;
+    KCHK(c, launch_gemm(g, s));
+    KCHK(c, launch_argmin(c->match_S.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_cnt, Q, N, D, idx, dist, s));
+    return 0;
+}
+
+}  // namespace
+
+// =========================================================================================== C ABI
+extern "C" {
+
+int mocha_abi_version(void) { return 1; }
+
+const char* mocha_last_error(const mocha_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
+    if (!cfg || !out) return fail(nullptr, MOCHA_ERR_ARG, "null argument");
+    *out = nullptr;
+    // the kernels are specialised for the shipped architecture (configs/config.yaml:13-31)
+    if (cfg->T != 60 || cfg->patch != 4 || cfg->dim != 256 || cfg->C_in != 15)
+        return fail(nullptr, MOCHA_ERR_ARG, "unsupported T/patch/dim/C_in (%d/%d/%d/%d), need 60/4/256/15", cfg->T, cfg->patch, cfg->dim, cfg->C_in);
+    if (cfg->enc_dim_head != 128 && cfg->enc_dim_head != 256) return fail(nullptr, MOCHA_ERR_ARG, "enc_dim_head must be 128 or 256");
+    if (cfg->dec_dim_head != 128 && cfg->dec_dim_head != 256) return fail(nullptr, MOCHA_ERR_ARG, "dec_dim_head must be 128 or 256");
+    if (cfg->enc_heads * cfg->enc_dim_head > 1024 || cfg->dec_heads * cfg->dec_dim_head > 1024 || cfg->enc_heads < 1 || cfg->dec_heads < 1)
+        return fail(nullptr, MOCHA_ERR_ARG, "heads*dim_head must be in [128, 1024]");
+    if (cfg->enc_mlp != 512 || cfg->dec_mlp != 512) return fail(nullptr, MOCHA_ERR_ARG, "mlp_dim must be 512");
+    if (cfg->enc_depth < 1 || cfg->enc_depth > 8 || cfg->dec_depth < 1 || cfg->dec_depth > 8) return fail(nullptr, MOCHA_ERR_ARG, "depth must be in [1, 8]");
+    mocha_ctx* c = new mocha_ctx();
+    c->cfg = *cfg; c->device = device;
+    if (!make_skeleton(cfg->layout, c->sk) || c->sk.V != cfg->V) {
+        int v = c->sk.V; delete c;
+        return fail(nullptr, MOCHA_ERR_ARG, "layout %d has %d joints, cfg.V = %d (0 = mocha/24, 1 = mixamo/22)", cfg->layout, v, cfg->V);
+    }
+    build_expectations(c);
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = gemm_init();
+    if (e != hipSuccess) { delete c; return fail(nullptr, MOCHA_ERR_HIP, "device %d init failed: %s", device, hipGetErrorString(e)); }
+    *out = c;
+    return 0;
+}
+
+void mocha_destroy(mocha_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (float* p : c->owned) (void)hipFree(p);
+    if (c->idx_ws) (void)hipFree(c->idx_ws);
+    delete c;
+}
+
+int mocha_load_weight(mocha_ctx* c, const char* name, const float* host, const int64_t* shape, int ndim) {
+    if (!c || !name || !host || !shape) return fail(c, MOCHA_ERR_ARG, "null argument");
+    const std::string n(name);
+    if (is_graph_buffer(n)) return check_graph_buffer(c, n, host, shape, ndim);
+    auto it = c->expect.find(n);
+    if (it == c->expect.end()) return fail(c, MOCHA_ERR_WEIGHT, "unknown weight name '%s'", name);
+    if ((int)it->second.size() != ndim) return fail(c, MOCHA_ERR_WEIGHT, "%s: rank %d, expected %zu", name, ndim, it->second.size());
+    size_t cnt = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] != it->second[i]) return fail(c, MOCHA_ERR_WEIGHT, "%s: dim %d is %lld, expected %lld", name, i, (long long)shape[i], (long long)it->second[i]);
+        cnt *= (size_t)shape[i];
+    }
+    HostTensor t; t.data.assign(host, host + cnt); t.shape.assign(shape, shape + ndim);
+    c->host_w[n] = std::move(t);
+    c->finalized = false;
+    return 0;
+}
+
+int mocha_finalize_weights(mocha_ctx* c) {
+    if (!c) return MOCHA_ERR_ARG;
+    for (auto& kv : c->expect)
+        if (!c->host_w.count(kv.first)) return fail(c, MOCHA_ERR_STATE, "missing weight '%s'", kv.first.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    const Skeleton& sk = c->sk;
+    const int V = sk.V;
+    int rc = 0;
+    auto up = [&](const std::string& n, const std::vector<float>& v) { if (!rc) rc = upload(c, n, v); };
+    auto f32 = [](const std::vector<double>& v) { return std::vector<float>(v.begin(), v.end()); };
+
+    // ---- graph operators
+    // AP[k][v][p] = sum_w A_j[k][v][w] pool[w][p]   (adjacency then joint->part mean, graph.py:463-465)
+    std::vector<double> AP((size_t)3 * V * 6, 0.0), APsum(3 * 6, 0.0);
+    for (int k = 0; k < 3; ++k)
+        for (int v = 0; v < V; ++v)
+            for (int p = 0; p < 6; ++p) {
+                double a = 0;
+                for (int w = 0; w < V; ++w) a += (double)(float)sk.A_j[((size_t)k * V + v) * V + w] * sk.pool[(size_t)w * 6 + p];
+                AP[((size_t)k * V + v) * 6 + p] = a;
+                APsum[k * 6 + p] += a;
+            }
+    up("AP", f32(AP));
+    // AU[k][p][w] = sum_{v in part p} A_j[k][v][w]    (part->joint copy then adjacency, graph.py:606-608)
+    std::vector<double> AU((size_t)3 * 6 * V, 0.0);
+    for (int k = 0; k < 3; ++k)
+        for (int v = 0; v < V; ++v)
+            for (int w = 0; w < V; ++w) AU[((size_t)k * 6 + sk.part_of[v]) * V + w] += (double)(float)sk.A_j[((size_t)k * V + v) * V + w];
+    up("AU", f32(AU));
+    up("A_b", f32(sk.A_b));
+    double Absum[2 * 6];
+    for (int k = 0; k < 2; ++k)
+        for (int w = 0; w < 6; ++w) { double a = 0; for (int v = 0; v < 6; ++v) a += (double)(float)sk.A_b[(k * 6 + v) * 6 + w]; Absum[k * 6 + w] = a; }
+
+    // ---- mot_embedding
+    up("pos_emb", W(c, "pos_emb"));
+    up("emb.W1", W(c, "mot_embedding.1.weight"));
+    up("emb.b1", W(c, "mot_embedding.1.bias"));
+    up("emb.Wg", repack_gcn_adjfirst(W(c, "mot_embedding.2.blk.gcn.conv.weight"), 3, 256, 64));
+    {
+        const auto& bg = W(c, "mot_embedding.2.blk.gcn.conv.bias");
+        std::vector<float> rb(6 * 256);
+        for (int p = 0; p < 6; ++p)
+            for (int co = 0; co < 256; ++co) { double a = 0; for (int k = 0; k < 3; ++k) a += (double)bg[k * 256 + co] * APsum[k * 6 + p]; rb[p * 256 + co] = (float)a; }
+        up("emb.rbg", rb);
+    }
+    up("emb.Wt", repack_tcn(W(c, "mot_embedding.2.blk.tcn.weight"), 256, 256, 5));
+    up("emb.bt", W(c, "mot_embedding.2.blk.tcn.bias"));
+    for (int which = 0; which < 2; ++which) {
+        const std::string src = which ? "to_mot.1.blk." : "mot_embedding.5.blk.";
+        const std::string dst = which ? "mot." : "emb.";
+        up(dst + "Wgb", repack_gcn_adjfirst(W(c, src + "gcn.conv.weight"), 2, 256, 256));
+        const auto& bg = W(c, src + "gcn.conv.bias");
+        std::vector<float> rb(6 * 256);
+        for (int w = 0; w < 6; ++w)
+            for (int co = 0; co < 256; ++co) { double a = 0; for (int k = 0; k < 2; ++k) a += (double)bg[k * 256 + co] * Absum[k * 6 + w]; rb[w * 256 + co] = (float)a; }
+        up(dst + "rbb", rb);
+        up(dst + "Wtb", repack_tcn(W(c, src + "tcn.weight"), 256, 256, 3));
+        up(dst + "btb", W(c, src + "tcn.bias"));
+    }
+    // ---- transformers
+    for (int l = 0; l < c->cfg.enc_depth; ++l) {
+        const std::string s = "encoder.layers." + std::to_string(l), d = "enc" + std::to_string(l);
+        std::vector<float> qkv = W(c, s + ".1.to_q.1.weight");
+        const auto& k = W(c, s + ".1.to_k.1.weight"); const auto& v = W(c, s + ".1.to_v.weight");
+        qkv.insert(qkv.end(), k.begin(), k.end()); qkv.insert(qkv.end(), v.begin(), v.end());
+        up(d + ".Wqkv", qkv);
+        up(d + ".Wo", W(c, s + ".1.to_out.0.weight")); up(d + ".bo", W(c, s + ".1.to_out.0.bias"));
+        up(d + ".W1", W(c, s + ".2.net.0.weight")); up(d + ".b1", W(c, s + ".2.net.0.bias"));
+        up(d + ".W2", W(c, s + ".2.net.3.weight")); up(d + ".b2", W(c, s + ".2.net.3.bias"));
+    }
+    for (int l = 0; l < c->cfg.dec_depth; ++l) {
+        const std::string s = "decoder.layers." + std::to_string(l), d = "dec" + std::to_string(l);
+        up(d + ".Ws1", W(c, s + ".0.style.2.weight")); up(d + ".bs1", W(c, s + ".0.style.2.bias"));
+        up(d + ".Ws2", W(c, s + ".0.style.4.weight")); up(d + ".bs2", W(c, s + ".0.style.4.bias"));
+        up(d + ".Wq", W(c, s + ".1.to_q.1.weight")); up(d + ".Wk", W(c, s + ".1.to_k.1.weight")); up(d + ".Wv", W(c, s + ".1.to_v.weight"));
+        up(d + ".Wo", W(c, s + ".1.to_out.0.weight")); up(d + ".bo", W(c, s + ".1.to_out.0.bias"));
+        up(d + ".W1", W(c, s + ".2.net.0.weight")); up(d + ".b1", W(c, s + ".2.net.0.bias"));
+        up(d + ".W2", W(c, s + ".2.net.3.weight")); up(d + ".b2", W(c, s + ".2.net.3.bias"));
+    }
+    // ---- to_mot joint block + head
+    up("mot.Wg2", W(c, "to_mot.4.blk.gcn.conv.weight")); up("mot.bg2", W(c, "to_mot.4.blk.gcn.conv.bias"));
+    up("mot.Wt2", repack_tcn(W(c, "to_mot.4.blk.tcn.weight"), 64, 64, 5)); up("mot.bt2", W(c, "to_mot.4.blk.tcn.bias"));
+    up("mot.W6", W(c, "to_mot.6.weight")); up("mot.b6", W(c, "to_mot.6.bias"));
+    if (rc) return rc;
+    c->finalized = true;
+    return 0;
+}
+
+int mocha_reserve(mocha_ctx* c, int max_batch) {
+    if (!c || max_batch < 1) return fail(c, MOCHA_ERR_ARG, "max_batch must be >= 1");
+    HIPCHK(c, hipSetDevice(c->device));
+    c->max_chunk = max_batch;
+    if (c->chunk > max_batch) {           // shrink: drop the larger arena first
+        HIPCHK(c, hipDeviceSynchronize());
+        c->chunk = 0;
+    }
+    return ensure_ws(c, max_batch);
+}
+
+int mocha_pos_emb(mocha_ctx* c, const float** dev_ptr) {
+    if (!c || !dev_ptr) return MOCHA_ERR_ARG;
+    if (!c->finalized) return fail(c, MOCHA_ERR_STATE, "weights not finalised");
+    *dev_ptr = DW(c, "pos_emb");
+    return 0;
+}
+
+int mocha_graph_constants(mocha_ctx* c, float* A_j, float* A_b, float* pool, float* unpool) {
+    if (!c) return MOCHA_ERR_ARG;
+    const Skeleton& sk = c->sk;
+    if (A_j) for (size_t i = 0; i < sk.A_j.size(); ++i) A_j[i] = (float)sk.A_j[i];
+    if (A_b) for (size_t i = 0; i < sk.A_b.size(); ++i) A_b[i] = (float)sk.A_b[i];
+    if (pool) for (size_t i = 0; i < sk.pool.size(); ++i) pool[i] = (float)sk.pool[i];
+    if (unpool) for (size_t i = 0; i < sk.unpool.size(); ++i) unpool[i] = (float)sk.unpool[i];
+    return 0;
+}
+
+int mocha_embed(mocha_ctx* c, const float* X, int B, float* tokens, int add_pos, void* stream) {
+    int rc = ready(c, B); if (rc) return rc;
+    const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in, ts = 90 * 256;
+    for (int b0 = 0; b0 < B; b0 += c->chunk) {
+        const int b = std::min(c->chunk, B - b0);
+        rc = run_embed(c, X + b0 * xs, b, tokens + b0 * ts, add_pos != 0, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int mocha_encoder(mocha_ctx* c, const float* tokens, int B, float* encoded, void* stream) {
+    int rc = ready(c, B); if (rc) return rc;
+    const size_t ts = 90 * 256;
+    for (int b0 = 0; b0 < B; b0 += c->chunk) {
+        const int b = std::min(c->chunk, B - b0);
+        rc = run_encoder(c, tokens + b0 * ts, b, encoded + b0 * ts, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int mocha_mvn(mocha_ctx* c, const float* encoded, int B, float* cnt, const float* cnt_mean, const float* cnt_std,
+              float* cnt_nm, void* stream) {
+    if (!c) return MOCHA_ERR_ARG;                      // needs no weights: usable on a bare context
+    if (!encoded || !cnt || B < 0) return fail(c, MOCHA_ERR_ARG, "bad mvn arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool zn = cnt_nm && cnt_mean && cnt_std;
+    KCHK(c, launch_instnorm(encoded, cnt, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr, zn ? cnt_nm : nullptr, B, 90, (hipStream_t)stream));
+    return 0;
+}
+
+int mocha_encode(mocha_ctx* c, const float* X, int B, float* encoded, float* cnt, const float* cnt_mean,
+                 const float* cnt_std, float* cnt_nm, void* stream) {
+    int rc = ready(c, B); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in, ts = 90 * 256;
+    const bool zn = cnt && cnt_nm && cnt_mean && cnt_std;
+    for (int b0 = 0; b0 < B; b0 += c->chunk) {
+        const int b = std::min(c->chunk, B - b0);
+        rc = run_embed(c, X + b0 * xs, b, WS(c, "x5"), true, s);      // x5 is free again once the body block has read it
+        if (rc) return rc;
+        rc = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s);
+        if (rc) return rc;
+        if (cnt)
+            KCHK(c, launch_instnorm(encoded + b0 * ts, cnt + b0 * ts, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
+                                    zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
+    }
+    return 0;
+}
+
+int mocha_decoder(mocha_ctx* c, const float* src_enc, const float* cha_enc, int B, float* out, void* stream) {
+    int rc = ready(c, B); if (rc) return rc;
+    const size_t ts = 90 * 256;
+    for (int b0 = 0; b0 < B; b0 += c->chunk) {
+        const int b = std::min(c->chunk, B - b0);
+        rc = run_decoder(c, src_enc + b0 * ts, cha_enc + b0 * ts, b, out + b0 * ts, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int mocha_to_mot(mocha_ctx* c, const float* tokens, int B, float* Y, void* stream) {
+    int rc = ready(c, B); if (rc) return rc;
+    const size_t ts = 90 * 256, ys = (size_t)60 * c->cfg.V * c->cfg.C_in;
+    for (int b0 = 0; b0 < B; b0 += c->chunk) {
+        const int b = std::min(c->chunk, B - b0);
+        rc = run_to_mot(c, tokens + b0 * ts, b, Y + b0 * ys, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+int mocha_forward(mocha_ctx* c, const float* src_X, const float* cha_X, int B, float* Y, void* stream) {
+    int rc = ready(c, B); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in;
+    for (int b0 = 0; b0 < B; b0 += c->chunk) {
+        const int b = std::min(c->chunk, B - b0);
+        if ((rc = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s))) return rc;
+        if ((rc = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return rc;
+        if ((rc = run_embed(c, cha_X + b0 * xs, b, WS(c, "x5"), true, s))) return rc;
+        if ((rc = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_c"), s))) return rc;
+        if ((rc = run_decoder(c, WS(c, "enc_s"), WS(c, "enc_c"), b, WS(c, "dec"), s))) return rc;
+        if ((rc = run_to_mot(c, WS(c, "dec"), b, Y + b0 * xs, s))) return rc;
+    }
+    return 0;
+}
+
+int mocha_forward_features(mocha_ctx* c, const float* src_X, const float* cha_X, int B, float* src_enc, float* cha_enc,
+                           float* src_cnt, float* cha_cnt, void* stream) {
+    int rc = mocha_encode(c, src_X, B, src_enc, src_cnt, nullptr, nullptr, nullptr, stream);
+    if (rc) return rc;
+    return mocha_encode(c, cha_X, B, cha_enc, cha_cnt, nullptr, nullptr, nullptr, stream);
+}
+
+int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int64_t N, int flags, void* stream) {
+    int rc = ready(c, 0); if (rc) return rc;
+    if (!cnt_nm || !encoded || N < 1 || N > (int64_t)1 << 30) return fail(c, MOCHA_ERR_ARG, "bad bank arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t D = 90 * 256;
+    if (flags & MOCHA_BANK_BORROW) {
+        c->bank_cnt = cnt_nm; c->bank_enc = encoded;
+    } else {
+        if (c->bank_cap < (size_t)N) {
+            for (float** p : {&c->bank_cnt_own, &c->bank_enc_own})
+                if (*p) { (void)hipFree(*p); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), *p), c->owned.end()); *p = nullptr; }
+            if ((rc = dev_alloc(c, &c->bank_cnt_own, (size_t)N * D))) return rc;
+            if ((rc = dev_alloc(c, &c->bank_enc_own, (size_t)N * D))) return rc;
+            c->bank_cap = (size_t)N;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->bank_cnt_own, cnt_nm, (size_t)N * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->bank_enc_own, encoded, (size_t)N * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+        c->bank_cnt = c->bank_cnt_own; c->bank_enc = c->bank_enc_own;
+    }
+    if (c->bank_norm_cap < (size_t)N) {
+        if (c->bank_norm) { (void)hipFree(c->bank_norm); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), c->bank_norm), c->owned.end()); c->bank_norm = nullptr; }
+        if ((rc = dev_alloc(c, &c->bank_norm, (size_t)N))) return rc;
+        c->bank_norm_cap = (size_t)N;
+    }
+    c->bank_N = N;
+    KCHK(c, launch_rownorm2(c->bank_cnt, c->bank_norm, N, (int)D, s));
+    return 0;
+}
+
+int mocha_match(mocha_ctx* c, const float* query_nm, int Q, int32_t* idx, float* dist, void* stream) {
+    int rc = ready(c, 0); if (rc) return rc;
+    if (!query_nm || !idx || Q < 0) return fail(c, MOCHA_ERR_ARG, "bad match arguments");
+    if (Q == 0) return 0;
+    return do_match(c, query_nm, Q, idx, dist, (hipStream_t)stream);
+}
+
+int mocha_bank_gather(mocha_ctx* c, const int32_t* idx, int Q, float* out, void* stream) {
+    int rc = ready(c, 0); if (rc) return rc;
+    if (!c->bank_enc) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
+    if (!idx || !out || Q < 0) return fail(c, MOCHA_ERR_ARG, "bad gather arguments");
+    KCHK(c, launch_gather_rows(c->bank_enc, idx, out, Q, 90 * 256, (hipStream_t)stream));
+    return 0;
+}
+
+int mocha_characterize(mocha_ctx* c, const float* src_X, int B, const float* cnt_mean, const float* cnt_std, float* Y,
+                       int32_t* idx, void* stream) {
+    int rc = ready(c, B); if (rc) return rc;
+    if (!c->bank_cnt) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
+    if (!cnt_mean || !cnt_std || !src_X || !Y) return fail(c, MOCHA_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in;
+    for (int b0 = 0; b0 < B; b0 += c->chunk) {
+        const int b = std::min(c->chunk, B - b0);
+        int32_t* ix = idx ? idx + b0 : c->idx_ws;
+        if ((rc = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s))) return rc;
+        if ((rc = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return rc;
+        KCHK(c, launch_instnorm(WS(c, "enc_s"), WS(c, "cnt"), nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s));
+        if ((rc = do_match(c, WS(c, "qnm"), b, ix, nullptr, s))) return rc;
+        KCHK(c, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), b, 90 * 256, s));
+        if ((rc = run_decoder(c, WS(c, "enc_s"), WS(c, "sel"), b, WS(c, "dec"), s))) return rc;
+        if ((rc = run_to_mot(c, WS(c, "dec"), b, Y + b0 * xs, s))) return rc;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,364 @@
+// Bandwidth-bound kernels of the MOCHA path on gfx950: graph-adjacency front ends, instance
+// norms, the final 64->15 projection, bank utilities.  All coalesced on the channel axis
+// (activations are kept channel-last: rows = (window, time, node), columns = channels).
+#include "kernels.h"
+
+namespace mocha {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * x; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// embed_front: model.py:43-46 up to (and including) the joint->body-part pool, which is linear
+// and is commuted in front of the two convolutions of the joint ST-GCN block.
+//   h[v][c]   = lrelu( sum_i X[v][i] W1[c][i] + b1[c] )                 (model.py:44, blocks.py:131)
+//   out[p][k*64+c] = sum_v AP[k][v][p] h[v][c],   AP[k] = A_j[k] · Pool  (blocks.py:64, graph.py:463-465)
+// One workgroup walks FPB frames; thread (c = tid&63, g = tid>>6).
+// ---------------------------------------------------------------------------------------
+static constexpr int EF_FPB = 4;
+
+__global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict__ X, const float* __restrict__ W1,
+                                                         const float* __restrict__ b1, const float* __restrict__ AP,
+                                                         float* __restrict__ out, int nframes, int V, int Cin) {
+    __shared__ float xs[32 * 16];
+    __shared__ float hs[32 * 64];
+    __shared__ float aps[3 * 32 * 6];
+    const int tid = threadIdx.x;
+    const int c = tid & 63, g = tid >> 6;
+    float w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = i < Cin ? W1[c * Cin + i] : 0.f;
+    const float bc = b1[c];
+    for (int i = tid; i < 3 * V * 6; i += 256) aps[i] = AP[i];
+
+    for (int f = 0; f < EF_FPB; ++f) {
+        const int frame = blockIdx.x * EF_FPB + f;
+        if (frame >= nframes) break;
+        __syncthreads();
+        const float* xf = X + (size_t)frame * V * Cin;
+        for (int i = tid; i < V * Cin; i += 256) {
+            const int v = i / Cin, ci = i - v * Cin;
+            xs[v * 16 + ci] = xf[i];
+        }
+        __syncthreads();
+        for (int v = g; v < V; v += 4) {
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (i < Cin) a = fmaf(xs[v * 16 + i], w[i], a);
+            hs[v * 64 + c] = lrelu02(a + bc);
+        }
+        __syncthreads();
+        float* of = out + (size_t)frame * 6 * 192;
+        for (int j = g; j < 18; j += 4) {
+            const int p = j / 3, k = j - p * 3;
+            float a = 0.f;
+            for (int v = 0; v < V; ++v) a = fmaf(aps[(k * V + v) * 6 + p], hs[v * 64 + c], a);
+            of[p * 192 + k * 64 + c] = a;
+        }
+    }
+}
+
+hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP, float* out,
+                              int nframes, int V, int Cin, hipStream_t s) {
+    if (nframes <= 0) return hipSuccess;
+    if (V > 32 || Cin > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_embed_front, dim3((nframes + EF_FPB - 1) / EF_FPB), dim3(256), 0, s, X, W1, b1, AP, out,
+                       nframes, V, Cin);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// body_front: LeakyReLU then the body-part adjacency (commuted in front of the 1x1 conv):
+//   out[(f,w)][k*256+c] = sum_v A_b[k][v][w] lrelu(x[(f,v)][c])      (blocks.py:131, :64)
+// one thread per (frame f, 4 channels)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_body_front(const float* __restrict__ x, const float* __restrict__ Ab,
+                                                        float* __restrict__ out, int frames) {
+    __shared__ float a[72];
+    if (threadIdx.x < 72) a[threadIdx.x] = Ab[threadIdx.x];
+    __syncthreads();
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int f = gid >> 6, c4 = (gid & 63) * 4;
+    if (f >= frames) return;
+    f32x4 xv[6];
+#pragma unroll
+    for (int v = 0; v < 6; ++v) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(x + ((size_t)f * 6 + v) * 256 + c4);
+        t[0] = lrelu02(t[0]); t[1] = lrelu02(t[1]); t[2] = lrelu02(t[2]); t[3] = lrelu02(t[3]);
+        xv[v] = t;
+    }
+#pragma unroll
+    for (int w = 0; w < 6; ++w)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int v = 0; v < 6; ++v) acc += xv[v] * a[(k * 6 + v) * 6 + w];
+            *reinterpret_cast<f32x4*>(out + ((size_t)f * 6 + w) * 512 + k * 256 + c4) = acc;
+        }
+}
+
+hipError_t launch_body_front(const float* x, const float* A_b, float* out, int rows6, hipStream_t s) {
+    if (rows6 <= 0) return hipSuccess;
+    const long long threads = (long long)rows6 * 64;
+    hipLaunchKernelGGL(mocha_body_front, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, x, A_b, out, rows6);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// joint_expand: body-part -> joint copy (graph.py:606-608) followed by the joint adjacency of the
+// output ST-GCN block (blocks.py:64) on the 3x64 gcn channels, at the 15-frame resolution (the
+// nearest x4 upsampling, model.py:74, repeats frames and is folded into the next GEMM's gather):
+//   out[(f,w)][c] = sum_k sum_p AU[k][p][w] g[(f,p)][k*64+c],   AU[k][p][w] = sum_{v in part p} A_j[k][v][w]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_joint_expand(const float* __restrict__ g, const float* __restrict__ AU,
+                                                          float* __restrict__ out, int frames, int V) {
+    __shared__ float gs[6 * 192];
+    __shared__ float au[3 * 6 * 32];
+    const int tid = threadIdx.x;
+    const int f = blockIdx.x;
+    for (int i = tid; i < 3 * 6 * V; i += 256) au[i] = AU[i];
+    for (int i = tid; i < 6 * 192; i += 256) gs[i] = g[(size_t)f * 6 * 192 + i];
+    __syncthreads();
+    const int c = tid & 63;
+    for (int w = tid >> 6; w < V; w += 4) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int p = 0; p < 6; ++p) a = fmaf(au[(k * 6 + p) * V + w], gs[p * 192 + k * 64 + c], a);
+        out[((size_t)f * V + w) * 64 + c] = a;
+    }
+}
+
+hipError_t launch_joint_expand(const float* g, const float* AU, float* out, int nframes15, int V, hipStream_t s) {
+    if (nframes15 <= 0) return hipSuccess;
+    if (V > 32) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_joint_expand, dim3(nframes15), dim3(256), 0, s, g, AU, out, nframes15, V);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// final_proj: Y[m][o] = sum_c lrelu(z[m][c]) W6[o][c] + b6[o]     (model.py:77-79)
+// 64 rows per workgroup, staged through LDS so both the z read and the Y write are coalesced.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_final_proj(const float* __restrict__ z, const float* __restrict__ W6,
+                                                        const float* __restrict__ b6, float* __restrict__ Y, int rows,
+                                                        int Cout) {
+    __shared__ float zs[64 * 65];
+    __shared__ float ws[16 * 64];
+    __shared__ float ys[64 * 16];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * 64;
+    for (int i = tid; i < Cout * 64; i += 256) ws[i] = W6[i];
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        const int row = r0 + r;
+        zs[r * 65 + c] = row < rows ? lrelu02(z[(size_t)row * 64 + c]) : 0.f;
+    }
+    __syncthreads();
+    const int r = tid & 63;
+    for (int o = tid >> 6; o < Cout; o += 4) {
+        float a = 0.f;
+#pragma unroll 16
+        for (int c = 0; c < 64; ++c) a = fmaf(zs[r * 65 + c], ws[o * 64 + c], a);
+        ys[r * Cout + o] = a + b6[o];
+    }
+    __syncthreads();
+    const int nrow = (rows - r0) < 64 ? (rows - r0) : 64;
+    for (int i = tid; i < nrow * Cout; i += 256) Y[(size_t)r0 * Cout + i] = ys[i];
+}
+
+hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, float* Y, int rows, int Cout,
+                             hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (Cout > 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_final_proj, dim3((rows + 63) / 64), dim3(256), 0, s, z, W6, b6, Y, rows, Cout);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// instance norm over the token axis, per (window, channel)  (net/transformer.py:13-20):
+//   mean = sum/n ; std = sqrt(sum (x-mean)^2 / (n-1)) ; out = (x-mean)/(std+1e-5)
+// one workgroup per window, thread = channel (dim is 256 on this path)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_instnorm(const float* __restrict__ x, float* __restrict__ out,
+                                                      float* __restrict__ mean_out, const float* __restrict__ gm,
+                                                      const float* __restrict__ gs, float* __restrict__ zn, int n) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    const float* xb = x + (size_t)b * n * 256 + c;
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += xb[i * 256];
+    const float mean = s / (float)n;
+    float q = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float d = xb[i * 256] - mean;
+        q = fmaf(d, d, q);
+    }
+    const float den = sqrtf(q / (float)(n - 1)) + 1e-5f;
+    if (mean_out) mean_out[(size_t)b * 256 + c] = mean;
+    float* ob = out + (size_t)b * n * 256 + c;
+    for (int i = 0; i < n; ++i) {
+        const float v = (xb[i * 256] - mean) / den;
+        ob[i * 256] = v;
+        if (zn) zn[(size_t)b * n * 256 + i * 256 + c] = (v - gm[i * 256 + c]) / gs[i * 256 + c];
+    }
+}
+
+hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
+                           int B, int n, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mocha_instnorm, dim3(B), dim3(256), 0, s, x, out, mean_out, gm, gs, zn, n);
+    return hipGetLastError();
+}
+
+// AdaIN followed by the attention's own mapping norm (net/transformer.py:108-113 then :49-56):
+//   xad = (1+gamma) * IN(x) + beta ;  qin = IN(xad)
+__global__ __launch_bounds__(256) void mocha_adain(const float* __restrict__ x, const float* __restrict__ gb,
+                                                   float* __restrict__ xad, float* __restrict__ qin, int n) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    const float* xb = x + (size_t)b * n * 256 + c;
+    const float gamma1 = 1.f + gb[(size_t)b * 512 + c];
+    const float beta = gb[(size_t)b * 512 + 256 + c];
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += xb[i * 256];
+    const float mean = s / (float)n;
+    float q = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float d = xb[i * 256] - mean;
+        q = fmaf(d, d, q);
+    }
+    const float den = sqrtf(q / (float)(n - 1)) + 1e-5f;
+    float* ab = xad + (size_t)b * n * 256 + c;
+    float s2 = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float v = gamma1 * ((xb[i * 256] - mean) / den) + beta;
+        ab[i * 256] = v;
+        s2 += v;
+    }
+    const float mean2 = s2 / (float)n;
+    float q2 = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const float d = ab[i * 256] - mean2;      // own writes, same thread: visible
+        q2 = fmaf(d, d, q2);
+    }
+    const float den2 = sqrtf(q2 / (float)(n - 1)) + 1e-5f;
+    float* qb = qin + (size_t)b * n * 256 + c;
+    for (int i = 0; i < n; ++i) qb[i * 256] = (ab[i * 256] - mean2) / den2;
+}
+
+hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin, int B, int n, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mocha_adain, dim3(B), dim3(256), 0, s, x, gb, xad, qin, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// bank utilities
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_rownorm2(const float* __restrict__ x, float* __restrict__ out, int cols) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * cols);
+    float a = 0.f;
+    for (int i = threadIdx.x; i < cols / 4; i += 256) {
+        const f32x4 v = xr[i];
+        a = fmaf(v[0], v[0], a); a = fmaf(v[1], v[1], a); a = fmaf(v[2], v[2], a); a = fmaf(v[3], v[3], a);
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[row] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (cols % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_rownorm2, dim3((unsigned)rows), dim3(256), 0, s, x, out, cols);
+    return hipGetLastError();
+}
+
+// argmin over the bank of ||b||^2 - 2 q·b (||q||^2 is constant per query), ties to the lowest
+// index; then the Euclidean distance to the winner in the direct (q-b)^2 form.
+// (semantics of BallTree.query(k=1), test_fullframework.py:296,443)
+__global__ __launch_bounds__(256) void mocha_argmin(const float* __restrict__ S, int ksplit, long long slab_stride,
+                                                    int lds, const float* __restrict__ bnorm,
+                                                    const float* __restrict__ query, const float* __restrict__ bank,
+                                                    long long N, int D, int32_t* __restrict__ idx,
+                                                    float* __restrict__ dist) {
+    __shared__ float rv[4];
+    __shared__ int ri[4];
+    __shared__ int win;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (long long nn = tid; nn < N; nn += 256) {
+        float dot = 0.f;
+        for (int z = 0; z < ksplit; ++z) dot += S[(size_t)z * slab_stride + (size_t)q * lds + nn];
+        const float v = bnorm[nn] - 2.f * dot;
+        if (v < best) { best = v; bi = (int)nn; }       // strided ascending: first hit is the lowest index
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        float b = rv[0]; int i = ri[0];
+        for (int w = 1; w < 4; ++w)
+            if (rv[w] < b || (rv[w] == b && ri[w] < i)) { b = rv[w]; i = ri[w]; }
+        win = i;
+        idx[q] = i;
+    }
+    __syncthreads();
+    if (!dist) return;
+    const f32x4* qr = reinterpret_cast<const f32x4*>(query + (size_t)q * D);
+    const f32x4* br = reinterpret_cast<const f32x4*>(bank + (size_t)win * D);
+    float a = 0.f;
+    for (int i = tid; i < D / 4; i += 256) {
+        const f32x4 d = qr[i] - br[i];
+        a = fmaf(d[0], d[0], a); a = fmaf(d[1], d[1], a); a = fmaf(d[2], d[2], a); a = fmaf(d[3], d[3], a);
+    }
+    a = wave_sum(a);
+    __syncthreads();
+    if ((tid & 63) == 0) rv[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) dist[q] = sqrtf((rv[0] + rv[1]) + (rv[2] + rv[3]));
+}
+
+hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm,
+                         const float* query, const float* bank, int Q, int64_t N, int D, int32_t* idx, float* dist,
+                         hipStream_t s) {
+    if (Q <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mocha_argmin, dim3(Q), dim3(256), 0, s, S, ksplit, slab_stride, lds, bnorm, query, bank,
+                       (long long)N, D, idx, dist);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void mocha_gather_rows(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                         float* __restrict__ out, int cols4) {
+    const size_t q = blockIdx.x;
+    const f32x4* s = reinterpret_cast<const f32x4*>(src) + (size_t)idx[q] * cols4;
+    f32x4* o = reinterpret_cast<f32x4*>(out) + q * cols4;
+    for (int i = threadIdx.x; i < cols4; i += 256) o[i] = s[i];
+}
+
+hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, int Q, int cols, hipStream_t s) {
+    if (Q <= 0) return hipSuccess;
+    if (cols % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_gather_rows, dim3(Q), dim3(256), 0, s, src, idx, out, cols / 4);
+    return hipGetLastError();
+}
+
+}  // namespace mocha

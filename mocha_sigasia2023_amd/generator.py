@@ -1,0 +1,324 @@
+"""Host-side mirror of the reference ``Generator`` call surface on top of libmocha_hip.so.
+
+The reference's boundary for this path is the attribute surface of its ``Generator``
+module (model.py:15-106) as the demo uses it (test_fullframework.py:190-193, 301-302,
+455-456, 465-467) plus ``mean_variance_norm`` (net/transformer.py:13-20) and the
+``BallTree`` query (test_fullframework.py:294-296, 443).  This module offers the same
+names with the same tensor-in/tensor-out meaning; PyTorch is used for device memory and
+streams only — every value is computed by the HIP kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _C
+from .skeleton import LAYOUT_ID, skeleton_constants
+from .weights import DEFAULT_CFG, buffer_arrays, param_shapes
+
+NTOK, DIM = 90, 256
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(t, device, shape_tail=None, name="tensor") -> torch.Tensor:
+    if isinstance(t, np.ndarray):
+        t = torch.from_numpy(t)
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor, got {type(t)}")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    t = t.to(device)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if shape_tail is not None and tuple(t.shape[-len(shape_tail):]) != tuple(shape_tail):
+        raise ValueError(f"{name}: trailing shape {tuple(t.shape)} does not end with {tuple(shape_tail)}")
+    return t
+
+
+class _Context:
+    """Owns one ``mocha_ctx*``."""
+
+    def __init__(self, cfg: Mapping, layout: str, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("the MOCHA HIP path needs a ROCm GPU device ('cuda:N'); there is no CPU fallback")
+        self.lib = _C.load_library()
+        self.device = device
+        sk = skeleton_constants(layout)
+        c = _C.mocha_cfg(
+            T=cfg["nframes"], V=sk.V, C_in=cfg["mot_in_dim"], patch=cfg["temporal_patch_size"], dim=cfg["encoder_dim"],
+            enc_depth=cfg["encoder_depth"], enc_heads=cfg["encoder_heads"], enc_dim_head=cfg["encoder_dim_head"],
+            enc_mlp=cfg["encoder_mlp_dim"], dec_depth=cfg["decoder_depth"], dec_heads=cfg["decoder_heads"],
+            dec_dim_head=cfg["decoder_dim_head"], dec_mlp=cfg["decoder_mlp_dim"], layout=LAYOUT_ID[layout])
+        if cfg["decoder_dim"] != cfg["encoder_dim"]:
+            raise ValueError("decoder_dim must equal encoder_dim")
+        h = C.c_void_p()
+        rc = self.lib.mocha_create(C.byref(c), device.index or 0, C.byref(h))
+        _C.check(self.lib, None, rc, "mocha_create")
+        self.h = h
+        self.V = sk.V
+        self.C_in = cfg["mot_in_dim"]
+        self.T = cfg["nframes"]
+
+    def call(self, fn: str, *args):
+        with torch.cuda.device(self.device):
+            rc = getattr(self.lib, fn)(self.h, *args)
+        _C.check(self.lib, self.h, rc, fn)
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.mocha_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+_util_ctx = {}
+
+
+def _utility_context(device: torch.device) -> _Context:
+    """Weight-less context for the free function ``mean_variance_norm``."""
+    key = (device.type, device.index)
+    if key not in _util_ctx:
+        _util_ctx[key] = _Context(DEFAULT_CFG, "mocha", device)
+    return _util_ctx[key]
+
+
+def mean_variance_norm(input: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """``mean_variance_norm`` of net/transformer.py:13-20 for the path's use: input (B, C=256, S)
+    normalised over S per (b, c) with the unbiased std and eps outside the sqrt.  The demo
+    passes ``encoded.permute(0, 2, 1)`` (test_fullframework.py:193); that view is consumed
+    in place (no copy) and a (B, C, S) view of the result is returned."""
+    if eps != 1e-5:
+        raise ValueError("only eps=1e-5 (the reference default, the only value on the path) is supported")
+    if input.dim() != 3 or input.shape[1] != DIM:
+        raise ValueError(f"expected (B, {DIM}, S), got {tuple(input.shape)}")
+    if not input.is_cuda:
+        raise RuntimeError("mean_variance_norm: tensor must be on the GPU; there is no CPU fallback")
+    tok_major = input.permute(0, 2, 1)             # (B, S, C)
+    if not tok_major.is_contiguous():
+        tok_major = tok_major.contiguous()
+    if tok_major.dtype != torch.float32:
+        raise TypeError("expected float32")
+    B, S, _ = tok_major.shape
+    if S != NTOK:
+        raise ValueError(f"expected {NTOK} tokens, got {S}")
+    ctx = _utility_context(input.device)
+    out = torch.empty_like(tok_major)
+    ctx.call("mocha_mvn", _ptr(tok_major), B, _ptr(out), _ptr(None), _ptr(None), _ptr(None), _stream())
+    return out.permute(0, 2, 1)
+
+
+class Generator:
+    """Drop-in for the reference ``Generator`` (model.py:15) on one MI355X.
+
+    >>> model = Generator(cfg['model']).load_state_dict(torch.load(path)['gen_ema']).eval()
+    >>> tokens = model.mot_embedding(X); tokens = tokens + model.pos_emb[:, :tokens.shape[1]]
+    >>> encoded = model.encoder(tokens); Y = model.to_mot(model.decoder(encoded, cha_encoded))
+    """
+
+    def __init__(self, config: Optional[Mapping] = None, layout: Optional[str] = None, device="cuda:0"):
+        cfg = dict(DEFAULT_CFG)
+        if config:
+            cfg.update({k: v for k, v in config.items() if k in DEFAULT_CFG})
+            if layout is None and "graph" in config:
+                layout = config["graph"]["joint"].get("layout", "mocha")   # configs/config.yaml:42
+        self.layout = layout or "mocha"
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self._ctx = _Context(cfg, self.layout, self.device)
+        self.V = self._ctx.V
+        self.pos_emb = None
+        self._loaded = False
+
+    # ---- nn.Module-like surface -------------------------------------------------------
+    def eval(self):                                  # test_fullframework.py:49
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise RuntimeError("create the Generator on its target device")
+        return self
+
+    def state_dict_keys(self):
+        return list(param_shapes(self.cfg, self.V)) + list(buffer_arrays(self.layout))
+
+    def load_state_dict(self, state_dict: Mapping, strict: bool = True):
+        """Accepts the ``gen_ema`` mapping of trainer.py:239-240 (name -> tensor / ndarray).
+        ``module.``-prefixed keys (nn.DataParallel checkpoints, trainer.py:45-47) are accepted."""
+        lib, ctx = self._ctx.lib, self._ctx
+        want = param_shapes(self.cfg, self.V)
+        seen = set()
+        for k, v in state_dict.items():
+            name = k[len("module."):] if k.startswith("module.") else k
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if name not in want and name not in buffer_arrays(self.layout):
+                if strict:
+                    raise KeyError(f"unexpected key in state_dict: {k}")
+                continue
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            ctx.call("mocha_load_weight", name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+            seen.add(name)
+            if name == "pos_emb":
+                self.pos_emb = torch.from_numpy(a.copy()).to(self.device)
+        missing = [k for k in want if k not in seen]
+        if missing and strict:
+            raise KeyError(f"missing keys in state_dict: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        ctx.call("mocha_finalize_weights")
+        self._loaded = True
+        return self
+
+    def reserve(self, max_batch: int):
+        """Pre-allocate workspaces for chunks of ``max_batch`` windows."""
+        self._ctx.call("mocha_reserve", int(max_batch))
+        return self
+
+    # ---- sub-module call surface of the demo -----------------------------------------
+    def _need(self):
+        if not self._loaded:
+            raise RuntimeError("weights not loaded: call load_state_dict first")
+
+    def _x(self, X, name):
+        return _dev_f32(X, self.device, (self.cfg["nframes"], self.V, self.cfg["mot_in_dim"]), name)
+
+    def _tok(self, t, name):
+        return _dev_f32(t, self.device, (NTOK, DIM), name)
+
+    def mot_embedding(self, X):                      # model.py:42-50
+        self._need()
+        X = self._x(X, "X")
+        out = torch.empty((X.shape[0], NTOK, DIM), dtype=torch.float32, device=self.device)
+        self._ctx.call("mocha_embed", _ptr(X), X.shape[0], _ptr(out), 0, _stream())
+        return out
+
+    def encoder(self, tokens):                       # model.py:53-59
+        self._need()
+        tokens = self._tok(tokens, "tokens")
+        out = torch.empty_like(tokens)
+        self._ctx.call("mocha_encoder", _ptr(tokens), tokens.shape[0], _ptr(out), _stream())
+        return out
+
+    def decoder(self, src_encoded, cha_encoded):     # model.py:62-68
+        self._need()
+        s = self._tok(src_encoded, "src_encoded")
+        c = self._tok(cha_encoded, "cha_encoded")
+        if s.shape[0] != c.shape[0]:
+            raise ValueError("decoder: batch sizes differ")
+        out = torch.empty_like(s)
+        self._ctx.call("mocha_decoder", _ptr(s), _ptr(c), s.shape[0], _ptr(out), _stream())
+        return out
+
+    def to_mot(self, tokens):                        # model.py:71-80
+        self._need()
+        tokens = self._tok(tokens, "tokens")
+        B = tokens.shape[0]
+        out = torch.empty((B, self.cfg["nframes"], self.V, self.cfg["mot_in_dim"]), dtype=torch.float32, device=self.device)
+        self._ctx.call("mocha_to_mot", _ptr(tokens), B, _ptr(out), _stream())
+        return out
+
+    def forward(self, src_X, cha_X, extract_feature: bool = False):     # model.py:82-106
+        self._need()
+        s, c = self._x(src_X, "src_X"), self._x(cha_X, "cha_X")
+        if s.shape[0] != c.shape[0]:
+            raise ValueError("forward: batch sizes differ")
+        B = s.shape[0]
+        if extract_feature:
+            outs = [torch.empty((B, NTOK, DIM), dtype=torch.float32, device=self.device) for _ in range(4)]
+            self._ctx.call("mocha_forward_features", _ptr(s), _ptr(c), B, *[_ptr(o) for o in outs], _stream())
+            return tuple(outs)                       # src_encoded, cha_encoded, src_cnt, cha_cnt
+        Y = torch.empty_like(s)
+        self._ctx.call("mocha_forward", _ptr(s), _ptr(c), B, _ptr(Y), _stream())
+        return Y
+
+    __call__ = forward
+
+    # ---- fused extras (same arithmetic, fewer launches) --------------------------------
+    def encode(self, X, cnt_mean=None, cnt_std=None):
+        """The demo's encode sequence (test_fullframework.py:190-193) in one call.
+        Returns (encoded, cnt) or (encoded, cnt, cnt_nm) when the global cnt norm is given
+        (cnt_nm = (cnt - cnt_mean) / cnt_std, test_fullframework.py:293,442)."""
+        self._need()
+        X = self._x(X, "X")
+        B = X.shape[0]
+        enc = torch.empty((B, NTOK, DIM), dtype=torch.float32, device=self.device)
+        cnt = torch.empty_like(enc)
+        if cnt_mean is None:
+            self._ctx.call("mocha_encode", _ptr(X), B, _ptr(enc), _ptr(cnt), _ptr(None), _ptr(None), _ptr(None), _stream())
+            return enc, cnt
+        m = _dev_f32(cnt_mean, self.device, (NTOK, DIM), "cnt_mean")
+        sd = _dev_f32(cnt_std, self.device, (NTOK, DIM), "cnt_std")
+        nm = torch.empty_like(enc)
+        self._ctx.call("mocha_encode", _ptr(X), B, _ptr(enc), _ptr(cnt), _ptr(m), _ptr(sd), _ptr(nm), _stream())
+        return enc, cnt, nm
+
+
+class ContextBank:
+    """The character feature bank with the demo's BallTree role (test_fullframework.py:293-298):
+    ``ContextBank(model, cha_cnt_nm, cha_encoded).query(src_cnt_nm)`` -> (dist, idx) like
+    ``BallTree.query(k=1)``; ``gather(idx)`` -> ``cha_encoded[idx]``."""
+
+    def __init__(self, model: Generator, cha_cnt_nm, cha_encoded, copy: bool = False):
+        model._need()
+        self.model = model
+        dev = model.device
+        self.cnt_nm = _dev_f32(cha_cnt_nm, dev, None, "cha_cnt_nm").reshape(-1, NTOK * DIM)
+        self.encoded = _dev_f32(cha_encoded, dev, (NTOK, DIM), "cha_encoded")
+        if self.cnt_nm.shape[0] != self.encoded.shape[0]:
+            raise ValueError("bank: cnt_nm and encoded have different entry counts")
+        self.N = self.cnt_nm.shape[0]
+        self._copy = copy
+        self.activate()
+
+    def activate(self):
+        """Make this bank the context's current bank (borrowed buffers unless copy=True)."""
+        flags = 0 if self._copy else 1
+        self.model._ctx.call("mocha_bank_set", _ptr(self.cnt_nm), _ptr(self.encoded), self.N, flags, _stream())
+        self.model._bank = self
+        return self
+
+    def query(self, query_nm, k: int = 1, return_distance: bool = True):
+        if k != 1:
+            raise ValueError("only k=1 is on the path (test_fullframework.py:296,443)")
+        if getattr(self.model, "_bank", None) is not self:
+            self.activate()
+        q = _dev_f32(query_nm, self.model.device, None, "query").reshape(-1, NTOK * DIM)
+        Q = q.shape[0]
+        idx = torch.empty((Q,), dtype=torch.int32, device=q.device)
+        dist = torch.empty((Q,), dtype=torch.float32, device=q.device) if return_distance else None
+        self.model._ctx.call("mocha_match", _ptr(q), Q, _ptr(idx), _ptr(dist), _stream())
+        if return_distance:
+            return dist[:, None], idx[:, None]
+        return idx[:, None]
+
+    def gather(self, idx):
+        if getattr(self.model, "_bank", None) is not self:
+            self.activate()
+        idx = idx.reshape(-1).to(device=self.model.device, dtype=torch.int32).contiguous()
+        out = torch.empty((idx.shape[0], NTOK, DIM), dtype=torch.float32, device=self.model.device)
+        self.model._ctx.call("mocha_bank_gather", _ptr(idx), idx.shape[0], _ptr(out), _stream())
+        return out
+
+    def characterize(self, src_X, cnt_mean, cnt_std, return_index: bool = False):
+        """NN ('cm_') branch of the demo for all source windows at once: encode, z-score,
+        1-NN match, gather, decode, to_mot (test_fullframework.py:188-194,438-443,465-467)."""
+        if getattr(self.model, "_bank", None) is not self:
+            self.activate()
+        m = self.model
+        X = m._x(src_X, "src_X")
+        mean = _dev_f32(cnt_mean, m.device, (NTOK, DIM), "cnt_mean")
+        std = _dev_f32(cnt_std, m.device, (NTOK, DIM), "cnt_std")
+        Y = torch.empty_like(X)
+        idx = torch.empty((X.shape[0],), dtype=torch.int32, device=m.device)
+        m._ctx.call("mocha_characterize", _ptr(X), X.shape[0], _ptr(mean), _ptr(std), _ptr(Y), _ptr(idx), _stream())
+        return (Y, idx) if return_index else Y

@@ -1,0 +1,61 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/mocha_hip.h declares (no compute calls here: there is no GPU)."""
+import os
+import re
+
+import pytest
+
+from mocha_sigasia2023_amd import _C, weights
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _built():
+    if not os.path.exists(_C.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _C.load_library()
+
+
+def header_symbols():
+    txt = open(os.path.join(REPO, "include", "mocha_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mocha_[a-z_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree():
+    syms = header_symbols()
+    assert syms, "no symbols parsed from the header"
+    assert sorted(_C.SIGNATURES) == syms
+
+
+def test_library_exports_every_symbol():
+    lib = _built()
+    for s in header_symbols():
+        assert hasattr(lib, s), f"libmocha_hip.so does not export {s}"
+    assert lib.mocha_abi_version() == _C.ABI_VERSION
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.setattr(_C, "_lib", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _C.load_library(str(tmp_path / "libmocha_hip.so"))
+
+
+def test_product_path_does_not_import_oracle():
+    pkg = os.path.join(REPO, "mocha_sigasia2023_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("no CPU oracle", "").replace("CPU oracle.", "") or f == "_C.py", f
+    src = open(os.path.join(pkg, "_C.py")).read()
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_weight_schema_matches_reference_count():
+    # 6 116 559 learnable parameters
+    n = sum(int(__import__("numpy").prod(s)) for s in weights.param_shapes().values())
+    assert n == 6116559
+    sd = weights.synthetic_state_dict(1, 1.0)
+    assert set(weights.param_shapes()) | set(weights.buffer_arrays()) == set(sd)
