@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py — characterized frames/s of the MOCHA Generator hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d "C2"): the demo pair — one source clip and
+one character clip of 585 sixty-frame windows each (a 600-frame clip slid with step 1,
+preprocess/generate_database.py:65-84), 24 joints x 15 channels, fp32, synthetic N(0,1)
+z-scored poses, synthetic weights of the reference architecture.
+
+One step = one pass of the demo's NN ("cm_") pipeline over the pair
+(test_fullframework.py:188-194, 271-277, 288-302, 438-443, 465-467), inputs resident in HBM:
+    bank build : encode the character clip (mot_embedding, +pos_emb, encoder, cnt, z-score), row norms
+    characterize: encode the source clip, z-score, exact 1-NN match against the bank, gather the
+                  matched character features, decoder, to_mot  -> 585 characterized pose windows
+and yields 585 characterized frames (one output pose per window, the [-1] slice).
+
+Multi-GPU (weak scaling, one process per GPU): every rank runs the same step on its own source
+clip; the character clip and the cnt norm are owned by rank 0 and broadcast once over RCCL
+before the timed region (a set-up step, reported as bank_broadcast_ms); there is no
+collective inside the timed region because windows are independent units.
+
+Prints ONE JSON line on rank 0 (see the keys below).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense f32 MFMA peak (MI355X_MICROARCH.md, chip table)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--windows", type=int, default=585, help="windows per clip (demo pair: 585)")
+    ap.add_argument("--chunk", type=int, default=0, help="windows per internal chunk (0 = library default)")
+    ap.add_argument("--joints", type=int, default=24, choices=(24, 22))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=48, help="windows per clip for the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, V, n, mean, std):
+    """The oracle (CPU restatement of the reference path, same op sequence on torch CPU) timed on a
+    bounded sample of the same workload: n source + n character windows through the same step."""
+    from oracle import mocha_oracle as O      # checker / baseline only
+    from mocha_sigasia2023_amd import synthetic
+    tsd = O.to_torch_state(sd)
+    src = torch.from_numpy(synthetic.pose_windows(901, n, V))
+    cha = torch.from_numpy(synthetic.pose_windows(902, n, V))
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        O.characterize(tsd, src[:8], cha[:8], mean, std)          # warm-up (oneDNN primitive caches)
+        t0 = time.perf_counter()
+        O.characterize(tsd, src, cha, mean, std)
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{n} src + {n} cha windows through the same step (encode both, 1-NN match, decode, to_mot), "
+                      f"torch-CPU oracle batch 32, {dt:.1f} s, os.cpu_count()={os.cpu_count()}"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist_on = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, synthetic_state_dict
+    layout = "mocha" if a.joints == 24 else "mixamo"
+    V, W = a.joints, a.windows
+    sd = synthetic_state_dict(seed=1777, gain=1.0, layout=layout)
+    model = Generator(layout=layout, device=dev).load_state_dict(sd).eval()
+    if a.chunk:
+        model.reserve(a.chunk)
+
+    # ---- inputs, resident in HBM before the timed region
+    src = torch.from_numpy(synthetic.pose_windows(1777 + 10 * rank, W, V)).to(dev)
+    if rank == 0:
+        cha = torch.from_numpy(synthetic.pose_windows(4242, W, V)).to(dev)
+        m_, s_ = synthetic.cnt_norm(7)
+        mean, std = torch.from_numpy(m_).to(dev), torch.from_numpy(s_).to(dev)
+    else:
+        cha = torch.empty((W, 60, V, 15), dtype=torch.float32, device=dev)
+        mean = torch.empty((90, 256), dtype=torch.float32, device=dev)
+        std = torch.empty_like(mean)
+    bcast_ms = None
+    if dist_on:
+        torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for t in (cha, mean, std):
+            dist.broadcast(t, src=0)              # RCCL over xGMI, set-up only
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+
+    def step():
+        enc_c, cnt_c, nm_c = model.encode(cha, mean, std)               # bank build
+        bank = ContextBank(model, nm_c, enc_c)                          # borrow + row norms
+        return bank.characterize(src, mean, std, return_index=True)     # src encode, match, gather, decode, to_mot
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(a.warmup):
+            Y, idx = step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            Y, idx = step()
+        sync_all()
+        elapsed = time.perf_counter() - t0
+    if dist_on:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    value = world * W * a.steps / elapsed
+
+    out = None
+    if rank == 0:
+        # ---- roofline leg: the same step once more with a HIP-event pair around every launch
+        with torch.no_grad():
+            model.profile_start()
+            for _ in range(3):
+                step()
+            prof = model.profile_stop()
+        kern = prof["kernels"]
+        dom = max(kern, key=lambda k: kern[k]["ms"])
+        d = kern[dom]
+        total_ms = sum(k["ms"] for k in kern.values())
+        ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roofline = {
+            "kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "launches_per_step": d["launches"] // 3, "avg_launch_us": d["ms"] / d["launches"] * 1e3,
+            "algorithmic_flops_per_launch": d["flops"] / d["launches"],
+            "share_of_step_kernel_time": d["ms"] / total_ms,
+        }
+        mk = {k: v for k, v in prof["sites"].items() if k.startswith("match.")}
+        breakdown = {k: {"ms_per_step": v["ms"] / 3, "launches_per_step": v["launches"] // 3,
+                         "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else 0.0,
+                         "gbs": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else 0.0}
+                     for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])}
+        out = {
+            "metric": "characterized frames/sec (whole node) at T=60",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"demo pair (BASELINE configs[1]): {W} src x {W} cha windows, T=60, V={V}, C=15, "
+                                   f"bank build + encode/match/decode/to_mot per step", "windows_per_gpu": W,
+                       "joints": V, "bank_entries": W, "parallelism": f"dp{world} (independent windows, no in-step collective)"},
+            "roofline": roofline,
+            "kernel_breakdown": breakdown,
+            "match_sites": {k: {"ms_per_step": v["ms"] / 3} for k, v in mk.items()},
+            "bank_broadcast_ms": bcast_ms,
+        }
+        if not a.no_cpu_baseline:
+            m_, s_ = synthetic.cnt_norm(7)
+            out["cpu_baseline"] = cpu_baseline(sd, V, a.cpu_sample, m_, s_)
+            out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

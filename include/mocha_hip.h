@@ -115,6 +115,13 @@ int mocha_abi_version(void);
 int mocha_graph_constants(mocha_ctx* ctx, float* A_j /*3*V*V host*/, float* A_b /*2*6*6 host*/,
                           float* pool /*V*6 host*/, float* unpool /*6*V host*/);
 
+/* Measurement support (bench.py roofline leg): between start and stop every kernel launch is
+ * bracketed by a HIP event pair on its launch stream.  stop synchronises those events and
+ * writes a JSON object {"kernels": {symbol: {launches, ms, flops, bytes}}, "sites": {...}} of
+ * per-kernel totals (algorithmic flops/bytes of the launches) into `json` (capacity `cap`). */
+int mocha_profile_start(mocha_ctx* ctx);
+int mocha_profile_stop(mocha_ctx* ctx, char* json, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

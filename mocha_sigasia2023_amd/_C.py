@@ -46,6 +46,8 @@ SIGNATURES = {
     "mocha_bank_gather": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mocha_characterize": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mocha_graph_constants": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mocha_profile_start": (_i, [_vp]),
+    "mocha_profile_stop": (_i, [_vp, C.c_char_p, _i64]),
 }
 
 _lib = None

@@ -109,7 +109,7 @@ struct mocha_ctx {
 
     // workspaces: sized for `chunk` windows; larger batches are processed chunk by chunk
     int chunk = 0;
-    int max_chunk = 256;
+    int max_chunk = 1024;
     std::map<std::string, DevBuf> ws;
     DevBuf match_S;
     int32_t* idx_ws = nullptr; size_t idx_ws_n = 0;
@@ -120,6 +120,11 @@ struct mocha_ctx {
     float* bank_cnt_own = nullptr; float* bank_enc_own = nullptr; size_t bank_cap = 0;
     float* bank_norm = nullptr; size_t bank_norm_cap = 0;
     int64_t bank_N = 0;
+
+    // per-launch HIP-event profiling (mocha_profile_start/stop); off in normal operation
+    struct ProfRec { std::string kernel, site; hipEvent_t e0, e1; double flops, bytes; };
+    bool prof_on = false;
+    std::vector<ProfRec> prof;
 };
 
 namespace {
@@ -287,12 +292,37 @@ int ensure_ws(mocha_ctx* c, int B) {
 float* WS(mocha_ctx* c, const char* n) { return c->ws.at(n).p; }
 float* DW(mocha_ctx* c, const std::string& n) { return c->w.at(n); }
 
-#define KCHK(c, expr)                                                                                        \
+// Every kernel launch goes through LAUNCH: error check, and when profiling is on a HIP event
+// pair on the launch stream around it, tagged with the kernel symbol and the call site.
+int prof_begin(mocha_ctx* c, hipStream_t s, const char* kernel, const char* site, double flops, double bytes) {
+    mocha_ctx::ProfRec r{kernel, site, nullptr, nullptr, flops, bytes};
+    HIPCHK(c, hipEventCreate(&r.e0));
+    HIPCHK(c, hipEventCreate(&r.e1));
+    HIPCHK(c, hipEventRecord(r.e0, s));
+    c->prof.push_back(r);
+    return 0;
+}
+
+#define LAUNCH(c, s, kernel, site, flops, bytes, expr)                                                       \
     do {                                                                                                     \
+        if ((c)->prof_on) { int rc__ = prof_begin((c), (s), (kernel), (site), (flops), (bytes)); if (rc__) return rc__; } \
         hipError_t e__ = (expr);                                                                             \
         if (e__ != hipSuccess)                                                                               \
             return fail((c), MOCHA_ERR_HIP, "launch %s: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+        if ((c)->prof_on) HIPCHK((c), hipEventRecord((c)->prof.back().e1, (s)));                             \
     } while (0)
+
+const char* gemm_kernel_name(const GemmParams& p) {
+    return ((p.N % 128 != 0) && (p.N <= 256)) ? "mocha_gemm_f32<64,4,1,1,2>" : "mocha_gemm_f32<128,2,2,2,2>";
+}
+
+int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
+    const double flops = 2.0 * p.M * (double)p.N * p.K;
+    const double bytes = 4.0 * ((double)p.M * p.K / (p.gather ? p.ntaps : 1) * (p.R) + (double)p.N * p.K + (double)p.M * p.N * p.ksplit);
+    LAUNCH(c, s, gemm_kernel_name(p), site, flops, bytes, launch_gemm(p, s));
+    return 0;
+}
+#define GEMM(c, s, site, p) do { int rc__ = gemm((c), (s), (site), (p)); if (rc__) return rc__; } while (0)
 
 GemmParams plain(const float* A, int lda, const float* Wt, float* C, int ldc, int M, int N, int K) {
     GemmParams p;
@@ -305,26 +335,27 @@ GemmParams plain(const float* A, int lda, const float* Wt, float* C, int ldc, in
 int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, hipStream_t s) {
     const int V = c->cfg.V;
     // conv1 + lrelu + adjacency + joint->part pool (commuted)                  model.py:44-46
-    KCHK(c, launch_embed_front(X, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar"), b * 60, V, c->cfg.C_in, s));
+    LAUNCH(c, s, "mocha_embed_front", "emb.front", b * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b * 60.0 * (V * 15 + 6 * 192) * 4,
+           launch_embed_front(X, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar"), b * 60, V, c->cfg.C_in, s));
     // gcn 1x1 conv on the pooled operand: (b*360, 192) x (256,192)^T + pooled bias
     GemmParams g1 = plain(WS(c, "hbar"), 192, DW(c, "emb.Wg"), WS(c, "ybar"), 256, b * 360, 256, 192);
     g1.rowbias = DW(c, "emb.rbg"); g1.rb_mod = 6;
-    KCHK(c, launch_gemm(g1, s));
+    GEMM(c, s, "emb.gcn_joint", g1);
     // temporal conv k=5 (reflect) fused with AvgPool2d((4,1)):  (b*90, 5*256) x (256, 1280)^T   blocks.py:112-118, model.py:47
     GemmParams g2 = plain(WS(c, "ybar"), 256, DW(c, "emb.Wt"), WS(c, "x5"), 256, b * 90, 256, 1280);
     g2.gather = 1; g2.T_out = 15; g2.V = 6; g2.ntaps = 5; g2.pad = 2; g2.stride = 4; g2.R = 4; g2.T_full = 60;
     g2.tshift = 0; g2.Cc = 256; g2.T_src = 60; g2.ascale = 0.25f; g2.bias = DW(c, "emb.bt");
-    KCHK(c, launch_gemm(g2, s));
+    GEMM(c, s, "emb.tcn_joint_pool", g2);
     // body block                                                               model.py:48,137-162
-    KCHK(c, launch_body_front(WS(c, "x5"), DW(c, "A_b"), WS(c, "xA"), b * 15, s));
+    LAUNCH(c, s, "mocha_body_front", "emb.body_front", b * 90.0 * 512 * 12, b * 90.0 * (256 + 512) * 4, launch_body_front(WS(c, "x5"), DW(c, "A_b"), WS(c, "xA"), b * 15, s));
     GemmParams g3 = plain(WS(c, "xA"), 512, DW(c, "emb.Wgb"), WS(c, "t1"), 256, b * 90, 256, 512);
     g3.rowbias = DW(c, "emb.rbb"); g3.rb_mod = 6;
-    KCHK(c, launch_gemm(g3, s));
+    GEMM(c, s, "emb.gcn_body", g3);
     GemmParams g4 = plain(WS(c, "t1"), 256, DW(c, "emb.Wtb"), tokens, 256, b * 90, 256, 768);
     g4.gather = 1; g4.T_out = 15; g4.V = 6; g4.ntaps = 3; g4.pad = 1; g4.stride = 1; g4.R = 1; g4.T_full = 15;
     g4.tshift = 0; g4.Cc = 256; g4.T_src = 15; g4.bias = DW(c, "emb.btb");
     if (add_pos) { g4.rowbias = DW(c, "pos_emb"); g4.rb_mod = 90; }           // model.py:88
-    KCHK(c, launch_gemm(g4, s));
+    GEMM(c, s, "emb.tcn_body", g4);
     return 0;
 }
 
@@ -333,13 +364,13 @@ int run_out_ff(mocha_ctx* c, const std::string& p, const float* ao, int inner, c
                float* out, hipStream_t s) {
     GemmParams o = plain(ao, inner, DW(c, p + ".Wo"), WS(c, "xb"), 256, M, 256, inner);
     o.bias = DW(c, p + ".bo"); o.residual = resid; o.ldr = 256;
-    KCHK(c, launch_gemm(o, s));
+    GEMM(c, s, "xf.out_proj", o);
     GemmParams f1 = plain(WS(c, "xb"), 256, DW(c, p + ".W1"), WS(c, "hff"), mlp, M, mlp, 256);
     f1.bias = DW(c, p + ".b1"); f1.act = 1;
-    KCHK(c, launch_gemm(f1, s));
+    GEMM(c, s, "xf.ff1", f1);
     GemmParams f2 = plain(WS(c, "hff"), mlp, DW(c, p + ".W2"), out, 256, M, 256, mlp);
     f2.bias = DW(c, p + ".b2"); f2.residual = WS(c, "xb"); f2.ldr = 256;
-    KCHK(c, launch_gemm(f2, s));
+    GEMM(c, s, "xf.ff2", f2);
     return 0;
 }
 
@@ -350,10 +381,11 @@ int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStr
     for (int l = 0; l < c->cfg.enc_depth; ++l) {
         const std::string p = "enc" + std::to_string(l);
         GemmParams q = plain(x, 256, DW(c, p + ".Wqkv"), WS(c, "qkv"), 3 * inner, M, 3 * inner, 256);
-        KCHK(c, launch_gemm(q, s));
+        GEMM(c, s, "enc.qkv", q);
         AttnParams a{WS(c, "qkv"), WS(c, "qkv") + inner, WS(c, "qkv") + 2 * inner, WS(c, "ao"),
                      3 * inner, 3 * inner, 3 * inner, inner, b, H, DH, 90, (float)std::pow((double)DH, -0.5)};
-        KCHK(c, launch_attention(a, s));
+        LAUNCH(c, s, DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>", "enc.attn", 4.0 * b * H * 90.0 * 90 * DH,
+               4.0 * M * 4 * inner, launch_attention(a, s));
         float* out = (l == c->cfg.enc_depth - 1) ? encoded : WS(c, "xa");
         int rc = run_out_ff(c, p, WS(c, "ao"), inner, x, M, c->cfg.enc_mlp, out, s);
         if (rc) return rc;
@@ -366,7 +398,7 @@ int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStr
 int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* outp, hipStream_t s) {
     const int M = b * 90, H = c->cfg.dec_heads, DH = c->cfg.dec_dim_head, inner = H * DH;
     // IN(cha) feeds every layer's keys; mean over tokens of cha feeds every layer's style MLP
-    KCHK(c, launch_instnorm(cha, WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s));
+    LAUNCH(c, s, "mocha_instnorm", "dec.in_cha", 0.0, b * 90.0 * 256 * 4 * 2, launch_instnorm(cha, WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s));
     const float* x = src;
     float* qb = WS(c, "qkv");
     float* kb = qb + (size_t)M * inner;
@@ -376,19 +408,20 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
         // style MLP: Linear 256->512, LeakyReLU, Linear 512->512           net/transformer.py:102-107
         GemmParams s1 = plain(WS(c, "smean"), 256, DW(c, p + ".Ws1"), WS(c, "s1"), 512, b, 512, 256);
         s1.bias = DW(c, p + ".bs1"); s1.act = 2;
-        KCHK(c, launch_gemm(s1, s));
+        GEMM(c, s, "dec.style1", s1);
         GemmParams s2 = plain(WS(c, "s1"), 512, DW(c, p + ".Ws2"), WS(c, "gb"), 512, b, 512, 512);
         s2.bias = DW(c, p + ".bs2");
-        KCHK(c, launch_gemm(s2, s));
-        KCHK(c, launch_adain(x, WS(c, "gb"), WS(c, "xad"), WS(c, "qin"), b, 90, s));
+        GEMM(c, s, "dec.style2", s2);
+        LAUNCH(c, s, "mocha_adain", "dec.adain", 0.0, b * 90.0 * 256 * 4 * 3, launch_adain(x, WS(c, "gb"), WS(c, "xad"), WS(c, "qin"), b, 90, s));
         GemmParams gq = plain(WS(c, "qin"), 256, DW(c, p + ".Wq"), qb, inner, M, inner, 256);
-        KCHK(c, launch_gemm(gq, s));
+        GEMM(c, s, "dec.q", gq);
         GemmParams gk = plain(WS(c, "kin"), 256, DW(c, p + ".Wk"), kb, inner, M, inner, 256);
-        KCHK(c, launch_gemm(gk, s));
+        GEMM(c, s, "dec.k", gk);
         GemmParams gv = plain(cha, 256, DW(c, p + ".Wv"), vb, inner, M, inner, 256);
-        KCHK(c, launch_gemm(gv, s));
+        GEMM(c, s, "dec.v", gv);
         AttnParams a{qb, kb, vb, WS(c, "ao"), inner, inner, inner, inner, b, H, DH, 90, (float)std::pow((double)DH, -0.5)};
-        KCHK(c, launch_attention(a, s));
+        LAUNCH(c, s, DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>", "dec.attn", 4.0 * b * H * 90.0 * 90 * DH,
+               4.0 * M * 4 * inner, launch_attention(a, s));
         float* out = (l == c->cfg.dec_depth - 1) ? outp : WS(c, "xa");
         int rc = run_out_ff(c, p, WS(c, "ao"), inner, WS(c, "xad"), M, c->cfg.dec_mlp, out, s);
         if (rc) return rc;
@@ -400,25 +433,25 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
 // to_mot (model.py:71-80)
 int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s) {
     const int V = c->cfg.V, M = b * 90;
-    KCHK(c, launch_body_front(tokens, DW(c, "A_b"), WS(c, "xA"), b * 15, s));
+    LAUNCH(c, s, "mocha_body_front", "mot.body_front", b * 90.0 * 512 * 12, b * 90.0 * (256 + 512) * 4, launch_body_front(tokens, DW(c, "A_b"), WS(c, "xA"), b * 15, s));
     GemmParams g1 = plain(WS(c, "xA"), 512, DW(c, "mot.Wgb"), WS(c, "t1"), 256, M, 256, 512);
     g1.rowbias = DW(c, "mot.rbb"); g1.rb_mod = 6;
-    KCHK(c, launch_gemm(g1, s));
+    GEMM(c, s, "mot.gcn_body", g1);
     GemmParams g2 = plain(WS(c, "t1"), 256, DW(c, "mot.Wtb"), WS(c, "x5"), 256, M, 256, 768);
     g2.gather = 1; g2.T_out = 15; g2.V = 6; g2.ntaps = 3; g2.pad = 1; g2.stride = 1; g2.R = 1; g2.T_full = 15;
     g2.tshift = 0; g2.Cc = 256; g2.T_src = 15; g2.bias = DW(c, "mot.btb");
-    KCHK(c, launch_gemm(g2, s));
+    GEMM(c, s, "mot.tcn_body", g2);
     // joint block gcn conv at body-part resolution (upsample + unpool only copy rows):  lrelu -> 256 -> 3*64
     GemmParams g3 = plain(WS(c, "x5"), 256, DW(c, "mot.Wg2"), WS(c, "g"), 192, M, 192, 256);
     g3.a_lrelu = 1; g3.bias = DW(c, "mot.bg2");
-    KCHK(c, launch_gemm(g3, s));
-    KCHK(c, launch_joint_expand(WS(c, "g"), DW(c, "AU"), WS(c, "y2c"), b * 15, V, s));
+    GEMM(c, s, "mot.gcn_joint", g3);
+    LAUNCH(c, s, "mocha_joint_expand", "mot.joint_expand", b * 15.0 * V * 64 * 36, b * 15.0 * (6 * 192 + V * 64) * 4, launch_joint_expand(WS(c, "g"), DW(c, "AU"), WS(c, "y2c"), b * 15, V, s));
     // temporal conv k=5 over the x4-upsampled frames, read through the gather (t >> 2)
     GemmParams g4 = plain(WS(c, "y2c"), 64, DW(c, "mot.Wt2"), WS(c, "z"), 64, b * 60 * V, 64, 320);
     g4.gather = 1; g4.T_out = 60; g4.V = V; g4.ntaps = 5; g4.pad = 2; g4.stride = 1; g4.R = 1; g4.T_full = 60;
     g4.tshift = 2; g4.Cc = 64; g4.T_src = 15; g4.bias = DW(c, "mot.bt2");
-    KCHK(c, launch_gemm(g4, s));
-    KCHK(c, launch_final_proj(WS(c, "z"), DW(c, "mot.W6"), DW(c, "mot.b6"), Y, b * 60 * V, c->cfg.C_in, s));
+    GEMM(c, s, "mot.tcn_joint", g4);
+    LAUNCH(c, s, "mocha_final_proj", "mot.final_proj", b * 60.0 * V * 64 * 15 * 2, b * 60.0 * V * (64 + 15) * 4, launch_final_proj(WS(c, "z"), DW(c, "mot.W6"), DW(c, "mot.b6"), Y, b * 60 * V, c->cfg.C_in, s));
     return 0;
 }
 
@@ -447,8 +480,8 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     }
     GemmParams g = plain(qnm, D, c->bank_cnt, c->match_S.p, (int)N, Q, (int)N, D);
     g.ksplit = ksplit; g.slab_stride = (long long)Q * N;
-    KCHK(c, launch_gemm(g, s));
-    KCHK(c, launch_argmin(c->match_S.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_cnt, Q, N, D, idx, dist, s));
+    GEMM(c, s, "match.qk", g);
+    LAUNCH(c, s, "mocha_argmin", "match.argmin", 0.0, (double)ksplit * Q * N * 4, launch_argmin(c->match_S.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_cnt, Q, N, D, idx, dist, s));
     return 0;
 }
 
@@ -658,7 +691,8 @@ int mocha_mvn(mocha_ctx* c, const float* encoded, int B, float* cnt, const float
     if (!encoded || !cnt || B < 0) return fail(c, MOCHA_ERR_ARG, "bad mvn arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const bool zn = cnt_nm && cnt_mean && cnt_std;
-    KCHK(c, launch_instnorm(encoded, cnt, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr, zn ? cnt_nm : nullptr, B, 90, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * (zn ? 3 : 2), launch_instnorm(encoded, cnt, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr, zn ? cnt_nm : nullptr, B, 90, s));
     return 0;
 }
 
@@ -675,8 +709,9 @@ int mocha_encode(mocha_ctx* c, const float* X, int B, float* encoded, float* cnt
         rc = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s);
         if (rc) return rc;
         if (cnt)
-            KCHK(c, launch_instnorm(encoded + b0 * ts, cnt + b0 * ts, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
-                                    zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
+            LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (zn ? 3 : 2),
+                   launch_instnorm(encoded + b0 * ts, cnt + b0 * ts, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
+                                   zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
     }
     return 0;
 }
@@ -751,7 +786,7 @@ int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int6
         c->bank_norm_cap = (size_t)N;
     }
     c->bank_N = N;
-    KCHK(c, launch_rownorm2(c->bank_cnt, c->bank_norm, N, (int)D, s));
+    LAUNCH(c, s, "mocha_rownorm2", "bank.norms", 2.0 * N * D, 4.0 * N * D, launch_rownorm2(c->bank_cnt, c->bank_norm, N, (int)D, s));
     return 0;
 }
 
@@ -766,7 +801,8 @@ int mocha_bank_gather(mocha_ctx* c, const int32_t* idx, int Q, float* out, void*
     int rc = ready(c, 0); if (rc) return rc;
     if (!c->bank_enc) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
     if (!idx || !out || Q < 0) return fail(c, MOCHA_ERR_ARG, "bad gather arguments");
-    KCHK(c, launch_gather_rows(c->bank_enc, idx, out, Q, 90 * 256, (hipStream_t)stream));
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, Q * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, idx, out, Q, 90 * 256, s));
     return 0;
 }
 
@@ -782,12 +818,55 @@ int mocha_characterize(mocha_ctx* c, const float* src_X, int B, const float* cnt
         int32_t* ix = idx ? idx + b0 : c->idx_ws;
         if ((rc = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s))) return rc;
         if ((rc = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return rc;
-        KCHK(c, launch_instnorm(WS(c, "enc_s"), WS(c, "cnt"), nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s));
+        LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * 3, launch_instnorm(WS(c, "enc_s"), WS(c, "cnt"), nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s));
         if ((rc = do_match(c, WS(c, "qnm"), b, ix, nullptr, s))) return rc;
-        KCHK(c, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), b, 90 * 256, s));
+        LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, b * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), b, 90 * 256, s));
         if ((rc = run_decoder(c, WS(c, "enc_s"), WS(c, "sel"), b, WS(c, "dec"), s))) return rc;
         if ((rc = run_to_mot(c, WS(c, "dec"), b, Y + b0 * xs, s))) return rc;
     }
+    return 0;
+}
+
+int mocha_profile_start(mocha_ctx* c) {
+    if (!c) return MOCHA_ERR_ARG;
+    for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    c->prof.clear();
+    c->prof_on = true;
+    return 0;
+}
+
+int mocha_profile_stop(mocha_ctx* c, char* json, int64_t cap) {
+    if (!c || !json || cap < 64) return fail(c, MOCHA_ERR_ARG, "bad profile buffer");
+    c->prof_on = false;
+    HIPCHK(c, hipSetDevice(c->device));
+    struct Agg { long n = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> byk, bys;
+    for (auto& r : c->prof) {
+        HIPCHK(c, hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, r.e0, r.e1));
+        for (auto* m : {&byk, &bys}) {
+            Agg& a = (*m)[m == &byk ? r.kernel : r.site + "|" + r.kernel];
+            a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+        }
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    c->prof.clear();
+    std::string o = "{";
+    for (int pass = 0; pass < 2; ++pass) {
+        o += pass ? ",\"sites\":{" : "\"kernels\":{";
+        bool first = true;
+        for (auto& kv : (pass ? bys : byk)) {
+            char buf[384];
+            snprintf(buf, sizeof buf, "%s\"%s\":{\"launches\":%ld,\"ms\":%.6f,\"flops\":%.6e,\"bytes\":%.6e}", first ? "" : ",",
+                     kv.first.c_str(), kv.second.n, kv.second.ms, kv.second.flops, kv.second.bytes);
+            o += buf; first = false;
+        }
+        o += "}";
+    }
+    o += "}";
+    if ((int64_t)o.size() + 1 > cap) return fail(c, MOCHA_ERR_ARG, "profile buffer too small (%zu needed)", o.size() + 1);
+    memcpy(json, o.c_str(), o.size() + 1);
     return 0;
 }
 

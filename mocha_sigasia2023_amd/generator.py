@@ -184,6 +184,17 @@ class Generator:
         self._ctx.call("mocha_reserve", int(max_batch))
         return self
 
+    # ---- measurement support -----------------------------------------------------------
+    def profile_start(self):
+        """Bracket every kernel launch with HIP events until ``profile_stop`` (bench.py)."""
+        self._ctx.call("mocha_profile_start")
+
+    def profile_stop(self) -> dict:
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        self._ctx.call("mocha_profile_stop", buf, len(buf))
+        return json.loads(buf.value.decode())
+
     # ---- sub-module call surface of the demo -----------------------------------------
     def _need(self):
         if not self._loaded:
