@@ -4,12 +4,20 @@
 // contractions with no normalisation layers in between; v_mfma_f32_32x32x2_f32 is a k-ordered
 // fmaf chain (bit-for-bit f32) at the full f32 rate (157 TFLOP/s dense peak on MI355X).
 //
-// Tile: 128 x BN x 32 per 256-thread workgroup (4 waves, each TM x TN tiles of 32x32),
-// two LDS stages (one s_barrier per K slab), next slab prefetched global->VGPR while the
-// current one is multiplied.  LDS rows are 36 floats (32 + 4 pad): the per-lane ds_read_b128 of
-// four consecutive k is bank-conflict free for every 16-lane service group (36*i mod 64 are 16
-// distinct multiples of 4).  Each lane's four k values feed four consecutive MFMAs; A and B use
-// the same k permutation so the sum over k is unchanged.
+// Structure (measured reasons in DESIGN.md §GEMM):
+//   * 128 x BN x 32 tile per 256-thread workgroup (4 waves, each TM x TN MFMA tiles of 32x32).  One
+//     LDS stage (36.9 KB for BN = 128) so that three workgroups share a CU: the K loops of this path
+//     are short (6-40 slabs), and a third co-resident workgroup hides more of the prologue /
+//     epilogue of its neighbours than a second LDS stage hides inside one workgroup (measured).
+//     The next slab is prefetched global->VGPR while the current one is multiplied.
+//   * LDS rows are 36 floats (32 + 4 pad): the per-lane ds_read_b128 of four consecutive k is
+//     bank-conflict free for every 16-lane service group (36*i mod 64 = 16 distinct multiples of 4).
+//     Each lane's four k values feed four consecutive MFMAs; A and B use the same k permutation.
+//   * The MFMA is issued with the operands swapped (W tile as "A", activation tile as "B"), so an
+//     accumulator holds C^T: lane&31 = output row, registers 4g..4g+3 = four consecutive output
+//     columns -> 16-byte stores and 16-byte bias / residual fetches (4x fewer store instructions).
+//   * XCD-aware tile order: the n-tiles of one m-tile get block ids that are equal mod 8, so they
+//     run on one XCD and share its L2 copy of the A tile (placement is a speed matter only).
 //
 // The A operand can be gathered on the fly (temporal conv as GEMM, reflect padding, folded
 // average pooling / nearest upsampling), see kernels.h.
@@ -22,7 +30,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int BM = 128;
 static constexpr int BK = 32;
-static constexpr int LDSK = 36;
+static constexpr int LDSK = BK + 4;
 
 __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * x; }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -30,73 +38,73 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 template <int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    constexpr int NA = BM / 32;                     // float4 loads of A per thread per slab
     constexpr int NB = BN / 32;                     // float4 loads of W per thread per slab
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                               // [2][BM][LDSK]
-    float* Bs = smem + 2 * BM * LDSK;               // [2][BN][LDSK]
+    float* As = smem;                               // [BM][LDSK]
+    float* Bs = smem + BM * LDSK;                   // [BN][LDSK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware tile order: the n-tiles of one m-tile get block ids that are equal mod 8, so they
-    // run on one XCD and share its L2 copy of the A tile (placement is a speed matter only).
     const int n_tiles = (p.N + BN - 1) / BN;
     const int m_tiles = (p.M + BM - 1) / BM;
     const int bid = blockIdx.x;
     const int grp = bid / (8 * n_tiles);
     const int rem = bid - grp * 8 * n_tiles;
     const int mt = grp * 8 + (rem & 7);
-    const int nt = rem >> 3;
     if (mt >= m_tiles) return;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = mt * BM, n0 = (rem >> 3) * BN;
 
-    // ---- loader assignment: 8 threads cover one 128-byte row segment
-    const int lrow = tid >> 3;
-    const int lcol = (tid & 7) * 4;
-    int a_rb[4], a_t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = m0 + lrow + 32 * i;
-        m = m < p.M ? m : p.M - 1;
-        if (p.gather) {
-            const int v = m % p.V;
-            const int bt = m / p.V;
-            const int t = bt % p.T_out;
-            const int b = bt / p.T_out;
-            a_rb[i] = b * p.T_src * p.V + v;
-            a_t[i] = t;
-        } else {
-            a_rb[i] = m;
-            a_t[i] = 0;
-        }
-    }
-    const float* wrow[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        int n = n0 + lrow + 32 * i;
-        n = n < p.N ? n : p.N - 1;
-        wrow[i] = p.W + (size_t)n * p.K + lcol;
-    }
-
-    const int slabs_total = p.K / BK;
+    const int slabs_total = p.K / BK;               // K % 32 == 0 is checked on the host
     const int per = (slabs_total + p.ksplit - 1) / p.ksplit;
     const int s_begin = blockIdx.z * per;
     const int s_end = (s_begin + per) < slabs_total ? (s_begin + per) : slabs_total;
 
-    f32x4 ra[4], rb[NB];
-    auto load_slab = [&](int s) {
+    // ---- loader: 8 threads cover one 128-byte row segment of a slab
+    const int lrow = tid >> 3;
+    const int lcol = (tid & 7) * 4;
+    int a_rb[NA], a_t[NA];
+    const float* wrow[NB];
+    {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            int m = m0 + lrow + 32 * i;
+            m = m < p.M ? m : p.M - 1;
+            if (p.gather) {
+                const int v = m % p.V;
+                const int bt = m / p.V;
+                const int t = bt % p.T_out;
+                const int b = bt / p.T_out;
+                a_rb[i] = b * p.T_src * p.V + v;
+                a_t[i] = t;
+            } else {
+                a_rb[i] = m;
+                a_t[i] = 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            int n = n0 + lrow + 32 * i;
+            n = n < p.N ? n : p.N - 1;
+            wrow[i] = p.W + (size_t)n * p.K + lcol;
+        }
+    }
+
+    f32x4 ra[NA], rb[NB];
+    auto load_slab = [&](int s) __attribute__((always_inline)) {
         const int k0 = s * BK;
         if (!p.gather) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < NA; ++i)
                 ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)a_rb[i] * p.lda + k0 + lcol);
         } else {
             const int tap = k0 / p.Cc;
             const int c0 = k0 - tap * p.Cc + lcol;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
                 for (int j = 0; j < p.R; ++j) {
                     int tf = a_t[i] * p.stride + j + tap - p.pad;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
         }
         if (p.a_lrelu) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 ra[i][0] = lrelu02(ra[i][0]); ra[i][1] = lrelu02(ra[i][1]);
                 ra[i][2] = lrelu02(ra[i][2]); ra[i][3] = lrelu02(ra[i][3]);
             }
@@ -118,11 +126,11 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + k0);
     };
-    auto store_slab = [&](int buf) {
-        float* Ab = As + buf * BM * LDSK;
-        float* Bb = Bs + buf * BN * LDSK;
+    auto store_slab = [&]() __attribute__((always_inline)) {
+        float* Ab = As;
+        float* Bb = Bs;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Ab + (lrow + 32 * i) * LDSK + lcol) = ra[i];
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<f32x4*>(Ab + (lrow + 32 * i) * LDSK + lcol) = ra[i];
 #pragma unroll
         for (int i = 0; i < NB; ++i) *reinterpret_cast<f32x4*>(Bb + (lrow + 32 * i) * LDSK + lcol) = rb[i];
     };
@@ -137,17 +145,15 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
 
     if (s_begin < s_end) {
         load_slab(s_begin);
-        store_slab(0);
+        store_slab();
     }
     __syncthreads();
 
-    int buf = 0;
+    const float* Ab = As + (wm * TM * 32 + l31) * LDSK + 4 * hh;
+    const float* Bb = Bs + (wn * TN * 32 + l31) * LDSK + 4 * hh;
     for (int s = s_begin; s < s_end; ++s) {
         const bool more = (s + 1) < s_end;
         if (more) load_slab(s + 1);                 // global -> VGPR, in flight under the MFMAs
-
-        const float* Ab = As + buf * BM * LDSK + (wm * TM * 32 + l31) * LDSK + 4 * hh;
-        const float* Bb = Bs + buf * BN * LDSK + (wn * TN * 32 + l31) * LDSK + 4 * hh;
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
             f32x4 a[TM], b[TN];
@@ -161,51 +167,81 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][ks], b[j][ks], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][ks], a[i][ks], acc[i][j], 0, 0, 0);   // C^T tile
         }
-        if (more) store_slab(buf ^ 1);              // other stage: last read one barrier ago
+        __syncthreads();                            // every wave is done reading the stage
+        if (more) store_slab();
         __syncthreads();
-        buf ^= 1;
     }
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // ---- epilogue: acc[i][j] holds C^T of MFMA tile (i, j): lane&31 = row, regs 4g..4g+3 = 4 columns
     float* Cz = p.C + (size_t)blockIdx.z * p.slab_stride;
     const bool raw = p.ksplit > 1;
+    const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) && ((p.N & 3) == 0 || raw);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const int row = m0 + (wm * TM + i) * 32 + l31;
+        if (row >= p.M) continue;
+        const float* rbrow = (!raw && p.rowbias) ? p.rowbias + (size_t)(row % p.rb_mod) * p.N : nullptr;
+        const float* rsrow = (!raw && p.residual) ? p.residual + (size_t)row * p.ldr : nullptr;
+        float* crow = Cz + (size_t)row * p.ldc;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + l31;
-            if (col >= p.N) continue;
-            const float bcol = (!raw && p.bias) ? p.bias[col] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (row >= p.M) continue;
-                float v = acc[i][j][r];
-                if (!raw) {
-                    v += bcol;
-                    if (p.rowbias) v += p.rowbias[(size_t)(row % p.rb_mod) * p.N + col];
-                    if (p.act == 1) v = gelu_erf(v);
-                    else if (p.act == 2) v = lrelu02(v);
-                    if (p.residual) v += p.residual[(size_t)row * p.ldr + col];
+            for (int g = 0; g < 4; ++g) {
+                const int col = n0 + (wn * TN + j) * 32 + 8 * g + 4 * hh;
+                if (col >= p.N) continue;
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (vec_ok && col + 3 < p.N) {
+                    if (!raw) {
+                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+                        if (rbrow) v += *reinterpret_cast<const f32x4*>(rbrow + col);
+                        if (p.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+                        else if (p.act == 2) { v[0] = lrelu02(v[0]); v[1] = lrelu02(v[1]); v[2] = lrelu02(v[2]); v[3] = lrelu02(v[3]); }
+                        if (rsrow) v += *reinterpret_cast<const f32x4*>(rsrow + col);
+                    }
+                    *reinterpret_cast<f32x4*>(crow + col) = v;
+                } else {                             // ragged N (split-K slabs of the matcher): scalar tail
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int c1 = col + e;
+                        if (c1 >= p.N) continue;
+                        float x = v[e];
+                        if (!raw) {
+                            if (p.bias) x += p.bias[c1];
+                            if (rbrow) x += rbrow[c1];
+                            if (p.act == 1) x = gelu_erf(x);
+                            else if (p.act == 2) x = lrelu02(x);
+                            if (rsrow) x += rsrow[c1];
+                        }
+                        crow[c1] = x;
+                    }
                 }
-                Cz[(size_t)row * p.ldc + col] = v;
             }
         }
     }
 }
 
-static constexpr size_t lds_bytes(int bn) { return (size_t)(2 * BM * LDSK + 2 * bn * LDSK) * sizeof(float); }
+template <int BN>
+static constexpr size_t lds_bytes() { return (size_t)(BM + BN) * LDSK * sizeof(float); }
 
 hipError_t gemm_init() {
-    hipError_t e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_f32<128, 2, 2, 2, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(128));
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_f32<128, 2, 2, 2, 2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<128>());
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_f32<64, 4, 1, 1, 2>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes(64));
-    return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_f32<64, 4, 1, 1, 2>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<64>());
+}
+
+bool gemm_is_narrow(const GemmParams& p) {
+    // Tile choice.  Every tile costs the same matrix-pipe time, so a launch takes about
+    // ceil(tiles / 256 CUs) tile-times; with few tiles per CU the rounding is expensive (824 tiles of
+    // 128x128 -> 3.2 per CU, a 4-tile critical path).  Use 128x64 tiles when that balances better.
+    const int m_tiles = (p.M + BM - 1) / BM;
+    auto balance = [](long long tiles) { return (tiles / 256.0) / (double)((tiles + 255) / 256); };
+    const long long t_wide = (long long)m_tiles * ((p.N + 127) / 128) * p.ksplit;
+    const long long t_narrow = (long long)m_tiles * ((p.N + 63) / 64) * p.ksplit;
+    return ((p.N % 128 != 0) && (p.N <= 256)) || balance(t_narrow) > 1.05 * balance(t_wide);
 }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
@@ -214,15 +250,12 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.gather && (p.Cc % BK != 0)) return hipErrorInvalidValue;
     const int m_tiles = (p.M + BM - 1) / BM;
     const int m_pad = (m_tiles + 7) / 8 * 8;
-    const bool narrow = (p.N % 128 != 0) && (p.N <= 256);     // N = 64, 192
-    if (narrow) {
-        const int n_tiles = (p.N + 63) / 64;
-        dim3 grid(m_pad * n_tiles, 1, p.ksplit);
-        hipLaunchKernelGGL((mocha_gemm_f32<64, 4, 1, 1, 2>), grid, dim3(256), lds_bytes(64), s, p);
+    if (gemm_is_narrow(p)) {
+        dim3 grid(m_pad * ((p.N + 63) / 64), 1, p.ksplit);
+        hipLaunchKernelGGL((mocha_gemm_f32<64, 4, 1, 1, 2>), grid, dim3(256), lds_bytes<64>(), s, p);
     } else {
-        const int n_tiles = (p.N + 127) / 128;
-        dim3 grid(m_pad * n_tiles, 1, p.ksplit);
-        hipLaunchKernelGGL((mocha_gemm_f32<128, 2, 2, 2, 2>), grid, dim3(256), lds_bytes(128), s, p);
+        dim3 grid(m_pad * ((p.N + 127) / 128), 1, p.ksplit);
+        hipLaunchKernelGGL((mocha_gemm_f32<128, 2, 2, 2, 2>), grid, dim3(256), lds_bytes<128>(), s, p);
     }
     return hipGetLastError();
 }

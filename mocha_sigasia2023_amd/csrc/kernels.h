@@ -36,6 +36,7 @@ struct GemmParams {
     long long slab_stride = 0;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
+bool gemm_is_narrow(const GemmParams& p);   // true: 128x64 tiles (mocha_gemm_f32<64,...>), false: 128x128
 hipError_t gemm_init();           // one-time function attributes (dynamic LDS size)
 
 // ---------------------------------------------------------------------------------------

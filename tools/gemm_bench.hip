@@ -1,0 +1,79 @@
+// Micro-benchmark + self-check of the fp32 MFMA GEMM on the shapes of the MOCHA path.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mocha_sigasia2023_amd/csrc tools/gemm_bench.hip \
+//        mocha_sigasia2023_amd/csrc/gemm_f32.o -o gpurun_out/gemm_bench      (tools/build_gemm_bench.sh)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <string>
+#include "kernels.h"
+using namespace mocha;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+__global__ void ref_gemm(const float* A, const float* W, float* C, int M, int N, int K) {
+    int n = blockIdx.x * 16 + threadIdx.x, m = blockIdx.y * 16 + threadIdx.y;
+    if (m >= M || n >= N) return;
+    double a = 0;
+    for (int k = 0; k < K; ++k) a += (double)A[(size_t)m * K + k] * W[(size_t)n * K + k];
+    C[(size_t)m * N + n] = (float)a;
+}
+
+struct Shape { const char* name; int M, N, K; int gather; int T_out, V, ntaps, pad, stride, R, T_full, tshift, Cc, T_src; int lda; };
+
+int main(int argc, char** argv) {
+    int B = argc > 1 ? atoi(argv[1]) : 585;
+    int iters = argc > 2 ? atoi(argv[2]) : 20;
+    int check = argc > 3 ? atoi(argv[3]) : 1;
+    CK(gemm_init());
+    std::vector<Shape> shapes = {
+        {"enc.qkv      ", B * 90, 1536, 256, 0},
+        {"xf.out512    ", B * 90, 256, 512, 0},
+        {"xf.ff1       ", B * 90, 512, 256, 0},
+        {"dec.q        ", B * 90, 1024, 256, 0},
+        {"dec.out1024  ", B * 90, 256, 1024, 0},
+        {"emb.gcn_joint", B * 360, 256, 192, 0},
+        {"emb.tcn_pool ", B * 90, 256, 1280, 1, 15, 6, 5, 2, 4, 4, 60, 0, 256, 60, 256},
+        {"emb.tcn_body ", B * 90, 256, 768, 1, 15, 6, 3, 1, 1, 1, 15, 0, 256, 15, 256},
+        {"mot.tcn_joint", B * 1440, 64, 320, 1, 60, 24, 5, 2, 1, 1, 60, 2, 64, 15, 64},
+        {"mot.gcn_joint", B * 90, 192, 256, 0},
+        {"match 585    ", 585, 585, 23040, 0},
+        {"square 4096  ", 4096, 4096, 4096, 0},
+    };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (auto& sh : shapes) {
+        size_t a_rows = sh.gather ? (size_t)(sh.M / (sh.T_out * sh.V)) * sh.T_src * sh.V : sh.M;
+        int lda = sh.gather ? sh.lda : sh.K;
+        size_t na = a_rows * lda, nw = (size_t)sh.N * sh.K, nc = (size_t)sh.M * sh.N;
+        std::vector<float> ha(na), hw(nw);
+        for (auto& v : ha) v = (float)rand() / RAND_MAX * 2 - 1;
+        for (auto& v : hw) v = (float)rand() / RAND_MAX * 2 - 1;
+        float *dA, *dW, *dC, *dR;
+        CK(hipMalloc(&dA, na * 4)); CK(hipMalloc(&dW, nw * 4)); CK(hipMalloc(&dC, nc * 4 * (sh.M == 585 && sh.N == 585 ? 16 : 1)));
+        CK(hipMemcpy(dA, ha.data(), na * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hw.data(), nw * 4, hipMemcpyHostToDevice));
+        GemmParams p; p.A = dA; p.W = dW; p.C = dC; p.M = sh.M; p.N = sh.N; p.K = sh.K; p.lda = lda; p.ldc = sh.N;
+        if (sh.gather) { p.gather = 1; p.T_out = sh.T_out; p.V = sh.V; p.ntaps = sh.ntaps; p.pad = sh.pad; p.stride = sh.stride; p.R = sh.R;
+                         p.T_full = sh.T_full; p.tshift = sh.tshift; p.Cc = sh.Cc; p.T_src = sh.T_src; p.ascale = sh.R > 1 ? 0.25f : 1.f; }
+        if (sh.M == 585 && sh.N == 585) { p.ksplit = 16; p.slab_stride = (long long)sh.M * sh.N; }
+        for (int i = 0; i < 3; ++i) CK(launch_gemm(p, 0));
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0, 0));
+        for (int i = 0; i < iters; ++i) CK(launch_gemm(p, 0));
+        CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+        double tf = 2.0 * sh.M * sh.N * sh.K / (ms * 1e-3) / 1e12;
+        double err = -1;
+        if (check && !sh.gather && p.ksplit == 1 && (double)sh.M * sh.N * sh.K < 3e11) {
+            CK(hipMalloc(&dR, nc * 4));
+            hipLaunchKernelGGL(ref_gemm, dim3((sh.N + 15) / 16, (sh.M + 15) / 16), dim3(16, 16), 0, 0, dA, dW, dR, sh.M, sh.N, sh.K);
+            std::vector<float> hc(nc), hr(nc);
+            CK(hipMemcpy(hc.data(), dC, nc * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr.data(), dR, nc * 4, hipMemcpyDeviceToHost));
+            err = 0; for (size_t i = 0; i < nc; ++i) err = fmax(err, fabs((double)hc[i] - hr[i]));
+            CK(hipFree(dR));
+        }
+        printf("%s M=%7d N=%5d K=%5d  %9.1f us  %7.2f TFLOP/s  (%.1f%% of 157.3)  maxerr=%g\n", sh.name, sh.M, sh.N, sh.K, ms * 1e3, tf, tf / 157.3 * 100, err);
+        CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC));
+    }
+    return 0;
+}
