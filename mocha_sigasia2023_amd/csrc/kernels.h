@@ -71,6 +71,8 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
 // AdaIN + the attention's mapping norm (net/transformer.py:108-113, 49-56):
 //   xad = (1+gamma)*IN(x)+beta ; qin = IN(xad) ; gb (B,512) = [gamma | beta]
 hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin, int B, int n, hipStream_t s);
+// u rows (b,t',p) x (dt*256+c) = 1/4 sum of the 4 reflect-indexed frames of tap dt (conv k=5 fused with AvgPool(4))
+hipError_t launch_window_sums(const float* ybar, float* u, int rows /*B*90*/, hipStream_t s);
 // bank row squared norms
 hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, hipStream_t s);
 // per query: argmin_n (bnorm[n] - 2*sum_z S[z][q][n]); then exact distance to the winner

@@ -262,7 +262,7 @@ int ensure_ws(mocha_ctx* c, int B) {
     const int V = c->cfg.V;
     const size_t T = 90 * 256;
     const std::pair<const char*, size_t> plan[] = {
-        {"hbar", 360 * 192}, {"ybar", 360 * 256}, {"x5", T}, {"xA", 90 * 512}, {"t1", T}, {"xa", T}, {"xb", T},
+        {"hbar", 360 * 192}, {"ybar", 360 * 256}, {"u", 90 * 1280}, {"x5", T}, {"xA", 90 * 512}, {"t1", T}, {"xa", T}, {"xb", T},
         {"qkv", 90 * 3072}, {"ao", 90 * 1024}, {"hff", 90 * 512}, {"kin", T}, {"xad", T}, {"qin", T},
         {"smean", 256}, {"s1", 512}, {"gb", 512}, {"g", 90 * 192}, {"y2c", (size_t)15 * V * 64},
         {"z", (size_t)60 * V * 64}, {"enc_s", T}, {"enc_c", T}, {"cnt", T}, {"qnm", T}, {"sel", T}, {"dec", T},
@@ -342,9 +342,10 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     g1.rowbias = DW(c, "emb.rbg"); g1.rb_mod = 6;
     GEMM(c, s, "emb.gcn_joint", g1);
     // temporal conv k=5 (reflect) fused with AvgPool2d((4,1)):  (b*90, 5*256) x (256, 1280)^T   blocks.py:112-118, model.py:47
-    GemmParams g2 = plain(WS(c, "ybar"), 256, DW(c, "emb.Wt"), WS(c, "x5"), 256, b * 90, 256, 1280);
-    g2.gather = 1; g2.T_out = 15; g2.V = 6; g2.ntaps = 5; g2.pad = 2; g2.stride = 4; g2.R = 4; g2.T_full = 60;
-    g2.tshift = 0; g2.Cc = 256; g2.T_src = 60; g2.ascale = 0.25f; g2.bias = DW(c, "emb.bt");
+    LAUNCH(c, s, "mocha_window_sums", "emb.window_sums", b * 90.0 * 1280 * 4, b * 4.0 * (360.0 * 256 + 90.0 * 1280),
+           launch_window_sums(WS(c, "ybar"), WS(c, "u"), b * 90, s));
+    GemmParams g2 = plain(WS(c, "u"), 1280, DW(c, "emb.Wt"), WS(c, "x5"), 256, b * 90, 256, 1280);
+    g2.bias = DW(c, "emb.bt");
     GEMM(c, s, "emb.tcn_joint_pool", g2);
     // body block                                                               model.py:48,137-162
     LAUNCH(c, s, "mocha_body_front", "emb.body_front", b * 90.0 * 512 * 12, b * 90.0 * (256 + 512) * 4, launch_body_front(WS(c, "x5"), DW(c, "A_b"), WS(c, "xA"), b * 15, s));

@@ -188,34 +188,65 @@ hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, f
 // ---------------------------------------------------------------------------------------
 // instance norm over the token axis, per (window, channel)  (net/transformer.py:13-20):
 //   mean = sum/n ; std = sqrt(sum (x-mean)^2 / (n-1)) ; out = (x-mean)/(std+1e-5)
-// one workgroup per window, thread = channel (dim is 256 on this path)
+// One workgroup per window.  Thread = (channel quad q = tid&63, token group g = tid>>6): it keeps
+// its <= 24 tokens x 4 channels in registers (one 16-byte load each), so the window is read once;
+// the four token groups combine their partial sums through LDS.
 // ---------------------------------------------------------------------------------------
+static constexpr int IN_MAXT = 24;          // tokens per thread (n <= 96)
+
+__device__ __forceinline__ f32x4 group_sum4(f32x4 v, f32x4* red, int q, int g) {
+    __syncthreads();                         // red[] may still be read from the previous reduction
+    red[g * 64 + q] = v;
+    __syncthreads();
+    return (red[q] + red[64 + q]) + (red[128 + q] + red[192 + q]);
+}
+
+__device__ __forceinline__ void inorm_stats(const f32x4* xv, int cnt, int n, f32x4* red, int q, int g, f32x4& mean, f32x4& den) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < IN_MAXT; ++i)
+        if (i < cnt) s += xv[i];
+    mean = group_sum4(s, red, q, g) / (float)n;
+    f32x4 qq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < IN_MAXT; ++i)
+        if (i < cnt) { const f32x4 d = xv[i] - mean; qq += d * d; }
+    qq = group_sum4(qq, red, q, g) / (float)(n - 1);
+    den[0] = sqrtf(qq[0]) + 1e-5f; den[1] = sqrtf(qq[1]) + 1e-5f; den[2] = sqrtf(qq[2]) + 1e-5f; den[3] = sqrtf(qq[3]) + 1e-5f;
+}
+
 __global__ __launch_bounds__(256) void mocha_instnorm(const float* __restrict__ x, float* __restrict__ out,
                                                       float* __restrict__ mean_out, const float* __restrict__ gm,
                                                       const float* __restrict__ gs, float* __restrict__ zn, int n) {
-    const int b = blockIdx.x, c = threadIdx.x;
-    const float* xb = x + (size_t)b * n * 256 + c;
-    float s = 0.f;
-    for (int i = 0; i < n; ++i) s += xb[i * 256];
-    const float mean = s / (float)n;
-    float q = 0.f;
-    for (int i = 0; i < n; ++i) {
-        const float d = xb[i * 256] - mean;
-        q = fmaf(d, d, q);
-    }
-    const float den = sqrtf(q / (float)(n - 1)) + 1e-5f;
-    if (mean_out) mean_out[(size_t)b * 256 + c] = mean;
-    float* ob = out + (size_t)b * n * 256 + c;
-    for (int i = 0; i < n; ++i) {
-        const float v = (xb[i * 256] - mean) / den;
-        ob[i * 256] = v;
-        if (zn) zn[(size_t)b * n * 256 + i * 256 + c] = (v - gm[i * 256 + c]) / gs[i * 256 + c];
-    }
+    __shared__ f32x4 red[256];
+    const int b = blockIdx.x, q = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int cnt = (n - g + 3) / 4;                       // tokens g, g+4, ...
+    const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * n * 256) + q;
+    f32x4 xv[IN_MAXT];
+#pragma unroll
+    for (int i = 0; i < IN_MAXT; ++i)
+        if (i < cnt) xv[i] = xb[(size_t)(g + 4 * i) * 64];
+    f32x4 mean, den;
+    inorm_stats(xv, cnt, n, red, q, g, mean, den);
+    if (mean_out && g == 0) reinterpret_cast<f32x4*>(mean_out + (size_t)b * 256)[q] = mean;
+    f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * n * 256) + q;
+#pragma unroll
+    for (int i = 0; i < IN_MAXT; ++i)
+        if (i < cnt) {
+            const int t = g + 4 * i;
+            const f32x4 v = (xv[i] - mean) / den;
+            ob[(size_t)t * 64] = v;
+            if (zn) {
+                const f32x4 m = reinterpret_cast<const f32x4*>(gm)[t * 64 + q], sd = reinterpret_cast<const f32x4*>(gs)[t * 64 + q];
+                (reinterpret_cast<f32x4*>(zn + (size_t)b * n * 256) + q)[(size_t)t * 64] = (v - m) / sd;
+            }
+        }
 }
 
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
                            int B, int n, hipStream_t s) {
     if (B <= 0) return hipSuccess;
+    if (n > 4 * IN_MAXT || n < 2) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mocha_instnorm, dim3(B), dim3(256), 0, s, x, out, mean_out, gm, gs, zn, n);
     return hipGetLastError();
 }
@@ -224,40 +255,69 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
 //   xad = (1+gamma) * IN(x) + beta ;  qin = IN(xad)
 __global__ __launch_bounds__(256) void mocha_adain(const float* __restrict__ x, const float* __restrict__ gb,
                                                    float* __restrict__ xad, float* __restrict__ qin, int n) {
-    const int b = blockIdx.x, c = threadIdx.x;
-    const float* xb = x + (size_t)b * n * 256 + c;
-    const float gamma1 = 1.f + gb[(size_t)b * 512 + c];
-    const float beta = gb[(size_t)b * 512 + 256 + c];
-    float s = 0.f;
-    for (int i = 0; i < n; ++i) s += xb[i * 256];
-    const float mean = s / (float)n;
-    float q = 0.f;
-    for (int i = 0; i < n; ++i) {
-        const float d = xb[i * 256] - mean;
-        q = fmaf(d, d, q);
-    }
-    const float den = sqrtf(q / (float)(n - 1)) + 1e-5f;
-    float* ab = xad + (size_t)b * n * 256 + c;
-    float s2 = 0.f;
-    for (int i = 0; i < n; ++i) {
-        const float v = gamma1 * ((xb[i * 256] - mean) / den) + beta;
-        ab[i * 256] = v;
-        s2 += v;
-    }
-    const float mean2 = s2 / (float)n;
-    float q2 = 0.f;
-    for (int i = 0; i < n; ++i) {
-        const float d = ab[i * 256] - mean2;      // own writes, same thread: visible
-        q2 = fmaf(d, d, q2);
-    }
-    const float den2 = sqrtf(q2 / (float)(n - 1)) + 1e-5f;
-    float* qb = qin + (size_t)b * n * 256 + c;
-    for (int i = 0; i < n; ++i) qb[i * 256] = (ab[i * 256] - mean2) / den2;
+    __shared__ f32x4 red[256];
+    const int b = blockIdx.x, q = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int cnt = (n - g + 3) / 4;
+    const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * n * 256) + q;
+    f32x4 xv[IN_MAXT];
+#pragma unroll
+    for (int i = 0; i < IN_MAXT; ++i)
+        if (i < cnt) xv[i] = xb[(size_t)(g + 4 * i) * 64];
+    f32x4 gamma1 = reinterpret_cast<const f32x4*>(gb + (size_t)b * 512)[q];
+    const f32x4 beta = reinterpret_cast<const f32x4*>(gb + (size_t)b * 512 + 256)[q];
+    gamma1 += 1.f;
+    f32x4 mean, den;
+    inorm_stats(xv, cnt, n, red, q, g, mean, den);
+    f32x4* ab = reinterpret_cast<f32x4*>(xad + (size_t)b * n * 256) + q;
+#pragma unroll
+    for (int i = 0; i < IN_MAXT; ++i)
+        if (i < cnt) {
+            xv[i] = gamma1 * ((xv[i] - mean) / den) + beta;
+            ab[(size_t)(g + 4 * i) * 64] = xv[i];
+        }
+    inorm_stats(xv, cnt, n, red, q, g, mean, den);
+    f32x4* qb = reinterpret_cast<f32x4*>(qin + (size_t)b * n * 256) + q;
+#pragma unroll
+    for (int i = 0; i < IN_MAXT; ++i)
+        if (i < cnt) qb[(size_t)(g + 4 * i) * 64] = (xv[i] - mean) / den;
 }
 
 hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin, int B, int n, hipStream_t s) {
     if (B <= 0) return hipSuccess;
+    if (n > 4 * IN_MAXT || n < 2) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mocha_adain, dim3(B), dim3(256), 0, s, x, gb, xad, qin, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// window_sums: operand of the joint temporal conv fused with AvgPool2d((4,1)) (blocks.py:112-118, model.py:47):
+//   u[(b,t',p)][dt*256 + c] = 1/4 * sum_{j<4} y[(b, refl(4t'+j+dt-2, 60), p)][c],   dt = 0..4
+// The five overlapping 4-frame windows of one output row share 8 input frames; one thread loads the
+// 8 frames of its (row, channel quad) once and emits the five sums.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_window_sums(const float* __restrict__ y, float* __restrict__ u, int rows /*B*15*6*/) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int row = gid >> 6, q = gid & 63;
+    if (row >= rows) return;
+    const int pp = row % 6, bt = row / 6, t15 = bt % 15, b = bt / 15;
+    const f32x4* yb = reinterpret_cast<const f32x4*>(y) + ((size_t)b * 60 * 6 + pp) * 64 + q;
+    f32x4 f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int t = 4 * t15 - 2 + i;
+        t = t < 0 ? -t : t;
+        t = t > 59 ? 118 - t : t;
+        f[i] = yb[(size_t)t * 6 * 64];
+    }
+    f32x4* ub = reinterpret_cast<f32x4*>(u) + (size_t)row * 5 * 64 + q;
+#pragma unroll
+    for (int dt = 0; dt < 5; ++dt) ub[dt * 64] = (((f[dt] + f[dt + 1]) + f[dt + 2]) + f[dt + 3]) * 0.25f;
+}
+
+hipError_t launch_window_sums(const float* y, float* u, int rows, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    const long long threads = (long long)rows * 64;
+    hipLaunchKernelGGL(mocha_window_sums, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, y, u, rows);
     return hipGetLastError();
 }
 
