@@ -70,18 +70,15 @@ def cpu_baseline(sd, V, n, mean, std):
 
 def main():
     a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from mocha_sigasia2023_amd import distributed as D
+    rank, local, world = D.env_rank()
     dist_on = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        D.init("nccl", dev)                       # "nccl" is RCCL on ROCm
 
     from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, synthetic_state_dict
     layout = "mocha" if a.joints == 24 else "mixamo"
@@ -103,10 +100,9 @@ def main():
         std = torch.empty_like(mean)
     bcast_ms = None
     if dist_on:
-        torch.cuda.synchronize(); dist.barrier()
+        torch.cuda.synchronize(); D.barrier()
         t0 = time.perf_counter()
-        for t in (cha, mean, std):
-            dist.broadcast(t, src=0)              # RCCL over xGMI, set-up only
+        D.broadcast_([cha, mean, std], src=0)     # RCCL over xGMI, set-up only: rank 0 owns the character clip
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
 
@@ -117,9 +113,8 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-            torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
 
     with torch.no_grad():
         for _ in range(a.warmup):
@@ -130,10 +125,7 @@ def main():
             Y, idx = step()
         sync_all()
         elapsed = time.perf_counter() - t0
-    if dist_on:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = D.max_over_ranks(elapsed, dev)
     ms_per_step = elapsed / a.steps * 1e3
     value = world * W * a.steps / elapsed
 
@@ -181,8 +173,8 @@ def main():
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist_on:
-        dist.barrier()
-        dist.destroy_process_group()
+        D.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
