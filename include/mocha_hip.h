@@ -96,6 +96,10 @@ int mocha_forward_features(mocha_ctx* ctx, const float* src_X, const float* cha_
  * encoded (N, 90, 256) the features gathered for the decoder.  flags bit 0: borrow the
  * caller's buffers instead of copying (they must stay valid and unchanged). */
 #define MOCHA_BANK_BORROW 1
+/* flags bit 1: additionally keep a bf16 copy of cnt_nm (round-to-nearest-even) and match against it
+ * (half the HBM bytes per bank scan; BASELINE configs[2]); indices then agree with the fp32 search
+ * except where the two nearest distances differ by less than the bf16 rounding of the bank. */
+#define MOCHA_BANK_BF16 2
 int mocha_bank_set(mocha_ctx* ctx, const float* cnt_nm, const float* encoded, int64_t N, int flags, void* stream);
 /* tree.query(q, k=1), test_fullframework.py:296,443: exact Euclidean 1-NN of each z-scored
  * query row (Q, 90*256) in the bank.  idx (Q,) int32; dist (Q,) fp32 Euclidean distance to the

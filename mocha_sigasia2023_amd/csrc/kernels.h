@@ -79,6 +79,13 @@ hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, h
 hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm,
                          const float* query, const float* bank, int Q, int64_t N, int D,
                          int32_t* idx, float* dist, hipStream_t s);
+// streaming matcher for few queries against a large bank (HBM-bound): bank fp32 or bf16;
+// partial = match_stream_scratch(Q, N) u64 words of scratch
+size_t match_stream_scratch(int Q, int64_t N);
+hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* bnorm, const float* query, int Q, int64_t N, int D,
+                               unsigned long long* partial, int32_t* idx, float* dist, hipStream_t s);
+hipError_t launch_to_bf16(const float* x, void* y, int64_t n, hipStream_t s);
+hipError_t launch_rownorm2_bf16(const void* x, float* out, int64_t rows, int cols, hipStream_t s);
 // out[q] = src[idx[q]] rows of `cols` floats
 hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, int Q, int cols, hipStream_t s);
 

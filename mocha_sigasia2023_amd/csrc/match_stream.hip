@@ -1,0 +1,257 @@
+// Context matching for FEW queries against a LARGE bank: the HBM-bound regime (streaming one query
+// per frame against a 4k-16k entry bank, BASELINE configs[4]; SURVEY.md §8d "bank scan").
+//
+// exact 1-NN = argmin_b ( ||b||^2 - 2 q.b )          (test_fullframework.py:296,443)
+// The bank is read exactly once per launch, 16 bytes per lane per load, straight to registers
+// (no LDS round trip for streamed-once data); the <= 8 query vectors of a launch are staged through
+// LDS one D-chunk at a time and reused by every bank row of the workgroup.  Each wave owns whole
+// rows (lanes stride the 23 040-dim row), so a row's dot products are finished by one wave
+// reduction.  Candidates are compared as 64-bit keys (order-preserving bits of the value << 32 | row),
+// which makes ties go to the lowest index; each workgroup writes one partial minimum per query and
+// the finish kernel reduces them (no atomics: 16k same-address atomics cost more than the scan).
+// The bank may be fp32 or bf16 (widened exactly on load; half the HBM bytes).
+#include "kernels.h"
+
+namespace mocha {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int MS_ROWS_PER_WAVE = 4;      // rows a wave carries through the D loop together
+static constexpr int MS_WAVES = 4;
+static constexpr int MS_CHUNK = 1280;           // floats of every query staged per step (5 x 16 B per lane)
+
+__device__ __forceinline__ unsigned long long pack_key(float v, unsigned row) {
+    unsigned u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | row;
+}
+
+template <int Q, bool BF16>
+__global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict__ bank, const float* __restrict__ bnorm,
+                                                          const float* __restrict__ query, int nq, long long N, int D,
+                                                          unsigned long long* __restrict__ partial /*[Q8][gridDim.x]*/) {
+    __shared__ __attribute__((aligned(16))) float qs[Q * MS_CHUNK];
+    __shared__ unsigned long long wbest[MS_WAVES][Q];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long row0 = ((long long)blockIdx.x * MS_WAVES + wave) * MS_ROWS_PER_WAVE;
+
+    float acc[MS_ROWS_PER_WAVE][Q];
+#pragma unroll
+    for (int r = 0; r < MS_ROWS_PER_WAVE; ++r)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[r][q] = 0.f;
+
+    const int nchunks = D / MS_CHUNK;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();
+        // stage this chunk of every query: Q * 320 float4, 256 threads
+        for (int i = tid; i < Q * (MS_CHUNK / 4); i += 256) {
+            const int q = i / (MS_CHUNK / 4), o = i - q * (MS_CHUNK / 4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (q < nq) v = reinterpret_cast<const f32x4*>(query + (size_t)q * D + (size_t)ch * MS_CHUNK)[o];
+            reinterpret_cast<f32x4*>(qs)[i] = v;
+        }
+        __syncthreads();
+        if (!BF16) {
+            // 320 float4 per row-chunk: 5 per lane
+            f32x4 bv[MS_ROWS_PER_WAVE][5];
+#pragma unroll
+            for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
+                long long row = row0 + r;
+                row = row < N ? row : N - 1;
+                const f32x4* bp = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(bank) + (size_t)row * D + (size_t)ch * MS_CHUNK);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) bv[r][i] = __builtin_nontemporal_load(bp + lane + 64 * i);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const f32x4 qv = reinterpret_cast<const f32x4*>(qs)[q * (MS_CHUNK / 4) + lane + 64 * i];
+#pragma unroll
+                    for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
+                        acc[r][q] = fmaf(bv[r][i][0], qv[0], acc[r][q]);
+                        acc[r][q] = fmaf(bv[r][i][1], qv[1], acc[r][q]);
+                        acc[r][q] = fmaf(bv[r][i][2], qv[2], acc[r][q]);
+                        acc[r][q] = fmaf(bv[r][i][3], qv[3], acc[r][q]);
+                    }
+                }
+        } else {
+            // bf16 bank: 1280 elements = 160 x 16 B per row-chunk: lanes 0..63 take pieces lane, lane+64, (lane+128 < 160)
+            u32x4 bv[MS_ROWS_PER_WAVE][3];
+#pragma unroll
+            for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
+                long long row = row0 + r;
+                row = row < N ? row : N - 1;
+                const u32x4* bp = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(bank) + (size_t)row * D + (size_t)ch * MS_CHUNK);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const int piece = lane + 64 * i;
+                    u32x4 z = {0u, 0u, 0u, 0u};
+                    bv[r][i] = piece < MS_CHUNK / 8 ? __builtin_nontemporal_load(bp + piece) : z;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int piece = lane + 64 * i;
+                if (piece < MS_CHUNK / 8) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const f32x4 q0 = reinterpret_cast<const f32x4*>(qs)[q * (MS_CHUNK / 4) + piece * 2];
+                        const f32x4 q1 = reinterpret_cast<const f32x4*>(qs)[q * (MS_CHUNK / 4) + piece * 2 + 1];
+#pragma unroll
+                        for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
+                            const u32x4 w = bv[r][i];      // 8 bf16: element 2j in the low half of word j
+                            acc[r][q] = fmaf(__uint_as_float(w[0] << 16), q0[0], acc[r][q]);
+                            acc[r][q] = fmaf(__uint_as_float(w[0] & 0xffff0000u), q0[1], acc[r][q]);
+                            acc[r][q] = fmaf(__uint_as_float(w[1] << 16), q0[2], acc[r][q]);
+                            acc[r][q] = fmaf(__uint_as_float(w[1] & 0xffff0000u), q0[3], acc[r][q]);
+                            acc[r][q] = fmaf(__uint_as_float(w[2] << 16), q1[0], acc[r][q]);
+                            acc[r][q] = fmaf(__uint_as_float(w[2] & 0xffff0000u), q1[1], acc[r][q]);
+                            acc[r][q] = fmaf(__uint_as_float(w[3] << 16), q1[2], acc[r][q]);
+                            acc[r][q] = fmaf(__uint_as_float(w[3] & 0xffff0000u), q1[3], acc[r][q]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // finish: one wave reduction per (row, query); the workgroup's minimum per query goes to partial[]
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        unsigned long long kmin = ~0ull;
+#pragma unroll
+        for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
+            const long long row = row0 + r;
+            float v = acc[r][q];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (row < N) {
+                const unsigned long long k = pack_key(bnorm[row] - 2.f * v, (unsigned)row);
+                kmin = k < kmin ? k : kmin;
+            }
+        }
+        if (lane == 0) wbest[wave][q] = kmin;
+    }
+    __syncthreads();
+    if (tid < Q) {
+        unsigned long long k = wbest[0][tid];
+#pragma unroll
+        for (int w = 1; w < MS_WAVES; ++w) k = wbest[w][tid] < k ? wbest[w][tid] : k;
+        partial[(size_t)tid * gridDim.x + blockIdx.x] = k;
+    }
+}
+
+// partial minima -> idx[q]; Euclidean distance to the winner in the direct (q-b)^2 form
+template <bool BF16>
+__global__ __launch_bounds__(256) void mocha_match_finish(const unsigned long long* __restrict__ partial, int nwg,
+                                                          const void* __restrict__ bank, const float* __restrict__ query, int D,
+                                                          int32_t* __restrict__ idx, float* __restrict__ dist) {
+    __shared__ unsigned long long kred[256];
+    __shared__ float red[4];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long* pq = partial + (size_t)q * nwg;          // query-major: partial[q][wg]
+    unsigned long long k = ~0ull;
+    for (int i = tid; i < nwg; i += 256) k = pq[i] < k ? pq[i] : k;
+    kred[tid] = k;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) kred[tid] = kred[tid + o] < kred[tid] ? kred[tid + o] : kred[tid];
+        __syncthreads();
+    }
+    const unsigned row = (unsigned)(kred[0] & 0xffffffffull);
+    if (tid == 0) idx[q] = (int32_t)row;
+    if (!dist) return;
+    float a = 0.f;
+    for (int i = tid; i < D; i += 256) {
+        float b;
+        if (BF16) b = __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(bank)[(size_t)row * D + i] << 16);
+        else b = reinterpret_cast<const float*>(bank)[(size_t)row * D + i];
+        const float d = query[(size_t)q * D + i] - b;
+        a = fmaf(d, d, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    if (tid == 0) dist[q] = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+size_t match_stream_scratch(int Q, int64_t N) {        // u64 words of partial[] needed
+    const int rows_per_wg = MS_WAVES * MS_ROWS_PER_WAVE;
+    const size_t nwg = (size_t)((N + rows_per_wg - 1) / rows_per_wg);
+    return (size_t)((Q + 7) / 8) * 8 * nwg;
+}
+
+hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* bnorm, const float* query, int Q, int64_t N, int D,
+                               unsigned long long* partial, int32_t* idx, float* dist, hipStream_t s) {
+    if (Q <= 0) return hipSuccess;
+    if (D % MS_CHUNK != 0) return hipErrorInvalidValue;
+    const int rows_per_wg = MS_WAVES * MS_ROWS_PER_WAVE;
+    const unsigned grid = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
+    for (int q0 = 0; q0 < Q; q0 += 8) {                 // more than 8 queries: one bank pass per 8
+        const int nq = (Q - q0) < 8 ? (Q - q0) : 8;
+        const float* qp = query + (size_t)q0 * D;
+        unsigned long long* pp = partial + (size_t)q0 * grid;      // partial[q][wg], q global
+#define MS_LAUNCH(QQ)                                                                                          \
+        do {                                                                                                   \
+            if (bank_bf16) hipLaunchKernelGGL((mocha_match_stream<QQ, true>), dim3(grid), dim3(256), 0, s, bank, bnorm, qp, nq, (long long)N, D, pp); \
+            else hipLaunchKernelGGL((mocha_match_stream<QQ, false>), dim3(grid), dim3(256), 0, s, bank, bnorm, qp, nq, (long long)N, D, pp);          \
+        } while (0)
+        if (nq == 1) MS_LAUNCH(1);
+        else if (nq == 2) MS_LAUNCH(2);
+        else if (nq <= 4) MS_LAUNCH(4);
+        else MS_LAUNCH(8);
+#undef MS_LAUNCH
+    }
+    if (bank_bf16) hipLaunchKernelGGL((mocha_match_finish<true>), dim3(Q), dim3(256), 0, s, partial, (int)grid, bank, query, D, idx, dist);
+    else hipLaunchKernelGGL((mocha_match_finish<false>), dim3(Q), dim3(256), 0, s, partial, (int)grid, bank, query, D, idx, dist);
+    return hipGetLastError();
+}
+
+// fp32 -> bf16 (round to nearest even) copy of the matching bank, and its squared row norms are then
+// taken from the rounded values (launch_rownorm2_bf16) so that value and norm stay consistent
+__global__ __launch_bounds__(256) void mocha_to_bf16(const float* __restrict__ x, unsigned short* __restrict__ y, long long n4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    unsigned short o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned u = __float_as_uint(v[e]);
+        o[e] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);      // inputs are finite features
+    }
+    reinterpret_cast<uint2*>(y)[i] = make_uint2((unsigned)o[0] | ((unsigned)o[1] << 16), (unsigned)o[2] | ((unsigned)o[3] << 16));
+}
+
+__global__ __launch_bounds__(256) void mocha_rownorm2_bf16(const unsigned short* __restrict__ x, float* __restrict__ out, int cols) {
+    __shared__ float red[4];
+    const size_t row = blockIdx.x;
+    float a = 0.f;
+    for (int i = threadIdx.x; i < cols; i += 256) {
+        const float v = __uint_as_float((unsigned)x[row * cols + i] << 16);
+        a = fmaf(v, v, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[row] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+hipError_t launch_to_bf16(const float* x, void* y, int64_t n, hipStream_t s) {
+    if (n <= 0) return hipSuccess;
+    if (n % 4) return hipErrorInvalidValue;
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(mocha_to_bf16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, (unsigned short*)y, n4);
+    return hipGetLastError();
+}
+
+hipError_t launch_rownorm2_bf16(const void* x, float* out, int64_t rows, int cols, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mocha_rownorm2_bf16, dim3((unsigned)rows), dim3(256), 0, s, (const unsigned short*)x, out, cols);
+    return hipGetLastError();
+}
+
+}  // namespace mocha

@@ -120,6 +120,8 @@ struct mocha_ctx {
     float* bank_cnt_own = nullptr; float* bank_enc_own = nullptr; size_t bank_cap = 0;
     float* bank_norm = nullptr; size_t bank_norm_cap = 0;
     int64_t bank_N = 0;
+    void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
+    unsigned long long* best_ws = nullptr; size_t best_ws_n = 0;
 
     // per-launch HIP-event profiling (mocha_profile_start/stop); off in normal operation
     struct ProfRec { std::string kernel, site; hipEvent_t e0, e1; double flops, bytes; };
@@ -469,6 +471,23 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     if (!c->bank_cnt || c->bank_N <= 0) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
     const int D = 90 * 256;
     const int64_t N = c->bank_N;
+    // Few queries (streaming, one per frame) or a bf16 bank: HBM-bound bank scan, bank read once per
+    // 8 queries.  Many queries against an fp32 bank: MFMA GEMM Q.Bank^T + arg-min.
+    if (Q <= 8 || c->bank_is_bf16) {
+        const size_t need_ws = match_stream_scratch(Q, N);
+        if (c->best_ws_n < need_ws) {
+            if (c->best_ws) (void)hipFree(c->best_ws);
+            void* bp = nullptr;
+            HIPCHK(c, hipMalloc(&bp, sizeof(unsigned long long) * need_ws));
+            c->best_ws = (unsigned long long*)bp; c->best_ws_n = need_ws;
+        }
+        const void* bank = c->bank_is_bf16 ? (const void*)c->bank_bf16 : (const void*)c->bank_cnt;
+        const double passes = (Q + 7) / 8;
+        LAUNCH(c, s, c->bank_is_bf16 ? "mocha_match_stream<bf16>" : "mocha_match_stream<f32>", "match.stream", 2.0 * Q * N * D,
+               passes * N * D * (c->bank_is_bf16 ? 2.0 : 4.0) + 4.0 * Q * D,
+               launch_match_stream(bank, c->bank_is_bf16 ? 1 : 0, c->bank_norm, qnm, Q, N, D, c->best_ws, idx, dist, s));
+        return 0;
+    }
     const long long tiles = (long long)((Q + 127) / 128) * ((N + 127) / 128);
     int ksplit = (int)std::min<long long>(16, std::max<long long>(1, (768 + tiles - 1) / tiles));
     const size_t need = (size_t)ksplit * Q * N;
@@ -526,6 +545,8 @@ void mocha_destroy(mocha_ctx* c) {
     (void)hipSetDevice(c->device);
     for (float* p : c->owned) (void)hipFree(p);
     if (c->idx_ws) (void)hipFree(c->idx_ws);
+    if (c->bank_bf16) (void)hipFree(c->bank_bf16);
+    if (c->best_ws) (void)hipFree(c->best_ws);
     delete c;
 }
 
@@ -787,7 +808,28 @@ int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int6
         c->bank_norm_cap = (size_t)N;
     }
     c->bank_N = N;
-    LAUNCH(c, s, "mocha_rownorm2", "bank.norms", 2.0 * N * D, 4.0 * N * D, launch_rownorm2(c->bank_cnt, c->bank_norm, N, (int)D, s));
+    {                                                     // scratch of the streaming matcher for up to 8 queries
+        const size_t need_ws = match_stream_scratch(8, N);  // (allocated here so a later single-query step is capture-safe)
+        if (c->best_ws_n < need_ws) {
+            if (c->best_ws) (void)hipFree(c->best_ws);
+            void* bp = nullptr;
+            HIPCHK(c, hipMalloc(&bp, sizeof(unsigned long long) * need_ws));
+            c->best_ws = (unsigned long long*)bp; c->best_ws_n = need_ws;
+        }
+    }
+    c->bank_is_bf16 = (flags & MOCHA_BANK_BF16) != 0;
+    if (c->bank_is_bf16) {
+        if (c->bank_bf16_cap < (size_t)N) {
+            if (c->bank_bf16) (void)hipFree(c->bank_bf16);
+            c->bank_bf16 = nullptr;
+            HIPCHK(c, hipMalloc(&c->bank_bf16, (size_t)N * D * 2));
+            c->bank_bf16_cap = (size_t)N;
+        }
+        LAUNCH(c, s, "mocha_to_bf16", "bank.to_bf16", 0.0, 6.0 * N * D, launch_to_bf16(c->bank_cnt, c->bank_bf16, (int64_t)N * D, s));
+        LAUNCH(c, s, "mocha_rownorm2_bf16", "bank.norms", 2.0 * N * D, 2.0 * N * D, launch_rownorm2_bf16(c->bank_bf16, c->bank_norm, N, (int)D, s));
+    } else {
+        LAUNCH(c, s, "mocha_rownorm2", "bank.norms", 2.0 * N * D, 4.0 * N * D, launch_rownorm2(c->bank_cnt, c->bank_norm, N, (int)D, s));
+    }
     return 0;
 }
 

@@ -182,6 +182,7 @@ class Generator:
     def reserve(self, max_batch: int):
         """Pre-allocate workspaces for chunks of ``max_batch`` windows."""
         self._ctx.call("mocha_reserve", int(max_batch))
+        self._reserved = int(max_batch)
         return self
 
     # ---- measurement support -----------------------------------------------------------
@@ -279,7 +280,7 @@ class ContextBank:
     ``ContextBank(model, cha_cnt_nm, cha_encoded).query(src_cnt_nm)`` -> (dist, idx) like
     ``BallTree.query(k=1)``; ``gather(idx)`` -> ``cha_encoded[idx]``."""
 
-    def __init__(self, model: Generator, cha_cnt_nm, cha_encoded, copy: bool = False):
+    def __init__(self, model: Generator, cha_cnt_nm, cha_encoded, copy: bool = False, bf16: bool = False):
         model._need()
         self.model = model
         dev = model.device
@@ -289,11 +290,12 @@ class ContextBank:
             raise ValueError("bank: cnt_nm and encoded have different entry counts")
         self.N = self.cnt_nm.shape[0]
         self._copy = copy
+        self._bf16 = bf16          # match against a bf16 copy of cnt_nm (half the bytes per bank scan)
         self.activate()
 
     def activate(self):
         """Make this bank the context's current bank (borrowed buffers unless copy=True)."""
-        flags = 0 if self._copy else 1
+        flags = (0 if self._copy else 1) | (2 if self._bf16 else 0)
         self.model._ctx.call("mocha_bank_set", _ptr(self.cnt_nm), _ptr(self.encoded), self.N, flags, _stream())
         self.model._bank = self
         return self
@@ -333,3 +335,43 @@ class ContextBank:
         idx = torch.empty((X.shape[0],), dtype=torch.int32, device=m.device)
         m._ctx.call("mocha_characterize", _ptr(X), X.shape[0], _ptr(mean), _ptr(std), _ptr(Y), _ptr(idx), _stream())
         return (Y, idx) if return_index else Y
+
+
+class StreamingCharacterizer:
+    """Window-by-window characterization (BASELINE configs[4]: a clip streamed one 60-frame window
+    per step against a large bank).  The whole per-window step — encode, z-score, 1-NN bank scan,
+    gather, decoder, to_mot (test_fullframework.py:438-443,465-467) — is captured once into a HIP
+    graph and replayed per window, so the ~45 kernel launches cost one graph launch."""
+
+    def __init__(self, bank: ContextBank, cnt_mean, cnt_std, use_graph: bool = True):
+        self.bank, self.model = bank, bank.model
+        m = self.model
+        m.reserve(max(m._reserved if hasattr(m, "_reserved") else 1, 1))
+        self.mean = _dev_f32(cnt_mean, m.device, (NTOK, DIM), "cnt_mean")
+        self.std = _dev_f32(cnt_std, m.device, (NTOK, DIM), "cnt_std")
+        self.x = torch.zeros((1, m.cfg["nframes"], m.V, m.cfg["mot_in_dim"]), dtype=torch.float32, device=m.device)
+        self.y = torch.empty_like(self.x)
+        self.idx = torch.zeros((1,), dtype=torch.int32, device=m.device)
+        bank.activate()
+        self._enqueue()                                   # warm-up outside capture (lazy allocations, module load)
+        torch.cuda.synchronize(m.device)
+        self.graph = None
+        if use_graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._enqueue()
+            self.graph = g
+
+    def _enqueue(self):
+        self.model._ctx.call("mocha_characterize", _ptr(self.x), 1, _ptr(self.mean), _ptr(self.std), _ptr(self.y),
+                             _ptr(self.idx), _stream())
+
+    def step(self, window: torch.Tensor):
+        """window (60, V, 15) or (1, 60, V, 15) on the GPU -> (Y (60, V, 15) view, idx tensor view); both
+        are overwritten by the next step."""
+        self.x.copy_(window.reshape(self.x.shape), non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._enqueue()
+        return self.y[0], self.idx

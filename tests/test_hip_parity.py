@@ -167,3 +167,66 @@ def test_errors_are_loud():
         Generator(device=dev()).load_state_dict(sd).mot_embedding(torch.zeros(1, 60, 22, 15))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         Generator(device="cpu")
+
+
+def _bf16_round(a):
+    u = a.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    return (u.astype(np.uint32) << 16).view(np.float32)
+
+
+@pytest.mark.parametrize("Q", [1, 2, 3, 8])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_streaming_matcher(golden_dir, Q, bf16):
+    """Few queries / bf16 bank take the HBM-bound bank-scan kernel; indices must equal the exact search
+    (for the bf16 bank: the exact search over the bf16-rounded bank)."""
+    _, _, model, _ = load(golden_dir, "mocha24_g1")
+    mean, std = synthetic.cnt_norm(90)
+    nb = 203                                               # ragged: not a multiple of the 16 rows per workgroup
+    cha = synthetic.token_features(300, nb)
+    src = synthetic.token_features(301, Q)
+    src[0] = cha[nb - 1] + 0.05 * src[0]
+    cha_nm, src_nm = O.znorm(cha, mean, std), O.znorm(src, mean, std)
+    bank = ContextBank(model, T(cha_nm), T(cha), bf16=bf16)
+    dist, idx = bank.query(T(src_nm), k=1)
+    ref_bank = _bf16_round(np.ascontiguousarray(cha_nm)) if bf16 else cha_nm
+    ridx, rdist = O.match_bruteforce(src_nm, ref_bank)
+    assert np.array_equal(idx[:, 0].cpu().numpy().astype(np.int64), ridx)
+    assert np.allclose(dist[:, 0].cpu().numpy(), rdist, rtol=1e-5)
+    assert idx[0, 0].item() == nb - 1
+
+
+def test_bf16_bank_many_queries_agrees_with_fp32():
+    """BASELINE configs[2] shape in small: bf16 bank, many queries; report-style agreement check."""
+    sd = weights.synthetic_state_dict(9, 1.0)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    mean, std = synthetic.cnt_norm(4)
+    cha = O.znorm(synthetic.token_features(400, 96), mean, std)
+    src = O.znorm(synthetic.token_features(401, 40), mean, std)
+    i32 = ContextBank(model, T(cha), T(cha)).query(T(src), return_distance=False)[:, 0].cpu().numpy()
+    i16 = ContextBank(model, T(cha), T(cha), bf16=True).query(T(src), return_distance=False)[:, 0].cpu().numpy()
+    assert np.array_equal(i32, O.match_bruteforce(src, cha)[0])
+    assert (i32 == i16).mean() >= 0.95                    # random N(0,1) banks: gaps >> bf16 rounding
+
+
+def test_streaming_graph_replay_matches_batched():
+    """BASELINE configs[4] in small: windows streamed one per step through a captured HIP graph must
+    reproduce the batched NN-branch result bit for bit (same kernels, same order per window)."""
+    from mocha_sigasia2023_amd import StreamingCharacterizer
+    sd = weights.synthetic_state_dict(55, 1.2)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    mean, std = synthetic.cnt_norm(8)
+    cha = T(synthetic.pose_windows(70, 37))
+    src = T(synthetic.pose_windows(71, 6))
+    enc_c, cnt_c, nm_c = model.encode(cha, mean, std)
+    bank = ContextBank(model, nm_c, enc_c)
+    Yb, ib = bank.characterize(src, mean, std, return_index=True)
+    with torch.no_grad():
+        Yo, io = O.characterize(O.to_torch_state(sd), src.cpu(), cha.cpu(), mean, std)
+    assert np.array_equal(ib.cpu().numpy(), io)
+    for use_graph in (False, True):
+        sc = StreamingCharacterizer(bank, mean, std, use_graph=use_graph)
+        for i in range(src.shape[0]):
+            y, idx = sc.step(src[i])
+            assert int(idx.item()) == int(io[i])
+            assert absmax(y, Yo[i].numpy()) < TOL * max(1.0, float(Yo.abs().max()))
