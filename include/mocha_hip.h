@@ -114,6 +114,17 @@ int mocha_bank_gather(mocha_ctx* ctx, const int32_t* idx, int Q, float* out, voi
 int mocha_characterize(mocha_ctx* ctx, const float* src_X, int B, const float* cnt_mean, const float* cnt_std,
                        float* Y, int32_t* idx, void* stream);
 
+/* Pose normalisation of the demo fused into the path: the four norm.npz
+ * arrays of the reference (test_fullframework.py:64-71), HOST fp32, (V+1)*C_in each with the root bone
+ * first.  Afterwards the *_raw entry points take un-normalised poses WITH the root bone,
+ * X_raw (B,T,V+1,C_in), apply X = (X[:,:,1:] - X_mean[:,:,1:]) / X_std[:,:,1:] on load
+ * (test_fullframework.py:186,269) and return Y * Y_std[0,:,1:] + Y_mean[0,:,1:] (test_fullframework.py:303,457). */
+int mocha_set_pose_norm(mocha_ctx* ctx, const float* x_mean, const float* x_std, const float* y_mean, const float* y_std);
+int mocha_encode_raw(mocha_ctx* ctx, const float* X_raw, int B, float* encoded, float* cnt,
+                     const float* cnt_mean, const float* cnt_std, float* cnt_nm, void* stream);
+int mocha_characterize_raw(mocha_ctx* ctx, const float* src_X_raw, int B, const float* cnt_mean, const float* cnt_std,
+                           float* Y_denorm, int32_t* idx, void* stream);
+
 /* Introspection for tests and tooling. */
 int mocha_abi_version(void);
 int mocha_graph_constants(mocha_ctx* ctx, float* A_j /*3*V*V host*/, float* A_b /*2*6*6 host*/,

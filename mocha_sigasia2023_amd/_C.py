@@ -45,6 +45,9 @@ SIGNATURES = {
     "mocha_match": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "mocha_bank_gather": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mocha_characterize": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mocha_set_pose_norm": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mocha_encode_raw": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocha_characterize_raw": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mocha_graph_constants": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mocha_profile_start": (_i, [_vp]),
     "mocha_profile_stop": (_i, [_vp, C.c_char_p, _i64]),

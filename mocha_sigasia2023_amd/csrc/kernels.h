@@ -56,14 +56,18 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 // ---------------------------------------------------------------------------------------
 // X (B,T,V,Cin) -> 1x1 conv Cin->64 + bias -> LeakyReLU -> hop-partitioned adjacency -> joint->part pool,
 // written as rows (b,t,p) x (k*64+c)   [model.py:44-46 front half, net/blocks.py:57-66,131]
+// raw_root = 1: X frames are (V+1, Cin) with the root bone first and are z-scored with xmean/xstd ((V+1)*Cin) on load
 hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP /*3*V*6*/,
-                              float* out, int nframes, int V, int Cin, hipStream_t s);
+                              float* out, int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root,
+                              hipStream_t s);
 // rows (b,t,p) x 256 -> LeakyReLU -> body-part adjacency (2 hops) -> rows (b,t,w) x (k*256+c)
 hipError_t launch_body_front(const float* x, const float* A_b /*2*6*6*/, float* out, int rows6 /*B*15*/, hipStream_t s);
 // g rows (b,t',p) x (k*64+c) -> y2c rows (b,t',w) x 64 : sum_k sum_p AU[k][p][w] g[...]
 hipError_t launch_joint_expand(const float* g, const float* AU /*3*6*V*/, float* out, int nframes15, int V, hipStream_t s);
 // z rows x 64 -> LeakyReLU -> 1x1 conv 64->Cout + bias -> Y rows x Cout   [model.py:77-79]
-hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, float* Y, int rows, int Cout, hipStream_t s);
+// ymean/ystd ((V+1)*Cout, root row first) non-null: Y is de-normalised in the epilogue
+hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, float* Y, int rows, int Cout, int V,
+                             const float* ymean, const float* ystd, hipStream_t s);
 // per (b, channel) instance norm over n tokens (net/transformer.py:13-20).
 //   out = (x-mean)/(std+eps); mean_out (B,256) optional; zn = (out - gm)/gs optional
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,

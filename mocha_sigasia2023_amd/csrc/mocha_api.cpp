@@ -120,6 +120,7 @@ struct mocha_ctx {
     float* bank_cnt_own = nullptr; float* bank_enc_own = nullptr; size_t bank_cap = 0;
     float* bank_norm = nullptr; size_t bank_norm_cap = 0;
     int64_t bank_N = 0;
+    float* pose_norm = nullptr;        // [x_mean | x_std | y_mean | y_std], (V+1)*C_in each (norm.npz of the reference)
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
     unsigned long long* best_ws = nullptr; size_t best_ws_n = 0;
 
@@ -334,11 +335,14 @@ GemmParams plain(const float* A, int lda, const float* Wt, float* C, int ldc, in
 
 // ---------------------------------------------------------------- stage pipelines on one chunk
 // mot_embedding (model.py:42-50) for b windows: X -> tokens (b*90, 256)
-int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, hipStream_t s) {
+int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, hipStream_t s, bool raw = false) {
     const int V = c->cfg.V;
+    const int nn = (V + 1) * c->cfg.C_in;
+    if (raw && !c->pose_norm) return fail(c, MOCHA_ERR_STATE, "raw input needs mocha_set_pose_norm first");
     // conv1 + lrelu + adjacency + joint->part pool (commuted)                  model.py:44-46
     LAUNCH(c, s, "mocha_embed_front", "emb.front", b * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b * 60.0 * (V * 15 + 6 * 192) * 4,
-           launch_embed_front(X, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar"), b * 60, V, c->cfg.C_in, s));
+           launch_embed_front(X, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar"), b * 60, V, c->cfg.C_in,
+                              raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s));
     // gcn 1x1 conv on the pooled operand: (b*360, 192) x (256,192)^T + pooled bias
     GemmParams g1 = plain(WS(c, "hbar"), 192, DW(c, "emb.Wg"), WS(c, "ybar"), 256, b * 360, 256, 192);
     g1.rowbias = DW(c, "emb.rbg"); g1.rb_mod = 6;
@@ -434,8 +438,10 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
 }
 
 // to_mot (model.py:71-80)
-int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s) {
+int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s, bool denorm = false) {
     const int V = c->cfg.V, M = b * 90;
+    const int nn = (V + 1) * c->cfg.C_in;
+    if (denorm && !c->pose_norm) return fail(c, MOCHA_ERR_STATE, "de-normalised output needs mocha_set_pose_norm first");
     LAUNCH(c, s, "mocha_body_front", "mot.body_front", b * 90.0 * 512 * 12, b * 90.0 * (256 + 512) * 4, launch_body_front(tokens, DW(c, "A_b"), WS(c, "xA"), b * 15, s));
     GemmParams g1 = plain(WS(c, "xA"), 512, DW(c, "mot.Wgb"), WS(c, "t1"), 256, M, 256, 512);
     g1.rowbias = DW(c, "mot.rbb"); g1.rb_mod = 6;
@@ -454,7 +460,8 @@ int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s
     g4.gather = 1; g4.T_out = 60; g4.V = V; g4.ntaps = 5; g4.pad = 2; g4.stride = 1; g4.R = 1; g4.T_full = 60;
     g4.tshift = 2; g4.Cc = 64; g4.T_src = 15; g4.bias = DW(c, "mot.bt2");
     GEMM(c, s, "mot.tcn_joint", g4);
-    LAUNCH(c, s, "mocha_final_proj", "mot.final_proj", b * 60.0 * V * 64 * 15 * 2, b * 60.0 * V * (64 + 15) * 4, launch_final_proj(WS(c, "z"), DW(c, "mot.W6"), DW(c, "mot.b6"), Y, b * 60 * V, c->cfg.C_in, s));
+    LAUNCH(c, s, "mocha_final_proj", "mot.final_proj", b * 60.0 * V * 64 * 15 * 2, b * 60.0 * V * (64 + 15) * 4, launch_final_proj(WS(c, "z"), DW(c, "mot.W6"), DW(c, "mot.b6"), Y, b * 60 * V, c->cfg.C_in, V,
+                             denorm ? c->pose_norm + 2 * nn : nullptr, denorm ? c->pose_norm + 3 * nn : nullptr, s));
     return 0;
 }
 
@@ -849,23 +856,64 @@ int mocha_bank_gather(mocha_ctx* c, const int32_t* idx, int Q, float* out, void*
     return 0;
 }
 
-int mocha_characterize(mocha_ctx* c, const float* src_X, int B, const float* cnt_mean, const float* cnt_std, float* Y,
-                       int32_t* idx, void* stream) {
+static int characterize_impl(mocha_ctx* c, const float* src_X, int B, const float* cnt_mean, const float* cnt_std, float* Y,
+                             int32_t* idx, void* stream, bool raw) {
     int rc = ready(c, B); if (rc) return rc;
     if (!c->bank_cnt) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
     if (!cnt_mean || !cnt_std || !src_X || !Y) return fail(c, MOCHA_ERR_ARG, "null argument");
     hipStream_t s = (hipStream_t)stream;
-    const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in;
+    const size_t ys = (size_t)60 * c->cfg.V * c->cfg.C_in;
+    const size_t xs = raw ? (size_t)60 * (c->cfg.V + 1) * c->cfg.C_in : ys;
     for (int b0 = 0; b0 < B; b0 += c->chunk) {
         const int b = std::min(c->chunk, B - b0);
         int32_t* ix = idx ? idx + b0 : c->idx_ws;
-        if ((rc = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s))) return rc;
+        if ((rc = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s, raw))) return rc;
         if ((rc = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return rc;
         LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * 3, launch_instnorm(WS(c, "enc_s"), WS(c, "cnt"), nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s));
         if ((rc = do_match(c, WS(c, "qnm"), b, ix, nullptr, s))) return rc;
         LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, b * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), b, 90 * 256, s));
         if ((rc = run_decoder(c, WS(c, "enc_s"), WS(c, "sel"), b, WS(c, "dec"), s))) return rc;
-        if ((rc = run_to_mot(c, WS(c, "dec"), b, Y + b0 * xs, s))) return rc;
+        if ((rc = run_to_mot(c, WS(c, "dec"), b, Y + b0 * ys, s, raw))) return rc;
+    }
+    return 0;
+}
+
+int mocha_characterize(mocha_ctx* c, const float* src_X, int B, const float* cnt_mean, const float* cnt_std, float* Y,
+                       int32_t* idx, void* stream) {
+    return characterize_impl(c, src_X, B, cnt_mean, cnt_std, Y, idx, stream, false);
+}
+
+int mocha_characterize_raw(mocha_ctx* c, const float* src_X_raw, int B, const float* cnt_mean, const float* cnt_std, float* Y,
+                           int32_t* idx, void* stream) {
+    return characterize_impl(c, src_X_raw, B, cnt_mean, cnt_std, Y, idx, stream, true);
+}
+
+int mocha_set_pose_norm(mocha_ctx* c, const float* x_mean, const float* x_std, const float* y_mean, const float* y_std) {
+    if (!c || !x_mean || !x_std || !y_mean || !y_std) return fail(c, MOCHA_ERR_ARG, "null argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nn = (size_t)(c->cfg.V + 1) * c->cfg.C_in;
+    for (size_t i = 0; i < nn; ++i)
+        if (!(x_std[i] != 0.f)) return fail(c, MOCHA_ERR_ARG, "x_std[%zu] is zero", i);
+    if (!c->pose_norm) { int rc = dev_alloc(c, &c->pose_norm, 4 * nn); if (rc) return rc; }
+    const float* src[4] = {x_mean, x_std, y_mean, y_std};
+    for (int k = 0; k < 4; ++k) HIPCHK(c, hipMemcpy(c->pose_norm + k * nn, src[k], nn * sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+
+int mocha_encode_raw(mocha_ctx* c, const float* X_raw, int B, float* encoded, float* cnt, const float* cnt_mean,
+                     const float* cnt_std, float* cnt_nm, void* stream) {
+    int rc = ready(c, B); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t xs = (size_t)60 * (c->cfg.V + 1) * c->cfg.C_in, ts = 90 * 256;
+    const bool zn = cnt && cnt_nm && cnt_mean && cnt_std;
+    for (int b0 = 0; b0 < B; b0 += c->chunk) {
+        const int b = std::min(c->chunk, B - b0);
+        if ((rc = run_embed(c, X_raw + b0 * xs, b, WS(c, "x5"), true, s, true))) return rc;
+        if ((rc = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s))) return rc;
+        if (cnt)
+            LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (zn ? 3 : 2),
+                   launch_instnorm(encoded + b0 * ts, cnt + b0 * ts, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
+                                   zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
     }
     return 0;
 }

@@ -26,7 +26,8 @@ static constexpr int EF_FPB = 4;
 
 __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict__ X, const float* __restrict__ W1,
                                                          const float* __restrict__ b1, const float* __restrict__ AP,
-                                                         float* __restrict__ out, int nframes, int V, int Cin) {
+                                                         float* __restrict__ out, int nframes, int V, int Cin,
+                                                         const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
     __shared__ float xs[32 * 16];
     __shared__ float hs[32 * 64];
     __shared__ float aps[3 * 32 * 6];
@@ -42,10 +43,14 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
         const int frame = blockIdx.x * EF_FPB + f;
         if (frame >= nframes) break;
         __syncthreads();
-        const float* xf = X + (size_t)frame * V * Cin;
+        // raw_root = 1: frames carry the root bone in front (V+1 joints) and are z-scored here,
+        // X = (X[:,:,1:] - X_mean[:,:,1:]) / X_std[:,:,1:]   (test_fullframework.py:186)
+        const float* xf = X + (size_t)frame * (V + raw_root) * Cin + raw_root * Cin;
         for (int i = tid; i < V * Cin; i += 256) {
             const int v = i / Cin, ci = i - v * Cin;
-            xs[v * 16 + ci] = xf[i];
+            float x = xf[i];
+            if (xmean) x = (x - xmean[raw_root * Cin + i]) / xstd[raw_root * Cin + i];
+            xs[v * 16 + ci] = x;
         }
         __syncthreads();
         for (int v = g; v < V; v += 4) {
@@ -67,11 +72,11 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
 }
 
 hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP, float* out,
-                              int nframes, int V, int Cin, hipStream_t s) {
+                              int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root, hipStream_t s) {
     if (nframes <= 0) return hipSuccess;
     if (V > 32 || Cin > 16) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mocha_embed_front, dim3((nframes + EF_FPB - 1) / EF_FPB), dim3(256), 0, s, X, W1, b1, AP, out,
-                       nframes, V, Cin);
+                       nframes, V, Cin, xmean, xstd, raw_root);
     return hipGetLastError();
 }
 
@@ -152,7 +157,8 @@ hipError_t launch_joint_expand(const float* g, const float* AU, float* out, int 
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mocha_final_proj(const float* __restrict__ z, const float* __restrict__ W6,
                                                         const float* __restrict__ b6, float* __restrict__ Y, int rows,
-                                                        int Cout) {
+                                                        int Cout, int V, const float* __restrict__ ymean,
+                                                        const float* __restrict__ ystd) {
     __shared__ float zs[64 * 65];
     __shared__ float ws[16 * 64];
     __shared__ float ys[64 * 16];
@@ -170,18 +176,23 @@ __global__ __launch_bounds__(256) void mocha_final_proj(const float* __restrict_
         float a = 0.f;
 #pragma unroll 16
         for (int c = 0; c < 64; ++c) a = fmaf(zs[r * 65 + c], ws[o * 64 + c], a);
-        ys[r * Cout + o] = a + b6[o];
+        float y = a + b6[o];
+        if (ymean) {       // de-normalise, Y * Y_std[0,:,1:] + Y_mean[0,:,1:] (test_fullframework.py:303,457); norms carry the root row
+            const int v = (r0 + r) % V;
+            y = y * ystd[(v + 1) * Cout + o] + ymean[(v + 1) * Cout + o];
+        }
+        ys[r * Cout + o] = y;
     }
     __syncthreads();
     const int nrow = (rows - r0) < 64 ? (rows - r0) : 64;
     for (int i = tid; i < nrow * Cout; i += 256) Y[(size_t)r0 * Cout + i] = ys[i];
 }
 
-hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, float* Y, int rows, int Cout,
-                             hipStream_t s) {
+hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, float* Y, int rows, int Cout, int V,
+                             const float* ymean, const float* ystd, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (Cout > 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_final_proj, dim3((rows + 63) / 64), dim3(256), 0, s, z, W6, b6, Y, rows, Cout);
+    hipLaunchKernelGGL(mocha_final_proj, dim3((rows + 63) / 64), dim3(256), 0, s, z, W6, b6, Y, rows, Cout, V, ymean, ystd);
     return hipGetLastError();
 }
 

@@ -256,22 +256,41 @@ class Generator:
     __call__ = forward
 
     # ---- fused extras (same arithmetic, fewer launches) --------------------------------
-    def encode(self, X, cnt_mean=None, cnt_std=None):
+    def set_pose_norm(self, X_mean, X_std, Y_mean, Y_std):
+        """The demo's norm.npz arrays (test_fullframework.py:64-71), any shape ending in (V+1, C) with the
+        root bone first.  Enables ``raw=True``: un-normalised poses with the root bone go in
+        ((B,T,V+1,C)), the z-score of :186 and the de-normalisation of :303 run inside the kernels."""
+        n = (self.V + 1) * self.cfg["mot_in_dim"]
+        arrs = []
+        for a in (X_mean, X_std, Y_mean, Y_std):
+            a = np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1))
+            if a.size != n:
+                raise ValueError(f"pose norm arrays must hold (V+1)*C = {n} values, got {a.size}")
+            arrs.append(a)
+        self._ctx.call("mocha_set_pose_norm", *[a.ctypes.data_as(C.c_void_p) for a in arrs])
+        self._has_pose_norm = True
+        return self
+
+    def _xraw(self, X, name):
+        return _dev_f32(X, self.device, (self.cfg["nframes"], self.V + 1, self.cfg["mot_in_dim"]), name)
+
+    def encode(self, X, cnt_mean=None, cnt_std=None, raw: bool = False):
         """The demo's encode sequence (test_fullframework.py:190-193) in one call.
         Returns (encoded, cnt) or (encoded, cnt, cnt_nm) when the global cnt norm is given
         (cnt_nm = (cnt - cnt_mean) / cnt_std, test_fullframework.py:293,442)."""
         self._need()
-        X = self._x(X, "X")
+        X = self._xraw(X, "X_raw") if raw else self._x(X, "X")
+        fn = "mocha_encode_raw" if raw else "mocha_encode"
         B = X.shape[0]
         enc = torch.empty((B, NTOK, DIM), dtype=torch.float32, device=self.device)
         cnt = torch.empty_like(enc)
         if cnt_mean is None:
-            self._ctx.call("mocha_encode", _ptr(X), B, _ptr(enc), _ptr(cnt), _ptr(None), _ptr(None), _ptr(None), _stream())
+            self._ctx.call(fn, _ptr(X), B, _ptr(enc), _ptr(cnt), _ptr(None), _ptr(None), _ptr(None), _stream())
             return enc, cnt
         m = _dev_f32(cnt_mean, self.device, (NTOK, DIM), "cnt_mean")
         sd = _dev_f32(cnt_std, self.device, (NTOK, DIM), "cnt_std")
         nm = torch.empty_like(enc)
-        self._ctx.call("mocha_encode", _ptr(X), B, _ptr(enc), _ptr(cnt), _ptr(m), _ptr(sd), _ptr(nm), _stream())
+        self._ctx.call(fn, _ptr(X), B, _ptr(enc), _ptr(cnt), _ptr(m), _ptr(sd), _ptr(nm), _stream())
         return enc, cnt, nm
 
 
@@ -322,18 +341,21 @@ class ContextBank:
         self.model._ctx.call("mocha_bank_gather", _ptr(idx), idx.shape[0], _ptr(out), _stream())
         return out
 
-    def characterize(self, src_X, cnt_mean, cnt_std, return_index: bool = False):
+    def characterize(self, src_X, cnt_mean, cnt_std, return_index: bool = False, raw: bool = False):
         """NN ('cm_') branch of the demo for all source windows at once: encode, z-score,
-        1-NN match, gather, decode, to_mot (test_fullframework.py:188-194,438-443,465-467)."""
+        1-NN match, gather, decode, to_mot (test_fullframework.py:188-194,438-443,465-467).
+        raw=True (after Generator.set_pose_norm): src_X is un-normalised with the root bone,
+        (B,T,V+1,C); the result is de-normalised (B,T,V,C)."""
         if getattr(self.model, "_bank", None) is not self:
             self.activate()
         m = self.model
-        X = m._x(src_X, "src_X")
+        X = m._xraw(src_X, "src_X_raw") if raw else m._x(src_X, "src_X")
         mean = _dev_f32(cnt_mean, m.device, (NTOK, DIM), "cnt_mean")
         std = _dev_f32(cnt_std, m.device, (NTOK, DIM), "cnt_std")
-        Y = torch.empty_like(X)
+        Y = torch.empty((X.shape[0], m.cfg["nframes"], m.V, m.cfg["mot_in_dim"]), dtype=torch.float32, device=m.device)
         idx = torch.empty((X.shape[0],), dtype=torch.int32, device=m.device)
-        m._ctx.call("mocha_characterize", _ptr(X), X.shape[0], _ptr(mean), _ptr(std), _ptr(Y), _ptr(idx), _stream())
+        m._ctx.call("mocha_characterize_raw" if raw else "mocha_characterize", _ptr(X), X.shape[0], _ptr(mean), _ptr(std),
+                    _ptr(Y), _ptr(idx), _stream())
         return (Y, idx) if return_index else Y
 
 

@@ -230,3 +230,30 @@ def test_streaming_graph_replay_matches_batched():
             y, idx = sc.step(src[i])
             assert int(idx.item()) == int(io[i])
             assert absmax(y, Yo[i].numpy()) < TOL * max(1.0, float(Yo.abs().max()))
+
+
+def test_fused_pose_normalisation():
+    """SURVEY §8 rows a1 + a13: raw poses with the root bone in, de-normalised poses out, against the
+    reference's NumPy pre/post-processing (test_fullframework.py:186, 303) around the oracle."""
+    sd = weights.synthetic_state_dict(21, 1.3)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    rng = np.random.Generator(np.random.PCG64(5))
+    Xm = rng.standard_normal((25, 15)).astype(np.float32); Xs = rng.uniform(0.5, 2.0, (25, 15)).astype(np.float32)
+    Ym = rng.standard_normal((25, 15)).astype(np.float32); Ys = rng.uniform(0.5, 2.0, (25, 15)).astype(np.float32)
+    model.set_pose_norm(Xm[None, None], Xs[None, None], Ym[None, None], Ys[None, None])   # norm.npz shapes (1,1,25,15)
+    src_raw = (rng.standard_normal((4, 60, 25, 15)) * 2 + 1).astype(np.float32)
+    cha_raw = (rng.standard_normal((9, 60, 25, 15)) * 2 + 1).astype(np.float32)
+    mean, std = synthetic.cnt_norm(6)
+    enc_c, cnt_c, nm_c = model.encode(T(cha_raw), mean, std, raw=True)
+    bank = ContextBank(model, nm_c, enc_c)
+    Y, idx = bank.characterize(T(src_raw), mean, std, return_index=True, raw=True)
+    # reference-style host processing around the oracle
+    src = (src_raw[:, :, 1:] - Xm[None, None, 1:]) / Xs[None, None, 1:]
+    cha = (cha_raw[:, :, 1:] - Xm[None, None, 1:]) / Xs[None, None, 1:]
+    with torch.no_grad():
+        Yo, io = O.characterize(O.to_torch_state(sd), torch.from_numpy(src), torch.from_numpy(cha), mean, std)
+    Yo = Yo.numpy() * Ys[None, None, 1:] + Ym[None, None, 1:]
+    assert np.array_equal(idx.cpu().numpy(), io)
+    assert absmax(Y, Yo) < TOL * max(1.0, np.abs(Yo).max())
+    with pytest.raises(RuntimeError, match="set_pose_norm"):
+        Generator(device=dev()).load_state_dict(sd).encode(T(cha_raw), raw=True)
