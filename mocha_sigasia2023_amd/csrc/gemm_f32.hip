@@ -52,11 +52,18 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
     const int n_tiles = (p.N + BN - 1) / BN;
     const int m_tiles = (p.M + BM - 1) / BM;
     const int bid = blockIdx.x;
-    const int grp = bid / (8 * n_tiles);
-    const int rem = bid - grp * 8 * n_tiles;
-    const int mt = grp * 8 + (rem & 7);
+    int mt, nt;
+    if (m_tiles >= 8) {                 // XCD-aware order: the n-tiles of one m-tile share an XCD (bid % 8)
+        const int grp = bid / (8 * n_tiles);
+        const int rem = bid - grp * 8 * n_tiles;
+        mt = grp * 8 + (rem & 7);
+        nt = rem >> 3;
+    } else {                            // few row tiles (single windows, small query sets): spread over all XCDs
+        mt = bid / n_tiles;
+        nt = bid - mt * n_tiles;
+    }
     if (mt >= m_tiles) return;
-    const int m0 = mt * BM, n0 = (rem >> 3) * BN;
+    const int m0 = mt * BM, n0 = nt * BN;
 
     const int slabs_total = p.K / BK;               // K % 32 == 0 is checked on the host
     const int per = (slabs_total + p.ksplit - 1) / p.ksplit;
@@ -249,7 +256,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.K % BK != 0) return hipErrorInvalidValue;
     if (p.gather && (p.Cc % BK != 0)) return hipErrorInvalidValue;
     const int m_tiles = (p.M + BM - 1) / BM;
-    const int m_pad = (m_tiles + 7) / 8 * 8;
+    const int m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
     if (gemm_is_narrow(p)) {
         dim3 grid(m_pad * ((p.N + 63) / 64), 1, p.ksplit);
         hipLaunchKernelGGL((mocha_gemm_f32<64, 4, 1, 1, 2>), grid, dim3(256), lds_bytes<64>(), s, p);

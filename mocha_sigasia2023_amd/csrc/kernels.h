@@ -20,6 +20,7 @@ namespace mocha {
 struct GemmParams {
     const float* A = nullptr;     // source activations
     const float* W = nullptr;     // [N][K], k contiguous (nn.Linear / repacked conv layout)
+    const unsigned short* Wsplit = nullptr;   // [planes][N][K] bf16 planes of W (gemm_split.hip), or a bf16 bank
     float* C = nullptr;
     const float* bias = nullptr;      // [N] or null
     const float* rowbias = nullptr;   // [rb_mod][N] or null, indexed by (row % rb_mod)
@@ -36,7 +37,11 @@ struct GemmParams {
     long long slab_stride = 0;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
-bool gemm_is_narrow(const GemmParams& p);   // true: 128x64 tiles (mocha_gemm_f32<64,...>), false: 128x128
+bool gemm_is_narrow(const GemmParams& p);
+// split-precision engine (gemm_split.hip): planes = 33 (fp32-accurate, 6 bf16 MFMAs) or 31 (3 query planes x bf16 bank)
+hipError_t gemm_split_init();
+hipError_t launch_gemm_split(const GemmParams& p, int planes, hipStream_t s);
+void split_weights_host(const float* w, size_t count, unsigned short* out /*3*count*/);   // true: 128x64 tiles (mocha_gemm_f32<64,...>), false: 128x128
 hipError_t gemm_init();           // one-time function attributes (dynamic LDS size)
 
 // ---------------------------------------------------------------------------------------
@@ -81,7 +86,7 @@ hipError_t launch_window_sums(const float* ybar, float* u, int rows /*B*90*/, hi
 hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, hipStream_t s);
 // per query: argmin_n (bnorm[n] - 2*sum_z S[z][q][n]); then exact distance to the winner
 hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm,
-                         const float* query, const float* bank, int Q, int64_t N, int D,
+                         const float* query, const float* bank, const void* bank16 /*bf16 bank or null*/, int Q, int64_t N, int D,
                          int32_t* idx, float* dist, hipStream_t s);
 // streaming matcher for few queries against a large bank (HBM-bound): bank fp32 or bf16;
 // partial = match_stream_scratch(Q, N) u64 words of scratch

@@ -480,7 +480,7 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     const int64_t N = c->bank_N;
     // Few queries (streaming, one per frame) or a bf16 bank: HBM-bound bank scan, bank read once per
     // 8 queries.  Many queries against an fp32 bank: MFMA GEMM Q.Bank^T + arg-min.
-    if (Q <= 8 || c->bank_is_bf16) {
+    if (Q <= 8) {
         const size_t need_ws = match_stream_scratch(Q, N);
         if (c->best_ws_n < need_ws) {
             if (c->best_ws) (void)hipFree(c->best_ws);
@@ -507,8 +507,17 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     }
     GemmParams g = plain(qnm, D, c->bank_cnt, c->match_S.p, (int)N, Q, (int)N, D);
     g.ksplit = ksplit; g.slab_stride = (long long)Q * N;
-    GEMM(c, s, "match.qk", g);
-    LAUNCH(c, s, "mocha_argmin", "match.argmin", 0.0, (double)ksplit * Q * N * 4, launch_argmin(c->match_S.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_cnt, Q, N, D, idx, dist, s));
+    if (c->bank_is_bf16) {
+        // bf16 bank: exact fp32 queries (three bf16 planes) against the rounded bank on the bf16 matrix pipe
+        g.Wsplit = (const unsigned short*)c->bank_bf16;
+        LAUNCH(c, s, "mocha_gemm_split<128,2,2,2,2,3,1,2>", "match.qk_bf16", 2.0 * Q * (double)N * D,
+               4.0 * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit, launch_gemm_split(g, 31, s));
+    } else {
+        GEMM(c, s, "match.qk", g);
+    }
+    LAUNCH(c, s, "mocha_argmin", "match.argmin", 0.0, (double)ksplit * Q * N * 4,
+           launch_argmin(c->match_S.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_cnt, c->bank_is_bf16 ? c->bank_bf16 : nullptr,
+                         Q, N, D, idx, dist, s));
     return 0;
 }
 
@@ -542,6 +551,7 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     build_expectations(c);
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = gemm_init();
+    if (e == hipSuccess) e = gemm_split_init();
     if (e != hipSuccess) { delete c; return fail(nullptr, MOCHA_ERR_HIP, "device %d init failed: %s", device, hipGetErrorString(e)); }
     *out = c;
     return 0;

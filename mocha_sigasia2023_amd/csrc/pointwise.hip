@@ -363,6 +363,7 @@ hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, h
 __global__ __launch_bounds__(256) void mocha_argmin(const float* __restrict__ S, int ksplit, long long slab_stride,
                                                     int lds, const float* __restrict__ bnorm,
                                                     const float* __restrict__ query, const float* __restrict__ bank,
+                                                    const unsigned short* __restrict__ bank16,
                                                     long long N, int D, int32_t* __restrict__ idx,
                                                     float* __restrict__ dist) {
     __shared__ float rv[4];
@@ -397,9 +398,17 @@ __global__ __launch_bounds__(256) void mocha_argmin(const float* __restrict__ S,
     const f32x4* qr = reinterpret_cast<const f32x4*>(query + (size_t)q * D);
     const f32x4* br = reinterpret_cast<const f32x4*>(bank + (size_t)win * D);
     float a = 0.f;
-    for (int i = tid; i < D / 4; i += 256) {
-        const f32x4 d = qr[i] - br[i];
-        a = fmaf(d[0], d[0], a); a = fmaf(d[1], d[1], a); a = fmaf(d[2], d[2], a); a = fmaf(d[3], d[3], a);
+    if (bank16) {                                   // distance to the bf16-rounded entry that was matched
+        const unsigned short* b16 = bank16 + (size_t)win * D;
+        for (int i = tid; i < D; i += 256) {
+            const float d = query[(size_t)q * D + i] - __uint_as_float((unsigned)b16[i] << 16);
+            a = fmaf(d, d, a);
+        }
+    } else {
+        for (int i = tid; i < D / 4; i += 256) {
+            const f32x4 d = qr[i] - br[i];
+            a = fmaf(d[0], d[0], a); a = fmaf(d[1], d[1], a); a = fmaf(d[2], d[2], a); a = fmaf(d[3], d[3], a);
+        }
     }
     a = wave_sum(a);
     __syncthreads();
@@ -409,11 +418,11 @@ __global__ __launch_bounds__(256) void mocha_argmin(const float* __restrict__ S,
 }
 
 hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm,
-                         const float* query, const float* bank, int Q, int64_t N, int D, int32_t* idx, float* dist,
-                         hipStream_t s) {
+                         const float* query, const float* bank, const void* bank16, int Q, int64_t N, int D, int32_t* idx,
+                         float* dist, hipStream_t s) {
     if (Q <= 0) return hipSuccess;
     hipLaunchKernelGGL(mocha_argmin, dim3(Q), dim3(256), 0, s, S, ksplit, slab_stride, lds, bnorm, query, bank,
-                       (long long)N, D, idx, dist);
+                       (const unsigned short*)bank16, (long long)N, D, idx, dist);
     return hipGetLastError();
 }
 

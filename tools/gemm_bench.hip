@@ -26,7 +26,8 @@ int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 585;
     int iters = argc > 2 ? atoi(argv[2]) : 20;
     int check = argc > 3 ? atoi(argv[3]) : 1;
-    CK(gemm_init());
+    int mode = argc > 4 ? atoi(argv[4]) : 0;      // 0 = exact f32 MFMA, 33 = split bf16 x6
+    CK(gemm_init()); CK(gemm_split_init());
     std::vector<Shape> shapes = {
         {"enc.qkv      ", B * 90, 1536, 256, 0},
         {"xf.out512    ", B * 90, 256, 512, 0},
@@ -52,14 +53,18 @@ int main(int argc, char** argv) {
         float *dA, *dW, *dC, *dR;
         CK(hipMalloc(&dA, na * 4)); CK(hipMalloc(&dW, nw * 4)); CK(hipMalloc(&dC, nc * 4 * (sh.M == 585 && sh.N == 585 ? 16 : 1)));
         CK(hipMemcpy(dA, ha.data(), na * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hw.data(), nw * 4, hipMemcpyHostToDevice));
-        GemmParams p; p.A = dA; p.W = dW; p.C = dC; p.M = sh.M; p.N = sh.N; p.K = sh.K; p.lda = lda; p.ldc = sh.N;
+        unsigned short* dWs = nullptr;
+        if (mode) { std::vector<unsigned short> hs(3 * nw); split_weights_host(hw.data(), nw, hs.data()); CK(hipMalloc(&dWs, 3 * nw * 2)); CK(hipMemcpy(dWs, hs.data(), 3 * nw * 2, hipMemcpyHostToDevice)); }
+        GemmParams p; p.Wsplit = dWs; p.A = dA; p.W = dW; p.C = dC; p.M = sh.M; p.N = sh.N; p.K = sh.K; p.lda = lda; p.ldc = sh.N;
         if (sh.gather) { p.gather = 1; p.T_out = sh.T_out; p.V = sh.V; p.ntaps = sh.ntaps; p.pad = sh.pad; p.stride = sh.stride; p.R = sh.R;
                          p.T_full = sh.T_full; p.tshift = sh.tshift; p.Cc = sh.Cc; p.T_src = sh.T_src; p.ascale = sh.R > 1 ? 0.25f : 1.f; }
         if (sh.M == 585 && sh.N == 585) { p.ksplit = 16; p.slab_stride = (long long)sh.M * sh.N; }
-        for (int i = 0; i < 3; ++i) CK(launch_gemm(p, 0));
+        auto run = [&]() { return mode ? launch_gemm_split(p, mode, 0) : launch_gemm(p, 0); };
+        if (mode && sh.gather && sh.R != 1) { printf("%s skipped (R != 1)\n", sh.name); CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(dWs)); continue; }
+        for (int i = 0; i < 3; ++i) CK(run());
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < iters; ++i) CK(launch_gemm(p, 0));
+        for (int i = 0; i < iters; ++i) CK(run());
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
         double tf = 2.0 * sh.M * sh.N * sh.K / (ms * 1e-3) / 1e12;
@@ -73,7 +78,7 @@ int main(int argc, char** argv) {
             CK(hipFree(dR));
         }
         printf("%s M=%7d N=%5d K=%5d  %9.1f us  %7.2f TFLOP/s  (%.1f%% of 157.3)  maxerr=%g\n", sh.name, sh.M, sh.N, sh.K, ms * 1e3, tf, tf / 157.3 * 100, err);
-        CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC));
+        CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); if (dWs) CK(hipFree(dWs));
     }
     return 0;
 }
