@@ -45,21 +45,36 @@ __global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
 
-    for (int c = 0; c < DH / 32; ++c) {
-        // 96 rows x 8 float4 per matrix = 768 float4; 192 threads x 4
+    // chunk c+1 of K and Q is fetched into registers while chunk c is multiplied (the global-load
+    // latency of a chunk is about the length of its 48 MFMAs, so an un-prefetched loop idles half the time)
+    f32x4 kr[4], qr[4];
+    auto fetch_kq = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {           // 96 rows x 8 float4 per matrix = 768 float4; 192 threads x 4
+            const int f = tid + 192 * i;
+            const int row = f >> 3, c4 = (f & 7) * 4;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            kr[i] = z; qr[i] = z;
+            if (row < n) {
+                kr[i] = *reinterpret_cast<const f32x4*>(kg + (size_t)row * p.ldk + c * 32 + c4);
+                qr[i] = *reinterpret_cast<const f32x4*>(qg + (size_t)row * p.ldq + c * 32 + c4);
+            }
+        }
+    };
+    auto stage_kq = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 192 * i;
             const int row = f >> 3, c4 = (f & 7) * 4;
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f}, qv = {0.f, 0.f, 0.f, 0.f};
-            if (row < n) {
-                kv = *reinterpret_cast<const f32x4*>(kg + (size_t)row * p.ldk + c * 32 + c4);
-                qv = *reinterpret_cast<const f32x4*>(qg + (size_t)row * p.ldq + c * 32 + c4);
-            }
-            *reinterpret_cast<f32x4*>(Ks + row * LK + c4) = kv;
-            *reinterpret_cast<f32x4*>(Qs + row * LK + c4) = qv;
+            *reinterpret_cast<f32x4*>(Ks + row * LK + c4) = kr[i];
+            *reinterpret_cast<f32x4*>(Qs + row * LK + c4) = qr[i];
         }
-        __syncthreads();
+    };
+    fetch_kq(0);
+    stage_kq();
+    __syncthreads();
+    for (int c = 0; c < DH / 32; ++c) {
+        if (c + 1 < DH / 32) fetch_kq(c + 1);
 #pragma unroll
         for (int kgp = 0; kgp < 4; ++kgp) {
             f32x4 a[3];
@@ -72,6 +87,8 @@ __global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
                 for (int t = 0; t < 3; ++t)
                     st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][ks], bq[ks], st[t], 0, 0, 0);
         }
+        __syncthreads();
+        if (c + 1 < DH / 32) stage_kq();
         __syncthreads();
     }
 
@@ -106,17 +123,30 @@ __global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
     // ---------------- phase 3: O^T[d][query] = sum_key V[key][d] * P^T[key][query]
     const int query = wave * 32 + l31;
     float* og = p.out + ((size_t)b * n + query) * p.ldo + head * DH;
-    for (int dp = 0; dp < DH / DV; ++dp) {
-        // stage V[:, dp*64 .. +64] as Vs[96][64]: 96 x 16 float4 = 1536; 192 threads x 8
+    // V is staged 64 head-dims at a time; pass dp+1 is fetched into registers during pass dp
+    f32x4 vr[8];
+    auto fetch_v = [&](int dp) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {           // 96 x 16 float4 = 1536; 192 threads x 8
+            const int f = tid + 192 * i;
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            vr[i] = row < n ? *reinterpret_cast<const f32x4*>(vg + (size_t)row * p.ldv + dp * DV + c4) : z;
+        }
+    };
+    auto stage_v = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int f = tid + 192 * i;
             const int row = f >> 4, c4 = (f & 15) * 4;
-            f32x4 vv = {0.f, 0.f, 0.f, 0.f};
-            if (row < n) vv = *reinterpret_cast<const f32x4*>(vg + (size_t)row * p.ldv + dp * DV + c4);
-            *reinterpret_cast<f32x4*>(Vs + row * DV + c4) = vv;
+            *reinterpret_cast<f32x4*>(Vs + row * DV + c4) = vr[i];
         }
-        __syncthreads();
+    };
+    fetch_v(0);                                  // (issued before the softmax above would be even better; the
+    stage_v();                                   //  K/Q stage is free: every wave passed the last barrier of phase 1)
+    __syncthreads();
+    for (int dp = 0; dp < DH / DV; ++dp) {
+        if (dp + 1 < DH / DV) fetch_v(dp + 1);
         f32x16 o[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -143,6 +173,8 @@ __global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
                     *reinterpret_cast<f32x4*>(og + dp * DV + d * 32 + 8 * g + 4 * hh) = w;
                 }
         }
+        __syncthreads();
+        if (dp + 1 < DH / DV) stage_v();
         __syncthreads();
     }
 }
