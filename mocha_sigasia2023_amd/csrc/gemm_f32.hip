@@ -229,6 +229,114 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Skinny variant for a handful of windows (streaming one window per step: M = 90 ... 1440).
+// The tiled kernel above would launch 2-24 workgroups with a serial K loop of up to 40 slabs; here
+// a workgroup owns one 32x32 output tile, its 4 waves split K four ways, every operand goes
+// global -> register in MFMA layout (no LDS staging, all loads of a wave in flight at once), and the
+// four partial tiles are summed in a fixed order through LDS (deterministic) before the same
+// fused epilogue.  Latency of a GEMM drops from ~K/32 slab times to ~K/128 MFMA groups + one load.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_gemm_skinny(GemmParams p) {
+    __shared__ float red[3][16][64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int n_tiles = (p.N + 31) / 32;
+    const int mt = blockIdx.x / n_tiles, nt = blockIdx.x - mt * n_tiles;
+    const int m0 = mt * 32, n0 = nt * 32;
+
+    int m = m0 + l31;
+    m = m < p.M ? m : p.M - 1;
+    int a_rb = m, a_t = 0;
+    if (p.gather) {
+        const int v = m % p.V;
+        const int bt = m / p.V;
+        a_t = bt % p.T_out;
+        a_rb = (bt / p.T_out) * p.T_src * p.V + v;
+    }
+    int n = n0 + l31;
+    n = n < p.N ? n : p.N - 1;
+    const float* wrow = p.W + (size_t)n * p.K;
+
+    const int groups = p.K / 8;                     // k groups of 8 (4 per lane half)
+    const int gper = (groups + 3) / 4;
+    const int g_begin = wave * gper;
+    const int g_end = (g_begin + gper) < groups ? (g_begin + gper) : groups;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int g0 = g_begin; g0 < g_end; g0 += 8) {
+        f32x4 a4[8], b4[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int k = (g0 + g) * 8 + 4 * hh;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            a4[g] = z; b4[g] = z;
+            if (g0 + g < g_end) {
+                if (!p.gather) {
+                    a4[g] = *reinterpret_cast<const f32x4*>(p.A + (size_t)a_rb * p.lda + k);
+                } else {
+                    const int tap = k / p.Cc;
+                    const int cc = k - tap * p.Cc;
+                    int tf = a_t * p.stride + tap - p.pad;
+                    tf = tf < 0 ? -tf : tf;
+                    tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
+                    a4[g] = *reinterpret_cast<const f32x4*>(p.A + (size_t)(a_rb + (tf >> p.tshift) * p.V) * p.lda + cc);
+                }
+                b4[g] = *reinterpret_cast<const f32x4*>(wrow + k);
+            }
+        }
+        if (p.a_lrelu) {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                a4[g][0] = lrelu02(a4[g][0]); a4[g][1] = lrelu02(a4[g][1]);
+                a4[g][2] = lrelu02(a4[g][2]); a4[g][3] = lrelu02(a4[g][3]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b4[g][ks], a4[g][ks], acc, 0, 0, 0);      // C^T tile; zero groups add 0
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
+
+    const int row = m0 + l31;
+    if (row >= p.M) return;
+    const float* rbrow = p.rowbias ? p.rowbias + (size_t)(row % p.rb_mod) * p.N : nullptr;
+    const float* rsrow = p.residual ? p.residual + (size_t)row * p.ldr : nullptr;
+    float* crow = p.C + (size_t)row * p.ldc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int col = n0 + 8 * g + 4 * hh;
+        if (col >= p.N) continue;                   // N % 4 == 0 is checked on the host for this kernel
+        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
+        if (rbrow) v += *reinterpret_cast<const f32x4*>(rbrow + col);
+        if (p.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+        else if (p.act == 2) { v[0] = lrelu02(v[0]); v[1] = lrelu02(v[1]); v[2] = lrelu02(v[2]); v[3] = lrelu02(v[3]); }
+        if (rsrow) v += *reinterpret_cast<const f32x4*>(rsrow + col);
+        *reinterpret_cast<f32x4*>(crow + col) = v;
+    }
+}
+
+// true when the tiled kernel would leave most of the chip idle and the shape fits the skinny kernel
+bool gemm_is_skinny(const GemmParams& p) {
+    if (p.ksplit > 1 || (p.N & 3) || (p.ldc & 3) || (p.residual && (p.ldr & 3)) || (p.gather && p.R != 1)) return false;
+    const long long wide_tiles = (long long)((p.M + BM - 1) / BM) * ((p.N + 63) / 64);
+    return wide_tiles < 96;
+}
+
 template <int BN>
 static constexpr size_t lds_bytes() { return (size_t)(BM + BN) * LDSK * sizeof(float); }
 
@@ -255,6 +363,11 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (p.K % BK != 0) return hipErrorInvalidValue;
     if (p.gather && (p.Cc % BK != 0)) return hipErrorInvalidValue;
+    if (gemm_is_skinny(p)) {
+        dim3 grid(((p.M + 31) / 32) * ((p.N + 31) / 32));
+        hipLaunchKernelGGL(mocha_gemm_skinny, grid, dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     const int m_tiles = (p.M + BM - 1) / BM;
     const int m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
     if (gemm_is_narrow(p)) {

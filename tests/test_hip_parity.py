@@ -141,8 +141,9 @@ def test_characterize_vs_oracle(B, chunk):
 
 
 def test_batch_independence_and_determinism():
-    """Windows are independent units: a window's output must not depend on its
-    batch neighbours or on the chunking, and two runs must agree bit for bit."""
+    """Windows are independent units.  Two runs of the same call agree bit for bit; a
+    window's output does not depend on its batch neighbours or the chunking beyond fp32 summation
+    order (small batches take the skinny GEMM, which splits K four ways), i.e. far inside 1e-4."""
     sd = weights.synthetic_state_dict(77, 1.0)
     model = Generator(device=dev()).load_state_dict(sd).eval().reserve(8)
     s, c = T(synthetic.pose_windows(1, 9)), T(synthetic.pose_windows(2, 9))
@@ -150,7 +151,11 @@ def test_batch_independence_and_determinism():
     Y2 = model(s, c)
     assert torch.equal(Y1, Y2)
     Ys = model(s[4:5].contiguous(), c[4:5].contiguous())
-    assert torch.equal(Ys[0], Y1[4])
+    assert torch.equal(Ys, model(s[4:5].contiguous(), c[4:5].contiguous()))
+    assert float((Ys[0] - Y1[4]).abs().max()) < 2e-6 * max(1.0, float(Y1.abs().max()))
+    # same batch size, different neighbours: bit-identical (same kernels, same per-row arithmetic)
+    s2 = s.clone(); s2[0] = s[8]; c2 = c.clone(); c2[0] = c[8]
+    assert torch.equal(model(s2, c2)[4], Y1[4])
 
 
 def test_errors_are_loud():
