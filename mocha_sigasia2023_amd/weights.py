@@ -116,3 +116,73 @@ def synthetic_state_dict(seed: int = 1777, gain: float = 1.0, layout: str = "moc
     if with_buffers:
         out.update(buffer_arrays(layout))
     return out
+
+
+# --------------------------------------------------------------------------- CVAE
+CVAE_CFG = dict(output_seq=90, latent_dim=256, depth=2, nheads=4, feedforward_dim=512)   # test_fullframework.py:52-55
+
+
+def cvae_param_shapes(cfg=None) -> "OrderedDict[str, tuple]":
+    """Learnable parameters of the reference ``CVAE`` that ``sample`` touches (model_CVAE.py:44-46):
+    ``prior_net`` (:49-92) and ``decoder`` (:138-165).  The posterior ``encoder.*`` entries of a
+    checkpoint are training-only and ignored; the ``pos_encoder.pe`` buffers are regenerated."""
+    c = dict(CVAE_CFG, **(cfg or {}))
+    d, ff = c["latent_dim"], c["feedforward_dim"]
+    s = OrderedDict()
+    s["prior_net.mu_token"] = (1, 1, d)
+    s["prior_net.logvar_token"] = (1, 1, d)
+
+    def attn(p):
+        s[f"{p}.in_proj_weight"] = (3 * d, d)
+        s[f"{p}.in_proj_bias"] = (3 * d,)
+        s[f"{p}.out_proj.weight"] = (d, d)
+        s[f"{p}.out_proj.bias"] = (d,)
+
+    def ffn(p, norms):
+        s[f"{p}.linear1.weight"] = (ff, d)
+        s[f"{p}.linear1.bias"] = (ff,)
+        s[f"{p}.linear2.weight"] = (d, ff)
+        s[f"{p}.linear2.bias"] = (d,)
+        for n in norms:
+            s[f"{p}.{n}.weight"] = (d,)
+            s[f"{p}.{n}.bias"] = (d,)
+
+    for l in range(c["depth"]):
+        p = f"prior_net.encoder.layers.{l}"
+        attn(f"{p}.self_attn")
+        ffn(p, ("norm1", "norm2"))
+    for l in range(c["depth"]):
+        p = f"decoder.decoder.layers.{l}"
+        attn(f"{p}.self_attn")
+        attn(f"{p}.multihead_attn")
+        ffn(p, ("norm1", "norm2", "norm3"))
+    return s
+
+
+def sincos_pe(n: int, d: int = 256) -> np.ndarray:
+    """``PositionalEncoding.pe[0, :n]`` of model_CVAE.py:168-178 (float32 arithmetic as in torch)."""
+    import torch
+    position = torch.arange(n).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2) * (-np.log(10000.0) / d))
+    pe = torch.zeros(n, d)
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe.numpy()
+
+
+def synthetic_cvae_state_dict(seed: int = 99, gain: float = 1.0, cfg=None) -> "OrderedDict[str, np.ndarray]":
+    """Deterministic fp32 CVAE weights with the reference's names and shapes."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    out = OrderedDict()
+    for name, shp in cvae_param_shapes(cfg).items():
+        if name.endswith("_token"):
+            out[name] = rng.standard_normal(shp).astype(np.float32)
+        elif ".norm" in name:
+            base = 1.0 if name.endswith("weight") else 0.0
+            out[name] = (base + 0.1 * rng.standard_normal(shp)).astype(np.float32)
+        elif name.endswith("weight"):
+            a = gain / np.sqrt(shp[1])
+            out[name] = rng.uniform(-a, a, size=shp).astype(np.float32)
+        else:
+            out[name] = rng.uniform(-0.05, 0.05, size=shp).astype(np.float32)
+    return out

@@ -136,6 +136,34 @@ def run_match():
     print("match", {k: v for k, v in out.items() if k.endswith("idx")})
 
 
+def run_cvae():
+    """CVAE.sample(c, deterministic=True) of the reference (model_CVAE.py:44-46) with synthetic weights,
+    constructed as the demo does (test_fullframework.py:52-58)."""
+    cwd = os.getcwd(); os.chdir(REF)
+    try:
+        if REF not in sys.path:
+            sys.path.append(REF)
+        import torch.nn.functional as F
+        from model_CVAE import CVAE
+        net = CVAE(output_seq=90, latent_dim=256, depth=2, nheads=4, feedforward_dim=512, dropout=0.1, activation=F.relu).eval()
+    finally:
+        os.chdir(cwd)
+    sd = weights.synthetic_cvae_state_dict(seed=99, gain=1.0)
+    ref_sd = net.state_dict()
+    for k, v in sd.items():
+        assert tuple(ref_sd[k].shape) == v.shape, k
+    missing, unexpected = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected and all(k.startswith("encoder.") or k.endswith("pos_encoder.pe") for k in missing), missing
+    assert np.array_equal(ref_sd["prior_net.pos_encoder.pe"][0, :182].numpy(), weights.sincos_pe(182))
+    c = torch.from_numpy(synthetic.token_features(500, 2 * 2).reshape(2, 180, 256))
+    with torch.no_grad():
+        mu, logvar = net.prior(c)
+        out = net.sample(c, deterministic=True)
+    np.savez(os.path.join(HERE, "cvae_sample.npz"), c=c.numpy(), mu=mu.numpy(), logvar=logvar.numpy(), out=out.numpy(),
+             meta=np.array(repr(dict(seed=99, gain=1.0, torch=torch.__version__))))
+    print("cvae", {k: float(np.abs(v).max()) for k, v in dict(mu=mu.numpy(), logvar=logvar.numpy(), out=out.numpy()).items()})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     run_graph_constants()
@@ -143,3 +171,4 @@ if __name__ == "__main__":
     run_variant("mocha24_g2", "mocha", seed=4242, gain=2.0, B=1)
     run_variant("mixamo22_g1", "mixamo", seed=2222, gain=1.0, B=1)
     run_match()
+    run_cvae()
