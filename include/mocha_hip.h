@@ -125,6 +125,16 @@ int mocha_encode_raw(mocha_ctx* ctx, const float* X_raw, int B, float* encoded, 
 int mocha_characterize_raw(mocha_ctx* ctx, const float* src_X_raw, int B, const float* cnt_mean, const float* cnt_std,
                            float* Y_denorm, int32_t* idx, void* stream);
 
+/* CVAE character-feature sampler: CVAE.sample(c) of model_CVAE.py:44-46, i.e.
+ * PriorNet (:49-92) then Decoder (:138-165).  Weights by their reference state_dict names
+ * ("prior_net.encoder.layers.0.self_attn.in_proj_weight", ...; test_fullframework.py:52-58); the
+ * posterior "encoder.*" entries and the pos_encoder.pe buffers of a checkpoint are accepted and ignored.
+ * cond (B,180,256) -> out (B,90,256).  eps (B,256) is the reparameterisation noise
+ * z = mu + eps*exp(0.5*logvar) (:81-87); eps == NULL is deterministic=True (z = mu).  mu/logvar (B,256) optional. */
+int mocha_cvae_load_weight(mocha_ctx* ctx, const char* name, const float* host, const int64_t* shape, int ndim);
+int mocha_cvae_finalize(mocha_ctx* ctx);
+int mocha_cvae_sample(mocha_ctx* ctx, const float* cond, int B, float* out, float* mu, float* logvar, const float* eps, void* stream);
+
 /* Introspection for tests and tooling. */
 int mocha_abi_version(void);
 int mocha_graph_constants(mocha_ctx* ctx, float* A_j /*3*V*V host*/, float* A_b /*2*6*6 host*/,

@@ -1,7 +1,9 @@
 // Multi-head softmax attention over <= 96 tokens on gfx950, exact-f32 MFMA
 // (reference: Attention.forward, net/transformer.py:65-76).
 //
-// One 192-thread workgroup (3 waves) per (window, head).  Wave w owns query block 32w..32w+31.
+// One workgroup of NQW waves per (window, head); wave w owns query block 32w..32w+31; keys are padded to
+// NKT tiles of 32.  <DH,3,3> serves the Generator (90 tokens, head dim 128 / 256); <64,6,6>, <64,6,3>,
+// <64,3,3> serve the CVAE sampler (182-token prior, 90 queries x 181 memory, 90 x 90; model_CVAE.py).
 //   1. S^T = K · Q^T  (keys on the MFMA rows, queries on the lanes): with the query on the
 //      lane, the softmax over keys is a per-lane reduction over the accumulator registers
 //      plus one cross-half shuffle — no LDS round trip, no 32-lane butterflies.
@@ -17,57 +19,69 @@ namespace mocha {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int NT = 96;       // padded token count (3 tiles of 32)
 static constexpr int LK = 36;       // LDS row stride for the K/Q chunks (32 + 4 pad)
 static constexpr int DV = 64;       // head dims of V staged per pass
 
-template <int DH>
-__global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * NT * LK];   // 27,648 B; V pass reuses it (96*64 floats)
+template <int DH, int NKT, int NQW>
+__global__ __launch_bounds__(NQW * 64) void mocha_attention_f32(AttnParams p) {
+    constexpr int NTHR = NQW * 64;
+    constexpr int KROWS = NKT * 32, QROWS = NQW * 32;
+    constexpr int KPT = KROWS * 8 / NTHR;           // float4 of a K chunk per thread
+    constexpr int QPT = QROWS * 8 / NTHR;           // = 4
+    constexpr int VPT = KROWS * 16 / NTHR;          // float4 of a V pass per thread
+    static_assert(KROWS * 8 % NTHR == 0 && KROWS * 16 % NTHR == 0 && DH % DV == 0, "shape");
+    constexpr int SMF = (KROWS + QROWS) * LK > KROWS * DV ? (KROWS + QROWS) * LK : KROWS * DV;
+    __shared__ __attribute__((aligned(16))) float smem[SMF];           // V pass reuses the K/Q stage
     float* Ks = smem;
-    float* Qs = smem + NT * LK;
+    float* Qs = smem + KROWS * LK;
     float* Vs = smem;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int head = blockIdx.x, b = blockIdx.y;
-    const int n = p.n;
+    const int nq = p.nq, nk = p.nk;
 
-    const float* qg = p.q + (size_t)b * n * p.ldq + head * DH;
-    const float* kg = p.k + (size_t)b * n * p.ldk + head * DH;
-    const float* vg = p.v + (size_t)b * n * p.ldv + head * DH;
+    const float* qg = p.q + (size_t)b * nq * p.ldq + head * DH;
+    const float* kg = p.k + (size_t)b * nk * p.ldk + head * DH;
+    const float* vg = p.v + (size_t)b * nk * p.ldv + head * DH;
 
     // ---------------- phase 1: S^T[key][query] over DH in chunks of 32
-    f32x16 st[3];
+    f32x16 st[NKT];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
 
     // chunk c+1 of K and Q is fetched into registers while chunk c is multiplied (the global-load
     // latency of a chunk is about the length of its 48 MFMAs, so an un-prefetched loop idles half the time)
-    f32x4 kr[4], qr[4];
+    f32x4 kr[KPT], qr[QPT];
     auto fetch_kq = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {           // 96 rows x 8 float4 per matrix = 768 float4; 192 threads x 4
-            const int f = tid + 192 * i;
+        for (int i = 0; i < KPT; ++i) {         // rows x 8 float4 per chunk
+            const int f = tid + NTHR * i;
             const int row = f >> 3, c4 = (f & 7) * 4;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            kr[i] = z; qr[i] = z;
-            if (row < n) {
-                kr[i] = *reinterpret_cast<const f32x4*>(kg + (size_t)row * p.ldk + c * 32 + c4);
-                qr[i] = *reinterpret_cast<const f32x4*>(qg + (size_t)row * p.ldq + c * 32 + c4);
-            }
+            kr[i] = row < nk ? *reinterpret_cast<const f32x4*>(kg + (size_t)row * p.ldk + c * 32 + c4) : z;
+        }
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int f = tid + NTHR * i;
+            const int row = f >> 3, c4 = (f & 7) * 4;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            qr[i] = row < nq ? *reinterpret_cast<const f32x4*>(qg + (size_t)row * p.ldq + c * 32 + c4) : z;
         }
     };
     auto stage_kq = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int f = tid + 192 * i;
-            const int row = f >> 3, c4 = (f & 7) * 4;
-            *reinterpret_cast<f32x4*>(Ks + row * LK + c4) = kr[i];
-            *reinterpret_cast<f32x4*>(Qs + row * LK + c4) = qr[i];
+        for (int i = 0; i < KPT; ++i) {
+            const int f = tid + NTHR * i;
+            *reinterpret_cast<f32x4*>(Ks + (f >> 3) * LK + (f & 7) * 4) = kr[i];
+        }
+#pragma unroll
+        for (int i = 0; i < QPT; ++i) {
+            const int f = tid + NTHR * i;
+            *reinterpret_cast<f32x4*>(Qs + (f >> 3) * LK + (f & 7) * 4) = qr[i];
         }
     };
     fetch_kq(0);
@@ -77,14 +91,14 @@ __global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
         if (c + 1 < DH / 32) fetch_kq(c + 1);
 #pragma unroll
         for (int kgp = 0; kgp < 4; ++kgp) {
-            f32x4 a[3];
+            f32x4 a[NKT];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a[t] = *reinterpret_cast<const f32x4*>(Ks + (t * 32 + l31) * LK + kgp * 8 + 4 * hh);
+            for (int t = 0; t < NKT; ++t) a[t] = *reinterpret_cast<const f32x4*>(Ks + (t * 32 + l31) * LK + kgp * 8 + 4 * hh);
             const f32x4 bq = *reinterpret_cast<const f32x4*>(Qs + (wave * 32 + l31) * LK + kgp * 8 + 4 * hh);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int t = 0; t < 3; ++t)
+                for (int t = 0; t < NKT; ++t)
                     st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][ks], bq[ks], st[t], 0, 0, 0);
         }
         __syncthreads();
@@ -96,18 +110,18 @@ __global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
     // st[t][r] = S[query = 32*wave + l31][key = 32t + (r&3) + 8(r>>2) + 4hh]
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float sv = key < n ? st[t][r] * p.scale : -INFINITY;
+            const float sv = key < nk ? st[t][r] * p.scale : -INFINITY;
             st[t][r] = sv;
             mx = fmaxf(mx, sv);
         }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float e = expf(st[t][r] - mx);
@@ -116,28 +130,28 @@ __global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
         }
     sum += __shfl_xor(sum, 32);
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] / sum;
 
     // ---------------- phase 3: O^T[d][query] = sum_key V[key][d] * P^T[key][query]
     const int query = wave * 32 + l31;
-    float* og = p.out + ((size_t)b * n + query) * p.ldo + head * DH;
+    float* og = p.out + ((size_t)b * nq + query) * p.ldo + head * DH;
     // V is staged 64 head-dims at a time; pass dp+1 is fetched into registers during pass dp
-    f32x4 vr[8];
+    f32x4 vr[VPT];
     auto fetch_v = [&](int dp) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {           // 96 x 16 float4 = 1536; 192 threads x 8
-            const int f = tid + 192 * i;
+        for (int i = 0; i < VPT; ++i) {         // rows x 16 float4 per pass
+            const int f = tid + NTHR * i;
             const int row = f >> 4, c4 = (f & 15) * 4;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            vr[i] = row < n ? *reinterpret_cast<const f32x4*>(vg + (size_t)row * p.ldv + dp * DV + c4) : z;
+            vr[i] = row < nk ? *reinterpret_cast<const f32x4*>(vg + (size_t)row * p.ldv + dp * DV + c4) : z;
         }
     };
     auto stage_v = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int f = tid + 192 * i;
+        for (int i = 0; i < VPT; ++i) {
+            const int f = tid + NTHR * i;
             const int row = f >> 4, c4 = (f & 15) * 4;
             *reinterpret_cast<f32x4*>(Vs + row * DV + c4) = vr[i];
         }
@@ -153,7 +167,7 @@ __global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < NKT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
                 }
             }
         // o[d][r] = O[query][dcol = dp*64 + d*32 + (r&3) + 8(r>>2) + 4hh]: regs 4g..4g+3 are 4 consecutive dims
-        if (query < n) {
+        if (query < nq) {
 #pragma unroll
             for (int d = 0; d < 2; ++d)
 #pragma unroll
@@ -181,10 +195,14 @@ __global__ __launch_bounds__(192) void mocha_attention_f32(AttnParams p) {
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
-    if (p.n > NT || p.n < 1) return hipErrorInvalidValue;
+    if (p.nq < 1 || p.nk < 1 || p.nq > 192 || p.nk > 192) return hipErrorInvalidValue;
     dim3 grid(p.heads, p.B);
-    if (p.dh == 128) hipLaunchKernelGGL((mocha_attention_f32<128>), grid, dim3(192), 0, s, p);
-    else if (p.dh == 256) hipLaunchKernelGGL((mocha_attention_f32<256>), grid, dim3(192), 0, s, p);
+    const bool small = p.nq <= 96 && p.nk <= 96;
+    if (p.dh == 128 && small) hipLaunchKernelGGL((mocha_attention_f32<128, 3, 3>), grid, dim3(192), 0, s, p);
+    else if (p.dh == 256 && small) hipLaunchKernelGGL((mocha_attention_f32<256, 3, 3>), grid, dim3(192), 0, s, p);
+    else if (p.dh == 64 && small) hipLaunchKernelGGL((mocha_attention_f32<64, 3, 3>), grid, dim3(192), 0, s, p);
+    else if (p.dh == 64 && p.nq <= 96) hipLaunchKernelGGL((mocha_attention_f32<64, 6, 3>), grid, dim3(192), 0, s, p);
+    else if (p.dh == 64) hipLaunchKernelGGL((mocha_attention_f32<64, 6, 6>), grid, dim3(384), 0, s, p);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

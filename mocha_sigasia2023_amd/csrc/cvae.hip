@@ -1,0 +1,86 @@
+// Small kernels of the CVAE sampler (model_CVAE.py): LayerNorm over 256 channels,
+// prior token assembly with sin/cos positional encoding, latent selection / re-parameterisation and
+// decoder memory + query initialisation.  The dense work runs on the shared GEMM / attention kernels.
+#include "kernels.h"
+
+namespace mocha {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// nn.LayerNorm(256): y = (x - mean) / sqrt(var + 1e-5) * w + b, biased variance; one wave per row
+__global__ __launch_bounds__(256) void mocha_layernorm256(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ y, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x + (size_t)row * 256)[lane];
+    float s = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.f / 256.f);
+    const f32x4 d = v - mean;
+    float q = (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.f / sqrtf(q * (1.f / 256.f) + 1e-5f);
+    const f32x4 wv = reinterpret_cast<const f32x4*>(w)[lane], bv = reinterpret_cast<const f32x4*>(b)[lane];
+    reinterpret_cast<f32x4*>(y + (size_t)row * 256)[lane] = d * rstd * wv + bv;
+}
+
+hipError_t launch_layernorm256(const float* x, const float* w, const float* b, float* y, int rows, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mocha_layernorm256, dim3((rows + 3) / 4), dim3(256), 0, s, x, w, b, y, rows);
+    return hipGetLastError();
+}
+
+// PriorNet.encode token assembly (model_CVAE.py:69-76): [mu_token, logvar_token, c] + pe[:2+nc]
+__global__ __launch_bounds__(256) void mocha_cvae_prior_tokens(const float* __restrict__ c, const float* __restrict__ mu_tok,
+                                                               const float* __restrict__ lv_tok, const float* __restrict__ pe,
+                                                               float* __restrict__ out, int nc, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);        // (b, t) flattened; one wave per 256-channel row
+    const int q = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int ntok = nc + 2;
+    const int b = row / ntok, t = row - b * ntok;
+    f32x4 v;
+    if (t == 0) v = reinterpret_cast<const f32x4*>(mu_tok)[q];
+    else if (t == 1) v = reinterpret_cast<const f32x4*>(lv_tok)[q];
+    else v = reinterpret_cast<const f32x4*>(c)[((size_t)b * nc + (t - 2)) * 64 + q];
+    const f32x4 pv = reinterpret_cast<const f32x4*>(pe)[t * 64 + q];
+    reinterpret_cast<f32x4*>(out)[(size_t)row * 64 + q] = v + pv;
+}
+
+hipError_t launch_cvae_prior_tokens(const float* c, const float* mu_tok, const float* lv_tok, const float* pe, float* out, int B, int nc,
+                                    hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const int rows = B * (nc + 2);
+    hipLaunchKernelGGL(mocha_cvae_prior_tokens, dim3((rows + 3) / 4), dim3(256), 0, s, c, mu_tok, lv_tok, pe, out, nc, rows);
+    return hipGetLastError();
+}
+
+// z = mu (+ eps * exp(0.5 logvar)), mu = x[:,0], logvar = x[:,1]  (model_CVAE.py:77-87);
+// memory = [z, c] (:160); queries = pe[:nq] (zeros + positional encoding, :161-162)
+__global__ __launch_bounds__(256) void mocha_cvae_latent(const float* __restrict__ x, int ntok, const float* __restrict__ eps,
+                                                         const float* __restrict__ c, int nc, const float* __restrict__ pe, int nq,
+                                                         float* __restrict__ mem, float* __restrict__ qout, float* __restrict__ mu_out,
+                                                         float* __restrict__ lv_out) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float mu = x[((size_t)b * ntok) * 256 + tid], lv = x[((size_t)b * ntok + 1) * 256 + tid];
+    float z = mu;
+    if (eps) z = mu + eps[(size_t)b * 256 + tid] * expf(0.5f * lv);
+    if (mu_out) mu_out[(size_t)b * 256 + tid] = mu;
+    if (lv_out) lv_out[(size_t)b * 256 + tid] = lv;
+    float* mb = mem + (size_t)b * (nc + 1) * 256;
+    mb[tid] = z;
+    for (int i = 0; i < nc; ++i) mb[(size_t)(i + 1) * 256 + tid] = c[((size_t)b * nc + i) * 256 + tid];
+    float* qb = qout + (size_t)b * nq * 256;
+    for (int i = 0; i < nq; ++i) qb[(size_t)i * 256 + tid] = pe[(size_t)i * 256 + tid];
+}
+
+hipError_t launch_cvae_latent(const float* x, int ntok, const float* eps, const float* c, int nc, const float* pe, int nq, float* mem,
+                              float* q, float* mu_out, float* logvar_out, int B, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mocha_cvae_latent, dim3(B), dim3(256), 0, s, x, ntok, eps, c, nc, pe, nq, mem, q, mu_out, logvar_out);
+    return hipGetLastError();
+}
+
+}  // namespace mocha

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
                         if (rbrow) v += *reinterpret_cast<const f32x4*>(rbrow + col);
                         if (p.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
                         else if (p.act == 2) { v[0] = lrelu02(v[0]); v[1] = lrelu02(v[1]); v[2] = lrelu02(v[2]); v[3] = lrelu02(v[3]); }
+                        else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                         if (rsrow) v += *reinterpret_cast<const f32x4*>(rsrow + col);
                     }
                     *reinterpret_cast<f32x4*>(crow + col) = v;
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
                             if (rbrow) x += rbrow[c1];
                             if (p.act == 1) x = gelu_erf(x);
                             else if (p.act == 2) x = lrelu02(x);
+                            else if (p.act == 3) x = fmaxf(x, 0.f);
                             if (rsrow) x += rsrow[c1];
                         }
                         crow[c1] = x;
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_skinny(GemmParams p) {
         if (rbrow) v += *reinterpret_cast<const f32x4*>(rbrow + col);
         if (p.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
         else if (p.act == 2) { v[0] = lrelu02(v[0]); v[1] = lrelu02(v[1]); v[2] = lrelu02(v[2]); v[3] = lrelu02(v[3]); }
+                        else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
         if (rsrow) v += *reinterpret_cast<const f32x4*>(rsrow + col);
         *reinterpret_cast<f32x4*>(crow + col) = v;
     }

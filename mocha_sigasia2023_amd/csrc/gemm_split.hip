@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_split(GemmParams p) {
                         if (rbrow) v += *reinterpret_cast<const f32x4*>(rbrow + col);
                         if (p.act == 1) { v[0] = gelu_erfs(v[0]); v[1] = gelu_erfs(v[1]); v[2] = gelu_erfs(v[2]); v[3] = gelu_erfs(v[3]); }
                         else if (p.act == 2) { v[0] = lrelu02s(v[0]); v[1] = lrelu02s(v[1]); v[2] = lrelu02s(v[2]); v[3] = lrelu02s(v[3]); }
+                        else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                         if (rsrow) v += *reinterpret_cast<const f32x4*>(rsrow + col);
                     }
                     *reinterpret_cast<f32x4*>(crow + col) = v;
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_split(GemmParams p) {
                             if (rbrow) x += rbrow[c1];
                             if (p.act == 1) x = gelu_erfs(x);
                             else if (p.act == 2) x = lrelu02s(x);
+                            else if (p.act == 3) x = fmaxf(x, 0.f);
                             if (rsrow) x += rsrow[c1];
                         }
                         crow[c1] = x;

@@ -28,7 +28,7 @@ struct GemmParams {
     int M = 0, N = 0, K = 0;
     int lda = 0, ldc = 0, ldr = 0;
     int rb_mod = 1;
-    int act = 0;          // 0 none, 1 exact-erf GELU, 2 LeakyReLU(0.2)
+    int act = 0;          // 0 none, 1 exact-erf GELU, 2 LeakyReLU(0.2), 3 ReLU
     int a_lrelu = 0;      // LeakyReLU(0.2) applied to the A operand as it is loaded
     int gather = 0;       // 0 plain rows, 1 temporal gather
     int T_out = 1, V = 1, ntaps = 1, pad = 0, stride = 1, R = 1, T_full = 1, tshift = 0, Cc = 0, T_src = 1;
@@ -46,13 +46,14 @@ void split_weights_host(const float* w, size_t count, unsigned short* out /*3*co
 hipError_t gemm_init();           // one-time function attributes (dynamic LDS size)
 
 // ---------------------------------------------------------------------------------------
-// Multi-head attention over n (<= 96) tokens, one workgroup per (window, head)
-// (net/transformer.py:65-76): out[b, i, h*DH + d] = softmax_j(q_i·k_j * scale) v_j
+// Multi-head attention, nq queries x nk keys (<= 192), one workgroup per (window, head)
+// (net/transformer.py:65-76; nn.MultiheadAttention in model_CVAE.py):
+//   out[b, i, h*DH + d] = softmax_j(q_i·k_j * scale) v_j ;  batch b starts at row b*nq (q, out) / b*nk (k, v)
 // ---------------------------------------------------------------------------------------
 struct AttnParams {
     const float* q; const float* k; const float* v; float* out;
     int ldq, ldk, ldv, ldo;       // row strides in floats
-    int B, heads, dh, n;
+    int B, heads, dh, nq, nk;
     float scale;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
@@ -83,6 +84,14 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
 hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin, int B, int n, hipStream_t s);
 // u rows (b,t',p) x (dt*256+c) = 1/4 sum of the 4 reflect-indexed frames of tap dt (conv k=5 fused with AvgPool(4))
 hipError_t launch_window_sums(const float* ybar, float* u, int rows /*B*90*/, hipStream_t s);
+// ---- CVAE sampler pieces (cvae.hip; model_CVAE.py)
+// y = LayerNorm(x) over 256 channels per row (eps 1e-5, biased variance), affine
+hipError_t launch_layernorm256(const float* x, const float* w, const float* b, float* y, int rows, hipStream_t s);
+// tokens (B,182,256) = [mu_token, logvar_token, c (B,180,256)] + pe[:182]          (model_CVAE.py:69-76)
+hipError_t launch_cvae_prior_tokens(const float* c, const float* mu_tok, const float* lv_tok, const float* pe, float* out, int B, int nc, hipStream_t s);
+// z = x[:,0] (+ eps * exp(0.5 x[:,1]));  mem (B,1+nc,256) = [z, c];  q (B,nq,256) = pe[:nq]   (model_CVAE.py:81-87,158-163)
+hipError_t launch_cvae_latent(const float* x /*B,ntok,256*/, int ntok, const float* eps, const float* c, int nc, const float* pe, int nq,
+                              float* mem, float* q, float* mu_out, float* logvar_out, int B, hipStream_t s);
 // bank row squared norms
 hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, hipStream_t s);
 // per query: argmin_n (bnorm[n] - 2*sum_z S[z][q][n]); then exact distance to the winner

@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <deque>
 #include <map>
 #include <string>
@@ -120,6 +121,13 @@ struct mocha_ctx {
     float* bank_cnt_own = nullptr; float* bank_enc_own = nullptr; size_t bank_cap = 0;
     float* bank_norm = nullptr; size_t bank_norm_cap = 0;
     int64_t bank_N = 0;
+    // CVAE sampler (row N1): weights under "cvae.<reference key>", workspace for cvae_B conditions
+    std::map<std::string, std::vector<int64_t>> cvae_expect;
+    std::map<std::string, HostTensor> cvae_host;
+    std::map<std::string, float*> cw;
+    bool cvae_ready = false;
+    int cvae_depth = 2, cvae_heads = 4, cvae_nc = 180, cvae_nq = 90;
+    std::map<std::string, DevBuf> cws; int cvae_B = 0;
     float* pose_norm = nullptr;        // [x_mean | x_std | y_mean | y_std], (V+1)*C_in each (norm.npz of the reference)
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
     unsigned long long* best_ws = nullptr; size_t best_ws_n = 0;
@@ -391,7 +399,7 @@ int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStr
         GemmParams q = plain(x, 256, DW(c, p + ".Wqkv"), WS(c, "qkv"), 3 * inner, M, 3 * inner, 256);
         GEMM(c, s, "enc.qkv", q);
         AttnParams a{WS(c, "qkv"), WS(c, "qkv") + inner, WS(c, "qkv") + 2 * inner, WS(c, "ao"),
-                     3 * inner, 3 * inner, 3 * inner, inner, b, H, DH, 90, (float)std::pow((double)DH, -0.5)};
+                     3 * inner, 3 * inner, 3 * inner, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5)};
         LAUNCH(c, s, DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>", "enc.attn", 4.0 * b * H * 90.0 * 90 * DH,
                4.0 * M * 4 * inner, launch_attention(a, s));
         float* out = (l == c->cfg.enc_depth - 1) ? encoded : WS(c, "xa");
@@ -427,7 +435,7 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
         GEMM(c, s, "dec.k", gk);
         GemmParams gv = plain(cha, 256, DW(c, p + ".Wv"), vb, inner, M, inner, 256);
         GEMM(c, s, "dec.v", gv);
-        AttnParams a{qb, kb, vb, WS(c, "ao"), inner, inner, inner, inner, b, H, DH, 90, (float)std::pow((double)DH, -0.5)};
+        AttnParams a{qb, kb, vb, WS(c, "ao"), inner, inner, inner, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5)};
         LAUNCH(c, s, DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>", "dec.attn", 4.0 * b * H * 90.0 * 90 * DH,
                4.0 * M * 4 * inner, launch_attention(a, s));
         float* out = (l == c->cfg.dec_depth - 1) ? outp : WS(c, "xa");
@@ -926,6 +934,190 @@ int mocha_encode_raw(mocha_ctx* c, const float* X_raw, int B, float* encoded, fl
                    launch_instnorm(encoded + b0 * ts, cnt + b0 * ts, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
                                    zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
     }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- CVAE sampler
+static void cvae_expectations(mocha_ctx* c) {
+    if (!c->cvae_expect.empty()) return;
+    auto& e = c->cvae_expect;
+    const int64_t d = 256, ff = 512;
+    e["prior_net.mu_token"] = {1, 1, d};
+    e["prior_net.logvar_token"] = {1, 1, d};
+    auto attn = [&](const std::string& p) {
+        e[p + ".in_proj_weight"] = {3 * d, d}; e[p + ".in_proj_bias"] = {3 * d};
+        e[p + ".out_proj.weight"] = {d, d}; e[p + ".out_proj.bias"] = {d};
+    };
+    auto ffn = [&](const std::string& p, int norms) {
+        e[p + ".linear1.weight"] = {ff, d}; e[p + ".linear1.bias"] = {ff};
+        e[p + ".linear2.weight"] = {d, ff}; e[p + ".linear2.bias"] = {d};
+        for (int n = 1; n <= norms; ++n) { e[p + ".norm" + std::to_string(n) + ".weight"] = {d}; e[p + ".norm" + std::to_string(n) + ".bias"] = {d}; }
+    };
+    for (int l = 0; l < c->cvae_depth; ++l) {
+        const std::string p = "prior_net.encoder.layers." + std::to_string(l);
+        attn(p + ".self_attn"); ffn(p, 2);
+        const std::string q = "decoder.decoder.layers." + std::to_string(l);
+        attn(q + ".self_attn"); attn(q + ".multihead_attn"); ffn(q, 3);
+    }
+}
+
+int mocha_cvae_load_weight(mocha_ctx* c, const char* name, const float* host, const int64_t* shape, int ndim) {
+    if (!c || !name || !host || !shape) return fail(c, MOCHA_ERR_ARG, "null argument");
+    cvae_expectations(c);
+    const std::string n(name);
+    // training-only posterior encoder and the regenerated positional-encoding buffers are accepted and ignored
+    if (n.rfind("encoder.", 0) == 0) return 0;
+    if (n.size() > 15 && n.compare(n.size() - 15, 15, ".pos_encoder.pe") == 0) {
+        // registered buffer (1, max_len, 256): keep its first 192 rows so the table is bit-identical to the checkpoint's
+        if (ndim == 3 && shape[0] == 1 && shape[1] >= 192 && shape[2] == 256) {
+            HostTensor t; t.data.assign(host, host + 192 * 256); t.shape = {192, 256};
+            c->cvae_host["pe"] = std::move(t);
+            c->cvae_ready = false;
+        }
+        return 0;
+    }
+    auto it = c->cvae_expect.find(n);
+    if (it == c->cvae_expect.end()) return fail(c, MOCHA_ERR_WEIGHT, "unknown CVAE weight name '%s'", name);
+    if ((int)it->second.size() != ndim) return fail(c, MOCHA_ERR_WEIGHT, "%s: rank %d, expected %zu", name, ndim, it->second.size());
+    size_t cnt = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] != it->second[i]) return fail(c, MOCHA_ERR_WEIGHT, "%s: dim %d is %lld, expected %lld", name, i, (long long)shape[i], (long long)it->second[i]);
+        cnt *= (size_t)shape[i];
+    }
+    HostTensor t; t.data.assign(host, host + cnt); t.shape.assign(shape, shape + ndim);
+    c->cvae_host[n] = std::move(t);
+    c->cvae_ready = false;
+    return 0;
+}
+
+int mocha_cvae_finalize(mocha_ctx* c) {
+    if (!c) return MOCHA_ERR_ARG;
+    cvae_expectations(c);
+    for (auto& kv : c->cvae_expect)
+        if (!c->cvae_host.count(kv.first)) return fail(c, MOCHA_ERR_STATE, "missing CVAE weight '%s'", kv.first.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    for (auto& kv : c->cvae_host) {
+        float* d = nullptr;
+        int rc = dev_alloc(c, &d, kv.second.data.size()); if (rc) return rc;
+        HIPCHK(c, hipMemcpy(d, kv.second.data.data(), kv.second.data.size() * sizeof(float), hipMemcpyHostToDevice));
+        c->cw[kv.first] = d;
+    }
+    if (c->cw.count("pe")) { c->cvae_ready = true; return 0; }     // table came with the state_dict (pos_encoder.pe)
+    // sin/cos positional encoding rows 0..191 (model_CVAE.py:168-178), float32 arithmetic like torch
+    std::vector<float> pe(192 * 256);
+    for (int i = 0; i < 128; ++i) {
+        const float div = expf((float)(2 * i) * (float)(-std::log(10000.0) / 256.0));
+        for (int t = 0; t < 192; ++t) {
+            const float a = (float)t * div;
+            pe[t * 256 + 2 * i] = sinf(a);
+            pe[t * 256 + 2 * i + 1] = cosf(a);
+        }
+    }
+    float* dpe = nullptr;
+    int rc = dev_alloc(c, &dpe, pe.size()); if (rc) return rc;
+    HIPCHK(c, hipMemcpy(dpe, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->cw["pe"] = dpe;
+    c->cvae_ready = true;
+    return 0;
+}
+
+static int cvae_ws(mocha_ctx* c, int B) {
+    if (c->cvae_B >= B) return 0;
+    if (c->cvae_B > 0) HIPCHK(c, hipDeviceSynchronize());
+    for (auto& kv : c->cws) if (kv.second.p) { (void)hipFree(kv.second.p); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), kv.second.p), c->owned.end()); }
+    c->cws.clear();
+    const std::pair<const char*, size_t> plan[] = {{"t0", 182 * 256}, {"t1", 182 * 256}, {"t2", 182 * 256}, {"qkv", 182 * 768},
+                                                   {"hff", 182 * 512}, {"mem", 181 * 256}, {"kv", 181 * 512}};
+    for (auto& pl : plan) { DevBuf b; b.n = pl.second * (size_t)B; int rc = dev_alloc(c, &b.p, b.n); if (rc) return rc; c->cws[pl.first] = b; }
+    c->cvae_B = B;
+    return 0;
+}
+
+// post-norm transformer sub-blocks shared by PriorNet and Decoder (nn.TransformerEncoderLayer / DecoderLayer defaults)
+static int cvae_attn_block(mocha_ctx* c, hipStream_t s, const std::string& p, const std::string& norm, float* x /*in/out*/, int nq,
+                           const float* kvsrc /*nullptr: self*/, int nk, int B) {
+    float* qkv = c->cws.at("qkv").p; float* t1 = c->cws.at("t1").p; float* t2 = c->cws.at("t2").p; float* kvb = c->cws.at("kv").p;
+    const float* Win = c->cw.at(p + ".in_proj_weight"); const float* bin = c->cw.at(p + ".in_proj_bias");
+    const int H = c->cvae_heads, DH = 256 / H;
+    AttnParams a{};
+    if (!kvsrc) {
+        GemmParams g = plain(x, 256, Win, qkv, 768, B * nq, 768, 256); g.bias = bin;
+        GEMM(c, s, "cvae.in_proj", g);
+        a = AttnParams{qkv, qkv + 256, qkv + 512, t1, 768, 768, 768, 256, B, H, DH, nq, nq, (float)std::pow((double)DH, -0.5)};
+    } else {
+        GemmParams gq = plain(x, 256, Win, qkv, 256, B * nq, 256, 256); gq.bias = bin;
+        GEMM(c, s, "cvae.q_proj", gq);
+        GemmParams gk = plain(kvsrc, 256, Win + 256 * 256, kvb, 512, B * nk, 512, 256); gk.bias = bin + 256;
+        GEMM(c, s, "cvae.kv_proj", gk);
+        a = AttnParams{qkv, kvb, kvb + 256, t1, 256, 512, 512, 256, B, H, DH, nq, nk, (float)std::pow((double)DH, -0.5)};
+    }
+    LAUNCH(c, s, "mocha_attention_f32<64>", "cvae.attn", 4.0 * B * H * (double)a.nq * a.nk * DH, 4.0 * B * (a.nq + 2.0 * a.nk) * 256,
+           launch_attention(a, s));
+    GemmParams o = plain(t1, 256, c->cw.at(p + ".out_proj.weight"), t2, 256, B * nq, 256, 256);
+    o.bias = c->cw.at(p + ".out_proj.bias"); o.residual = x; o.ldr = 256;
+    GEMM(c, s, "cvae.out_proj", o);
+    LAUNCH(c, s, "mocha_layernorm256", "cvae.norm", 0.0, B * nq * 256.0 * 8,
+           launch_layernorm256(t2, c->cw.at(norm + ".weight"), c->cw.at(norm + ".bias"), x, B * nq, s));
+    return 0;
+}
+
+static int cvae_ff_block(mocha_ctx* c, hipStream_t s, const std::string& p, const std::string& norm, float* x, float* out, int n, int B) {
+    float* hff = c->cws.at("hff").p; float* t2 = c->cws.at("t2").p;
+    GemmParams f1 = plain(x, 256, c->cw.at(p + ".linear1.weight"), hff, 512, B * n, 512, 256);
+    f1.bias = c->cw.at(p + ".linear1.bias"); f1.act = 3;
+    GEMM(c, s, "cvae.ff1", f1);
+    GemmParams f2 = plain(hff, 512, c->cw.at(p + ".linear2.weight"), t2, 256, B * n, 256, 512);
+    f2.bias = c->cw.at(p + ".linear2.bias"); f2.residual = x; f2.ldr = 256;
+    GEMM(c, s, "cvae.ff2", f2);
+    LAUNCH(c, s, "mocha_layernorm256", "cvae.norm", 0.0, B * n * 256.0 * 8,
+           launch_layernorm256(t2, c->cw.at(norm + ".weight"), c->cw.at(norm + ".bias"), out, B * n, s));
+    return 0;
+}
+
+int mocha_cvae_sample(mocha_ctx* c, const float* cond, int B, float* out, float* mu, float* logvar, const float* eps, void* stream) {
+    if (!c || !cond || !out || B < 0) return fail(c, MOCHA_ERR_ARG, "bad CVAE arguments");
+    if (!c->cvae_ready) return fail(c, MOCHA_ERR_STATE, "CVAE weights not finalised: call mocha_cvae_finalize first");
+    if (B == 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = cvae_ws(c, B); if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int nc = c->cvae_nc, nq = c->cvae_nq, ntok = nc + 2;
+    float* t0 = c->cws.at("t0").p; float* mem = c->cws.at("mem").p;
+    // PriorNet.encode (model_CVAE.py:69-79)
+    LAUNCH(c, s, "mocha_cvae_prior_tokens", "cvae.tokens", 0.0, B * ntok * 256.0 * 8,
+           launch_cvae_prior_tokens(cond, c->cw.at("prior_net.mu_token"), c->cw.at("prior_net.logvar_token"), c->cw.at("pe"), t0, B, nc, s));
+    for (int l = 0; l < c->cvae_depth; ++l) {
+        const std::string p = "prior_net.encoder.layers." + std::to_string(l);
+        if ((rc = cvae_attn_block(c, s, p + ".self_attn", p + ".norm1", t0, ntok, nullptr, ntok, B))) return rc;
+        if ((rc = cvae_ff_block(c, s, p, p + ".norm2", t0, t0, ntok, B))) return rc;
+    }
+    // reparameterize + Decoder inputs (model_CVAE.py:81-87, 158-163); the decoder state reuses t1's sibling t0 after this
+    float* xq = c->cws.at("t1").p;     // free until the first attention writes it: use hff as query buffer instead
+    xq = c->cws.at("hff").p;           // (B, nq, 256) fits in (B, 182, 512)
+    LAUNCH(c, s, "mocha_cvae_latent", "cvae.latent", 0.0, B * (nc + nq + 2) * 256.0 * 4,
+           launch_cvae_latent(t0, ntok, eps, cond, nc, c->cw.at("pe"), nq, mem, xq, mu, logvar, B, s));
+    HIPCHK(c, hipMemcpyAsync(t0, xq, (size_t)B * nq * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    for (int l = 0; l < c->cvae_depth; ++l) {
+        const std::string p = "decoder.decoder.layers." + std::to_string(l);
+        if ((rc = cvae_attn_block(c, s, p + ".self_attn", p + ".norm1", t0, nq, nullptr, nq, B))) return rc;
+        if ((rc = cvae_attn_block(c, s, p + ".multihead_attn", p + ".norm2", t0, nq, mem, nc + 1, B))) return rc;
+        const bool last = l == c->cvae_depth - 1;
+        if ((rc = cvae_ff_block(c, s, p, p + ".norm3", t0, last ? out : t0, nq, B))) return rc;
+    }
+    return 0;
+}
+
+// debugging aid (not in the public header): copy a workspace buffer to the host after a device sync
+int mocha_debug_read(mocha_ctx* c, const char* name, float* host, int64_t count) {
+    if (!c || !name || !host) return MOCHA_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    const std::string n(name);
+    const DevBuf* b = nullptr;
+    if (n.rfind("cvae.", 0) == 0 && c->cws.count(n.substr(5))) b = &c->cws.at(n.substr(5));
+    else if (c->ws.count(n)) b = &c->ws.at(n);
+    if (!b || (size_t)count > b->n) return fail(c, MOCHA_ERR_ARG, "no such buffer or too many elements");
+    HIPCHK(c, hipMemcpy(host, b->p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
     return 0;
 }
 

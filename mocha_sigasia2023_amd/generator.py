@@ -397,3 +397,77 @@ class StreamingCharacterizer:
         else:
             self._enqueue()
         return self.y[0], self.idx
+
+
+class CVAE:
+    """Drop-in for the reference ``CVAE`` sampler (model_CVAE.py:8-46) as the demo uses it
+    (test_fullframework.py:52-58, 446-449): ``CVAE(...).load_state_dict(sd).eval().sample(condition)``.
+    Only the inference path (``sample``, ``prior``) is provided; the posterior encoder is training-only."""
+
+    def __init__(self, output_seq: int = 90, latent_dim: int = 256, depth: int = 2, nheads: int = 4,
+                 feedforward_dim: int = 512, dropout: float = 0.1, activation=None, device="cuda:0"):
+        if (output_seq, latent_dim, depth, nheads, feedforward_dim) != (90, 256, 2, 4, 512):
+            raise ValueError("the HIP CVAE is built for the demo's configuration (90, 256, 2, 4, 512)")
+        self.device = torch.device(device)
+        self._ctx = _Context(DEFAULT_CFG, "mocha", self.device)
+        self._loaded = False
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise RuntimeError("create the CVAE on its target device")
+        return self
+
+    def load_state_dict(self, state_dict: Mapping, strict: bool = True):
+        from .weights import cvae_param_shapes
+        want = cvae_param_shapes()
+        seen = set()
+        for k, v in state_dict.items():
+            a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if k not in want and not k.startswith("encoder.") and not k.endswith("pos_encoder.pe"):
+                if strict:
+                    raise KeyError(f"unexpected key in CVAE state_dict: {k}")
+                continue
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            self._ctx.call("mocha_cvae_load_weight", k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+            seen.add(k)
+        missing = [k for k in want if k not in seen]
+        if missing:
+            raise KeyError(f"missing keys in CVAE state_dict: {missing[:4]}{'...' if len(missing) > 4 else ''}")
+        if "prior_net.pos_encoder.pe" not in state_dict:
+            # regenerate the registered buffer exactly as torch builds it (model_CVAE.py:168-178)
+            from .weights import sincos_pe
+            pe = np.ascontiguousarray(sincos_pe(192)[None], dtype=np.float32)
+            self._ctx.call("mocha_cvae_load_weight", b"prior_net.pos_encoder.pe", pe.ctypes.data_as(C.c_void_p),
+                           (C.c_int64 * 3)(*pe.shape), 3)
+        self._ctx.call("mocha_cvae_finalize")
+        self._loaded = True
+        return self
+
+    def _run(self, c, eps):
+        if not self._loaded:
+            raise RuntimeError("CVAE weights not loaded: call load_state_dict first")
+        c = _dev_f32(c, self.device, (180, DIM), "condition")
+        B = c.shape[0]
+        out = torch.empty((B, NTOK, DIM), dtype=torch.float32, device=self.device)
+        mu = torch.empty((B, DIM), dtype=torch.float32, device=self.device)
+        logvar = torch.empty_like(mu)
+        e = None if eps is None else _dev_f32(eps, self.device, (DIM,), "eps")
+        self._ctx.call("mocha_cvae_sample", _ptr(c), B, _ptr(out), _ptr(mu), _ptr(logvar), _ptr(e), _stream())
+        return out, mu, logvar
+
+    def prior(self, c):                                      # model_CVAE.py:32-34
+        _, mu, logvar = self._run(c, None)
+        return mu, logvar
+
+    def sample(self, c, deterministic: bool = False, eps: Optional[torch.Tensor] = None):    # model_CVAE.py:44-46
+        """``eps`` (B, 256) is the reparameterisation noise; when omitted and not deterministic it is drawn
+        with ``torch.randn`` on the device (the reference draws ``torch.randn_like(std)``, :83)."""
+        if deterministic:
+            eps = None
+        elif eps is None:
+            eps = torch.randn((c.shape[0], DIM), dtype=torch.float32, device=self.device)
+        return self._run(c, eps)[0]

@@ -1,0 +1,53 @@
+"""GPU parity of the CVAE sampler against the reference-generated fixture and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mocha_sigasia2023_amd import CVAE, synthetic, weights
+from oracle import cvae_oracle as CO
+from oracle.mocha_oracle import to_torch_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    return CVAE(output_seq=90, latent_dim=256, depth=2, nheads=4, feedforward_dim=512, device="cuda:0") \
+        .load_state_dict(weights.synthetic_cvae_state_dict(99, 1.0)).eval()
+
+
+def test_sample_deterministic_matches_reference_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "cvae_sample.npz"))
+    net = _model()
+    c = torch.from_numpy(z["c"]).cuda()
+    mu, logvar = net.prior(c)
+    out = net.sample(c, deterministic=True)
+    assert np.abs(mu.cpu().numpy() - z["mu"]).max() < 1e-4
+    assert np.abs(logvar.cpu().numpy() - z["logvar"]).max() < 1e-4
+    assert np.abs(out.cpu().numpy() - z["out"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("B", [1, 5])
+def test_sample_with_noise_matches_oracle(B):
+    net = _model()
+    sd = to_torch_state(weights.synthetic_cvae_state_dict(99, 1.0))
+    c = torch.from_numpy(synthetic.token_features(700 + B, 2 * B).reshape(B, 180, 256))
+    eps = torch.from_numpy(synthetic.token_features(800 + B, 1)[0, :B].copy())
+    with torch.no_grad():
+        ref, mu, logvar = CO.sample(sd, c, eps)
+    out = net.sample(c.cuda(), eps=eps.cuda())
+    assert float((out.cpu() - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+    # autoregressive use (test_fullframework.py:446-452): feeding the output back must stay in tolerance
+    cond2 = torch.cat([c[:, :90], ref], dim=1)
+    with torch.no_grad():
+        ref2, _, _ = CO.sample(sd, cond2)
+    out2 = net.sample(torch.cat([c[:, :90].cuda(), out], dim=1), deterministic=True)
+    assert float((out2.cpu() - ref2).abs().max()) < 2e-4 * max(1.0, float(ref2.abs().max()))
+
+
+def test_cvae_errors():
+    with pytest.raises(KeyError):
+        CVAE(device="cuda:0").load_state_dict({"prior_net.mu_token": np.zeros((1, 1, 256), np.float32)})
+    with pytest.raises(RuntimeError, match="not loaded"):
+        CVAE(device="cuda:0").sample(torch.zeros(1, 180, 256))

@@ -39,6 +39,9 @@ int main(int argc, char** argv) {
         {"emb.tcn_body ", B * 90, 256, 768, 1, 15, 6, 3, 1, 1, 1, 15, 0, 256, 15, 256},
         {"mot.tcn_joint", B * 1440, 64, 320, 1, 60, 24, 5, 2, 1, 1, 60, 2, 64, 15, 64},
         {"mot.gcn_joint", B * 90, 192, 256, 0},
+        {"cvae M=182   ", 182, 768, 256, 0},
+        {"cvae M=364   ", 364, 768, 256, 0},
+        {"cvae M=90    ", 90, 768, 256, 0},
         {"match 585    ", 585, 585, 23040, 0},
         {"square 4096  ", 4096, 4096, 4096, 0},
     };
