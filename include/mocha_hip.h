@@ -135,6 +135,13 @@ int mocha_cvae_load_weight(mocha_ctx* ctx, const char* name, const float* host, 
 int mocha_cvae_finalize(mocha_ctx* ctx);
 int mocha_cvae_sample(mocha_ctx* ctx, const float* cond, int B, float* out, float* mu, float* logvar, const float* eps, void* stream);
 
+/* Conditioning glue of the demo's CVAE ("Ours") branch, test_fullframework.py:446-449, all (.., 90, 256):
+ *   cond (B,180,256) = cat[(src_cnt - src_mean)/src_std , (prev_cha - cha_mean)/cha_std]  (token axis)
+ *   out = x * std + mean                       (curr_cha_encoded = vae_output * cha_encoded_std + cha_encoded_mean) */
+int mocha_cvae_condition(mocha_ctx* ctx, const float* src_cnt, const float* src_mean, const float* src_std, const float* prev_cha,
+                         const float* cha_mean, const float* cha_std, int B, float* cond, void* stream);
+int mocha_scale_shift(mocha_ctx* ctx, const float* x, const float* mean, const float* std_, int B, float* out, void* stream);
+
 /* Introspection for tests and tooling. */
 int mocha_abi_version(void);
 int mocha_graph_constants(mocha_ctx* ctx, float* A_j /*3*V*V host*/, float* A_b /*2*6*6 host*/,

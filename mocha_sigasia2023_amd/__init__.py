@@ -3,10 +3,10 @@ hot path (motion encoder -> context matching -> body-part decoder) behind the re
 own call surface.  The arithmetic lives in ``libmocha_hip.so`` (``csrc/``, C ABI in
 ``include/mocha_hip.h``); this package is the thin host-side mirror of the reference interface.
 """
-from .generator import CVAE, ContextBank, Generator, StreamingCharacterizer, mean_variance_norm  # noqa: F401
+from .generator import CVAE, ContextBank, Generator, OursSession, StreamingCharacterizer, mean_variance_norm  # noqa: F401
 from .skeleton import skeleton_constants  # noqa: F401
 from . import synthetic  # noqa: F401
 from .weights import DEFAULT_CFG, param_shapes, synthetic_state_dict  # noqa: F401
 
-__all__ = ["Generator", "CVAE", "ContextBank", "StreamingCharacterizer", "mean_variance_norm", "skeleton_constants",
+__all__ = ["Generator", "CVAE", "OursSession", "ContextBank", "StreamingCharacterizer", "mean_variance_norm", "skeleton_constants",
            "synthetic_state_dict", "param_shapes", "DEFAULT_CFG"]

@@ -83,4 +83,47 @@ hipError_t launch_cvae_latent(const float* x, int ntok, const float* eps, const 
     return hipGetLastError();
 }
 
+// Conditioning glue of the demo's CVAE branch (test_fullframework.py:446-449):
+//   cond[b] = cat[(src_cnt[b] - src_mean)/src_std , (prev_cha[b] - cha_mean)/cha_std]   along tokens -> (B, 2n, 256)
+__global__ __launch_bounds__(256) void mocha_cvae_condition(const float* __restrict__ src_cnt, const float* __restrict__ sm,
+                                                            const float* __restrict__ ss, const float* __restrict__ prev,
+                                                            const float* __restrict__ cm, const float* __restrict__ cs,
+                                                            float* __restrict__ cond, int n, int rows /*B*2n*/) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), q = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int b = row / (2 * n), t = row - b * 2 * n;
+    const bool first = t < n;
+    const int tt = first ? t : t - n;
+    const f32x4 x = reinterpret_cast<const f32x4*>(first ? src_cnt : prev)[((size_t)b * n + tt) * 64 + q];
+    const f32x4 m = reinterpret_cast<const f32x4*>(first ? sm : cm)[tt * 64 + q];
+    const f32x4 sd = reinterpret_cast<const f32x4*>(first ? ss : cs)[tt * 64 + q];
+    reinterpret_cast<f32x4*>(cond)[(size_t)row * 64 + q] = (x - m) / sd;
+}
+
+hipError_t launch_cvae_condition(const float* src_cnt, const float* sm, const float* ss, const float* prev, const float* cm,
+                                 const float* cs, float* cond, int B, int n, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const int rows = B * 2 * n;
+    hipLaunchKernelGGL(mocha_cvae_condition, dim3((rows + 3) / 4), dim3(256), 0, s, src_cnt, sm, ss, prev, cm, cs, cond, n, rows);
+    return hipGetLastError();
+}
+
+// curr_cha_encoded = vae_output * cha_encoded_std + cha_encoded_mean   (test_fullframework.py:449)
+__global__ __launch_bounds__(256) void mocha_scale_shift(const float* __restrict__ x, const float* __restrict__ mean,
+                                                         const float* __restrict__ sd, float* __restrict__ out, int n, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), q = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int t = row % n;
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[(size_t)row * 64 + q];
+    reinterpret_cast<f32x4*>(out)[(size_t)row * 64 + q] =
+        v * reinterpret_cast<const f32x4*>(sd)[t * 64 + q] + reinterpret_cast<const f32x4*>(mean)[t * 64 + q];
+}
+
+hipError_t launch_scale_shift(const float* x, const float* mean, const float* sd, float* out, int B, int n, hipStream_t s) {
+    if (B <= 0) return hipSuccess;
+    const int rows = B * n;
+    hipLaunchKernelGGL(mocha_scale_shift, dim3((rows + 3) / 4), dim3(256), 0, s, x, mean, sd, out, n, rows);
+    return hipGetLastError();
+}
+
 }  // namespace mocha

@@ -92,6 +92,10 @@ hipError_t launch_cvae_prior_tokens(const float* c, const float* mu_tok, const f
 // z = x[:,0] (+ eps * exp(0.5 x[:,1]));  mem (B,1+nc,256) = [z, c];  q (B,nq,256) = pe[:nq]   (model_CVAE.py:81-87,158-163)
 hipError_t launch_cvae_latent(const float* x /*B,ntok,256*/, int ntok, const float* eps, const float* c, int nc, const float* pe, int nq,
                               float* mem, float* q, float* mu_out, float* logvar_out, int B, hipStream_t s);
+// cond (B,2n,256) = cat[(src_cnt - sm)/ss, (prev - cm)/cs] over tokens; out = x*sd + mean   (test_fullframework.py:446-449)
+hipError_t launch_cvae_condition(const float* src_cnt, const float* sm, const float* ss, const float* prev, const float* cm,
+                                 const float* cs, float* cond, int B, int n, hipStream_t s);
+hipError_t launch_scale_shift(const float* x, const float* mean, const float* sd, float* out, int B, int n, hipStream_t s);
 // bank row squared norms
 hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, hipStream_t s);
 // per query: argmin_n (bnorm[n] - 2*sum_z S[z][q][n]); then exact distance to the winner

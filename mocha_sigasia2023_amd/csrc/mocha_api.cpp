@@ -1107,6 +1107,24 @@ int mocha_cvae_sample(mocha_ctx* c, const float* cond, int B, float* out, float*
     return 0;
 }
 
+int mocha_cvae_condition(mocha_ctx* c, const float* src_cnt, const float* src_mean, const float* src_std, const float* prev_cha,
+                         const float* cha_mean, const float* cha_std, int B, float* cond, void* stream) {
+    if (!c || !src_cnt || !src_mean || !src_std || !prev_cha || !cha_mean || !cha_std || !cond || B < 0) return fail(c, MOCHA_ERR_ARG, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(c, s, "mocha_cvae_condition", "cvae.condition", 0.0, B * 180.0 * 256 * 8,
+           launch_cvae_condition(src_cnt, src_mean, src_std, prev_cha, cha_mean, cha_std, cond, B, 90, s));
+    return 0;
+}
+
+int mocha_scale_shift(mocha_ctx* c, const float* x, const float* mean, const float* std_, int B, float* out, void* stream) {
+    if (!c || !x || !mean || !std_ || !out || B < 0) return fail(c, MOCHA_ERR_ARG, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(c, s, "mocha_scale_shift", "cvae.denorm", 0.0, B * 90.0 * 256 * 8, launch_scale_shift(x, mean, std_, out, B, 90, s));
+    return 0;
+}
+
 // debugging aid (not in the public header): copy a workspace buffer to the host after a device sync
 int mocha_debug_read(mocha_ctx* c, const char* name, float* host, int64_t count) {
     if (!c || !name || !host) return MOCHA_ERR_ARG;

@@ -471,3 +471,42 @@ class CVAE:
         elif eps is None:
             eps = torch.randn((c.shape[0], DIM), dtype=torch.float32, device=self.device)
         return self._run(c, eps)[0]
+
+
+class OursSession:
+    """The demo's CVAE ("Ours") branch, frame by frame and entirely on the device
+    (test_fullframework.py:446-457): condition = cat[z-scored src cnt, z-scored previous character feature]
+    -> CVAE.sample -> de-normalise -> decoder -> to_mot, feeding the sampled feature back.  The CVAE and the
+    Generator live in one context; each frame enqueues ~50 small kernels (skinny GEMMs)."""
+
+    def __init__(self, model: Generator, cvae: "CVAE", src_cnt_mean, src_cnt_std, cha_encoded_mean, cha_encoded_std):
+        if cvae.device != model.device:
+            raise ValueError("CVAE and Generator must be on the same device")
+        self.model, self.cvae = model, cvae
+        d = model.device
+        self.sm = _dev_f32(src_cnt_mean, d, (NTOK, DIM), "src_cnt_mean")
+        self.ss = _dev_f32(src_cnt_std, d, (NTOK, DIM), "src_cnt_std")
+        self.cm = _dev_f32(cha_encoded_mean, d, (NTOK, DIM), "cha_encoded_mean")
+        self.cs = _dev_f32(cha_encoded_std, d, (NTOK, DIM), "cha_encoded_std")
+        self.prev = None
+        self.cond = torch.empty((1, 2 * NTOK, DIM), dtype=torch.float32, device=d)
+
+    def reset(self, first_cha_encoded):
+        """prev_cha_encoded = curr_cha_encoded.clone() of the first frame (test_fullframework.py:436)."""
+        self.prev = _dev_f32(first_cha_encoded, self.model.device, (NTOK, DIM), "cha_encoded").reshape(1, NTOK, DIM).clone()
+        return self
+
+    def step(self, src_encoded, src_cnt, eps=None, deterministic: bool = False):
+        """One frame: returns (trans_Ytil (1,60,V,15), curr_cha_encoded (1,90,256))."""
+        if self.prev is None:
+            raise RuntimeError("call reset(first_cha_encoded) first")
+        m, d = self.model, self.model.device
+        se = _dev_f32(src_encoded, d, (NTOK, DIM), "src_encoded").reshape(1, NTOK, DIM)
+        sc = _dev_f32(src_cnt, d, (NTOK, DIM), "src_cnt").reshape(1, NTOK, DIM)
+        self.cvae._ctx.call("mocha_cvae_condition", _ptr(sc), _ptr(self.sm), _ptr(self.ss), _ptr(self.prev), _ptr(self.cm),
+                            _ptr(self.cs), 1, _ptr(self.cond), _stream())
+        vae = self.cvae.sample(self.cond, deterministic=deterministic, eps=eps)
+        cur = torch.empty_like(vae)
+        self.cvae._ctx.call("mocha_scale_shift", _ptr(vae), _ptr(self.cm), _ptr(self.cs), 1, _ptr(cur), _stream())
+        self.prev = cur
+        return m.to_mot(m.decoder(se, cur)), cur

@@ -51,3 +51,36 @@ def test_cvae_errors():
         CVAE(device="cuda:0").load_state_dict({"prior_net.mu_token": np.zeros((1, 1, 256), np.float32)})
     with pytest.raises(RuntimeError, match="not loaded"):
         CVAE(device="cuda:0").sample(torch.zeros(1, 180, 256))
+
+
+def test_ours_branch_frames_match_oracle():
+    """The demo's CVAE branch for a few frames (test_fullframework.py:446-457) against the same loop on the oracles."""
+    from mocha_sigasia2023_amd import Generator, OursSession
+    from oracle import mocha_oracle as O
+    gsd = weights.synthetic_state_dict(12, 1.2)
+    csd = weights.synthetic_cvae_state_dict(99, 1.0)
+    model = Generator(device="cuda:0").load_state_dict(gsd).eval()
+    net = _model()
+    rng = np.random.Generator(np.random.PCG64(3))
+    stats = [(0.1 * rng.standard_normal((90, 256))).astype(np.float32), rng.uniform(0.5, 1.5, (90, 256)).astype(np.float32),
+             (0.1 * rng.standard_normal((90, 256))).astype(np.float32), rng.uniform(0.5, 1.5, (90, 256)).astype(np.float32)]
+    src = torch.from_numpy(synthetic.pose_windows(40, 4))
+    cha = torch.from_numpy(synthetic.pose_windows(41, 1))
+    tg, tc = O.to_torch_state(gsd), to_torch_state(csd)
+    with torch.no_grad():
+        enc_s, cnt_s = O.encode(tg, src)
+        enc_c, _ = O.encode(tg, cha)
+    sess = OursSession(model, net, *stats).reset(enc_c[0].cuda())
+    prev = enc_c[:1].clone()
+    sm, ss, cm, cs = (torch.from_numpy(a) for a in stats)
+    for i in range(1, 4):
+        eps = torch.from_numpy(synthetic.token_features(900 + i, 1)[0, :1].copy())
+        with torch.no_grad():
+            cond = torch.cat([(cnt_s[i:i + 1] - sm) / ss, (prev - cm) / cs], dim=1)
+            vae, _, _ = CO.sample(tc, cond, eps)
+            cur = vae * cs + cm
+            Yo = O.to_mot(tg, O.decoder(tg, enc_s[i:i + 1], cur))
+            prev = cur
+        Y, gcur = sess.step(enc_s[i].cuda(), cnt_s[i].cuda(), eps=eps.cuda())
+        assert float((gcur.cpu() - cur).abs().max()) < 1e-4 * max(1.0, float(cur.abs().max())) * i
+        assert float((Y.cpu() - Yo).abs().max()) < 1e-4 * max(1.0, float(Yo.abs().max())) * i
