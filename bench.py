@@ -51,6 +51,23 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic_for(kernel_name):
+    """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (separate
+    --pmc FETCH_SIZE / WRITE_SIZE passes, read side x2 on gfx950; tools/pmc_traffic.sh).  None if absent."""
+    import glob, re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_traffic_summary.txt")))
+    if not files:
+        return None, None
+    key = re.sub(r"[ ,]", "", kernel_name.split("<")[0] + "<" + kernel_name.split("<")[1]) if "<" in kernel_name else kernel_name
+    for line in open(files[-1]):
+        flat = re.sub(r"[ ,]", "", line)
+        if key in flat:
+            m = re.search(r"\)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
+            if m:
+                return (float(m.group(2)) + float(m.group(3))) * 1e6, os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def cpu_baseline(sd, V, n, mean, std):
     """The oracle (CPU restatement of the reference path, same op sequence on torch CPU) timed on a
     bounded sample of the same workload: n source + n character windows through the same step."""
@@ -198,9 +215,11 @@ def main():
         d = kern[dom]
         total_ms = sum(k["ms"] for k in kern.values())
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        traffic, traffic_src = pmc_traffic_for(dom)
         roofline = {
             "kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
             "launches_per_step": d["launches"] // 3, "avg_launch_us": d["ms"] / d["launches"] * 1e3,
             "algorithmic_flops_per_launch": d["flops"] / d["launches"],
             "share_of_step_kernel_time": d["ms"] / total_ms,
