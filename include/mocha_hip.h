@@ -142,6 +142,14 @@ int mocha_cvae_condition(mocha_ctx* ctx, const float* src_cnt, const float* src_
                          const float* cha_mean, const float* cha_std, int B, float* cond, void* stream);
 int mocha_scale_shift(mocha_ctx* ctx, const float* x, const float* mean, const float* std_, int B, float* out, void* stream);
 
+/* Window featurisation of the demo (test_fullframework.py:141-185): local bone features
+ * of B windows — Yrot (B,T,V+1,4) quaternions (w,x,y,z), Ypos / Yvel / Yang (B,T,V+1,3), root bone first, as
+ * process_data produces them (:126-139) — to the un-normalised features X_raw (B,T,V+1,15) that the *_raw
+ * entry points consume: FK with velocities, re-rooting on each window's last frame, root-relative
+ * position | rotation-matrix xy | velocity | angular velocity. */
+int mocha_featurize(mocha_ctx* ctx, const float* Yrot, const float* Ypos, const float* Yvel, const float* Yang, int B,
+                    float* X_raw, void* stream);
+
 /* Introspection for tests and tooling. */
 int mocha_abi_version(void);
 int mocha_graph_constants(mocha_ctx* ctx, float* A_j /*3*V*V host*/, float* A_b /*2*6*6 host*/,

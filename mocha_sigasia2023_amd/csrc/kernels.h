@@ -96,6 +96,10 @@ hipError_t launch_cvae_latent(const float* x /*B,ntok,256*/, int ntok, const flo
 hipError_t launch_cvae_condition(const float* src_cnt, const float* sm, const float* ss, const float* prev, const float* cm,
                                  const float* cs, float* cond, int B, int n, hipStream_t s);
 hipError_t launch_scale_shift(const float* x, const float* mean, const float* sd, float* out, int B, int n, hipStream_t s);
+// demo featurisation (featurize.hip): local bone features of B windows -> X (B,T,J,15) un-normalised, root bone included
+hipError_t featurize_init();
+hipError_t launch_featurize(const float* Yrot, const float* Ypos, const float* Yvel, const float* Yang, const int* parents /*J, device*/,
+                            float* X, int B, int T, int J, hipStream_t s);
 // bank row squared norms
 hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, hipStream_t s);
 // per query: argmin_n (bnorm[n] - 2*sum_z S[z][q][n]); then exact distance to the winner

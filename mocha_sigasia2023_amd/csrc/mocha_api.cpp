@@ -128,6 +128,7 @@ struct mocha_ctx {
     bool cvae_ready = false;
     int cvae_depth = 2, cvae_heads = 4, cvae_nc = 180, cvae_nq = 90;
     std::map<std::string, DevBuf> cws; int cvae_B = 0;
+    int* bone_parents = nullptr;       // device: parents of the (V+1)-bone skeleton with the root bone in front
     float* pose_norm = nullptr;        // [x_mean | x_std | y_mean | y_std], (V+1)*C_in each (norm.npz of the reference)
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
     unsigned long long* best_ws = nullptr; size_t best_ws_n = 0;
@@ -561,6 +562,7 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = gemm_init();
     if (e == hipSuccess) e = gemm_split_init();
+    if (e == hipSuccess) e = featurize_init();
     if (e != hipSuccess) { delete c; return fail(nullptr, MOCHA_ERR_HIP, "device %d init failed: %s", device, hipGetErrorString(e)); }
     *out = c;
     return 0;
@@ -573,6 +575,7 @@ void mocha_destroy(mocha_ctx* c) {
     if (c->idx_ws) (void)hipFree(c->idx_ws);
     if (c->bank_bf16) (void)hipFree(c->bank_bf16);
     if (c->best_ws) (void)hipFree(c->best_ws);
+    if (c->bone_parents) (void)hipFree(c->bone_parents);
     delete c;
 }
 
@@ -1122,6 +1125,26 @@ int mocha_scale_shift(mocha_ctx* c, const float* x, const float* mean, const flo
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     LAUNCH(c, s, "mocha_scale_shift", "cvae.denorm", 0.0, B * 90.0 * 256 * 8, launch_scale_shift(x, mean, std_, out, B, 90, s));
+    return 0;
+}
+
+int mocha_featurize(mocha_ctx* c, const float* Yrot, const float* Ypos, const float* Yvel, const float* Yang, int B, float* X_raw,
+                    void* stream) {
+    if (!c || !Yrot || !Ypos || !Yvel || !Yang || !X_raw || B < 0) return fail(c, MOCHA_ERR_ARG, "bad featurize arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int J = c->cfg.V + 1;
+    if (!c->bone_parents) {                       // parents = [-1] + (joint parents + 1), test_fullframework.py:101-102
+        std::vector<int> par(J);
+        par[0] = -1;
+        for (int i = 0; i < c->cfg.V; ++i) par[i + 1] = c->sk.parents[i] + 1;
+        void* dp = nullptr;
+        HIPCHK(c, hipMalloc(&dp, sizeof(int) * J));
+        HIPCHK(c, hipMemcpy(dp, par.data(), sizeof(int) * J, hipMemcpyHostToDevice));
+        c->bone_parents = (int*)dp;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(c, s, "mocha_featurize", "featurize", B * 60.0 * J * 150, B * 60.0 * J * (13 + 15) * 4,
+           launch_featurize(Yrot, Ypos, Yvel, Yang, c->bone_parents, X_raw, B, c->cfg.T, J, s));
     return 0;
 }
 

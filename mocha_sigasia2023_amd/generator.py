@@ -271,6 +271,20 @@ class Generator:
         self._has_pose_norm = True
         return self
 
+    def featurize(self, Yrot, Ypos, Yvel, Yang):
+        """The demo's featurisation on the device (test_fullframework.py:141-185): local bone features of B
+        windows, root bone first — Yrot (B,T,V+1,4) (w,x,y,z), Ypos/Yvel/Yang (B,T,V+1,3) — to the
+        un-normalised X (B,T,V+1,15) that ``encode(..., raw=True)`` / ``characterize(..., raw=True)`` take."""
+        T, J = self.cfg["nframes"], self.V + 1
+        r = _dev_f32(Yrot, self.device, (T, J, 4), "Yrot")
+        ps = [_dev_f32(a, self.device, (T, J, 3), n) for a, n in ((Ypos, "Ypos"), (Yvel, "Yvel"), (Yang, "Yang"))]
+        B = r.shape[0]
+        if any(p.shape[0] != B for p in ps):
+            raise ValueError("featurize: batch sizes differ")
+        X = torch.empty((B, T, J, self.cfg["mot_in_dim"]), dtype=torch.float32, device=self.device)
+        self._ctx.call("mocha_featurize", _ptr(r), _ptr(ps[0]), _ptr(ps[1]), _ptr(ps[2]), B, _ptr(X), _stream())
+        return X
+
     def _xraw(self, X, name):
         return _dev_f32(X, self.device, (self.cfg["nframes"], self.V + 1, self.cfg["mot_in_dim"]), name)
 

@@ -39,3 +39,16 @@ def cnt_norm(seed: int, ntok: int = 90, dim: int = 256):
     mean = (0.1 * r.standard_normal((ntok, dim))).astype(np.float32)
     std = r.uniform(0.5, 1.5, size=(ntok, dim)).astype(np.float32)
     return mean, (std / temporal_weight(ntok // 6, 6, dim)).astype(np.float32)
+
+
+def bone_windows(seed: int, B: int, J: int = 25, T: int = 60):
+    """Synthetic local bone features of B windows, the inputs of the demo's featurisation
+    (test_fullframework.py:135-139): unit quaternions, offsets, linear and angular velocities, float32."""
+    r = _rng(seed)
+    q = r.standard_normal((B, T, J, 4)).astype(np.float32)
+    q /= np.sqrt((q * q).sum(-1, keepdims=True))
+    q = np.where(q[..., :1] > 0, q, -q).astype(np.float32)
+    pos = (0.3 * r.standard_normal((B, T, J, 3))).astype(np.float32)
+    vel = r.standard_normal((B, T, J, 3)).astype(np.float32)
+    ang = r.standard_normal((B, T, J, 3)).astype(np.float32)
+    return q, pos, vel, ang

@@ -164,6 +164,31 @@ def run_cvae():
     print("cvae", {k: float(np.abs(v).max()) for k, v in dict(mu=mu.numpy(), logvar=logvar.numpy(), out=out.numpy()).items()})
 
 
+def run_featurize():
+    """test_fullframework.py:141-185 executed with the reference's own quaternion library (motion/quat.py)
+    on synthetic local bone features; only the X features are stored."""
+    sys.path.insert(0, os.path.join(REF, "motion"))
+    import quat                                           # the reference's motion/quat.py
+    from mocha_sigasia2023_amd.skeleton import LAYOUTS
+    parents = np.concatenate([[-1], np.asarray(LAYOUTS["mocha"]["parents"]) + 1])   # :101-102
+    window = 60
+    Yrot, Ypos, Yvel, Yang = synthetic.bone_windows(321, 3)
+    Grot, Gpos, Gvel, Gang = quat.fk_vel(Yrot, Ypos, Yvel, Yang, parents)
+    Gpos[:, :, 0:1] = np.repeat(Gpos[:, -1:, 0:1], window, axis=1)
+    Grot[:, :, 0:1] = np.repeat(Grot[:, -1:, 0:1], window, axis=1)
+    Gvel[:, :, 0:1] = np.repeat(Gvel[:, -1:, 0:1], window, axis=1)
+    Gang[:, :, 0:1] = np.repeat(Gang[:, -1:, 0:1], window, axis=1)
+    Xpos = quat.inv_mul_vec(Grot[:, :, 0:1], Gpos - Gpos[:, :, 0:1])
+    Xrot = quat.inv_mul(Grot[:, :, 0:1], Grot)
+    Xtxy = quat.to_xform_xy(Xrot).astype(np.float32)
+    Xvel = quat.inv_mul_vec(Grot[:, :, 0:1], Gvel)
+    Xang = quat.inv_mul_vec(Grot[:, :, 0:1], Gang)
+    b, ns, nj, _, _ = Xtxy.shape
+    X = np.concatenate([Xpos, Xtxy.reshape(b, ns, nj, -1), Xvel, Xang], axis=-1)
+    np.savez(os.path.join(HERE, "featurize.npz"), X=X.astype(np.float32), seed=np.array([321, 3]))
+    print("featurize", X.shape, X.dtype, float(np.abs(X).max()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     run_graph_constants()
@@ -172,3 +197,4 @@ if __name__ == "__main__":
     run_variant("mixamo22_g1", "mixamo", seed=2222, gain=1.0, B=1)
     run_match()
     run_cvae()
+    run_featurize()
