@@ -95,7 +95,7 @@ def bank4k(a):
     rank, local, world = D.env_rank()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or os.environ.get("MOCHA_FORCE_DIST"):
         D.init("nccl", dev)
     V, NB, W = a.joints, 4096, 1024
     layout = "mocha" if V == 24 else "mixamo"
@@ -135,7 +135,7 @@ def bank4k(a):
             "config": {"workload": f"BASELINE configs[2]/[3]: 1024 windows x 4096-entry bank (bf16 cnt), V={V}, {W // world} windows per GPU",
                        "parallelism": f"dp{world}, bank broadcast from rank 0"},
             "bank_broadcast_ms": bcast_ms, "bank_bytes": bank_nm.numel() * 4 + bank_enc.numel() * 4}), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():
         D.barrier(); torch.distributed.destroy_process_group()
 
 
@@ -145,7 +145,7 @@ def main():
         return bank4k(a)
     from mocha_sigasia2023_amd import distributed as D
     rank, local, world = D.env_rank()
-    dist_on = world > 1
+    dist_on = world > 1 or bool(os.environ.get("MOCHA_FORCE_DIST"))      # the env knob runs the RCCL plumbing with one rank
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local)

@@ -44,7 +44,7 @@ def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
 
 def broadcast_(tensors: Iterable[torch.Tensor], src: int = 0) -> None:
     """In-place broadcast of the bank tensors (cnt_nm, encoded, cnt norm, or the raw character clip)."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         for t in tensors:
             dist.broadcast(t, src=src)
 
@@ -67,7 +67,7 @@ def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
 
 
 def max_over_ranks(value: float, device: torch.device) -> float:
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -75,5 +75,5 @@ def max_over_ranks(value: float, device: torch.device) -> float:
 
 
 def barrier() -> None:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
