@@ -150,6 +150,12 @@ int mocha_scale_shift(mocha_ctx* ctx, const float* x, const float* mean, const f
 int mocha_featurize(mocha_ctx* ctx, const float* Yrot, const float* Ypos, const float* Yvel, const float* Yang, int B,
                     float* X_raw, void* stream);
 
+/* Runtime options.  "dual_stream" (default 0): batches of at least "dual_min" (default 128) windows are split in two
+ * halves that run concurrently on the caller's stream and on an internal stream (forked / joined with events, so
+ * the call keeps stream semantics and stays graph-capturable); the two kernel chains fill each other's prologue /
+ * epilogue / tail bubbles (+5 % on the demo step).  Results are unchanged except for the kernel choice per half. */
+int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
+
 /* Introspection for tests and tooling. */
 int mocha_abi_version(void);
 int mocha_graph_constants(mocha_ctx* ctx, float* A_j /*3*V*V host*/, float* A_b /*2*6*6 host*/,

@@ -111,9 +111,15 @@ struct mocha_ctx {
     // workspaces: sized for `chunk` windows; larger batches are processed chunk by chunk
     int chunk = 0;
     int max_chunk = 1024;
-    std::map<std::string, DevBuf> ws;
-    DevBuf match_S;
-    int32_t* idx_ws = nullptr; size_t idx_ws_n = 0;
+    // Two workspace sets: large batches are split in two halves that run on two HIP streams (the caller's and
+    // `aux`), so that the prologue / epilogue / tail of one half's kernels overlaps the other half's MFMA phases
+    // (+5..10 % measured); `cur` selects the set the pipelines below write to.
+    std::map<std::string, DevBuf> wss[2];
+    int cur = 0;
+    bool dual_stream = false; int dual_min = 128;     // opt-in: mocha_set_option(ctx, "dual_stream", 1) or MOCHA_DUAL_STREAM=1
+    hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DevBuf match_S[2];
+    int32_t* idx_ws[2] = {nullptr, nullptr}; size_t idx_ws_n = 0;
 
     // bank
     const float* bank_cnt = nullptr;
@@ -131,7 +137,7 @@ struct mocha_ctx {
     int* bone_parents = nullptr;       // device: parents of the (V+1)-bone skeleton with the root bone in front
     float* pose_norm = nullptr;        // [x_mean | x_std | y_mean | y_std], (V+1)*C_in each (norm.npz of the reference)
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
-    unsigned long long* best_ws = nullptr; size_t best_ws_n = 0;
+    unsigned long long* best_ws[2] = {nullptr, nullptr}; size_t best_ws_n[2] = {0, 0};
 
     // per-launch HIP-event profiling (mocha_profile_start/stop); off in normal operation
     struct ProfRec { std::string kernel, site; hipEvent_t e0, e1; double flops, bytes; };
@@ -279,29 +285,35 @@ int ensure_ws(mocha_ctx* c, int B) {
         {"smean", 256}, {"s1", 512}, {"gb", 512}, {"g", 90 * 192}, {"y2c", (size_t)15 * V * 64},
         {"z", (size_t)60 * V * 64}, {"enc_s", T}, {"enc_c", T}, {"cnt", T}, {"qnm", T}, {"sel", T}, {"dec", T},
     };
-    // free old workspace
-    for (auto& kv : c->ws) {
-        if (kv.second.p) {
-            (void)hipFree(kv.second.p);
-            c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), kv.second.p), c->owned.end());
+    // free old workspaces
+    for (int set = 0; set < 2; ++set) {
+        for (auto& kv : c->wss[set]) {
+            if (kv.second.p) {
+                (void)hipFree(kv.second.p);
+                c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), kv.second.p), c->owned.end());
+            }
         }
+        c->wss[set].clear();
+        if (c->idx_ws[set]) { (void)hipFree(c->idx_ws[set]); c->idx_ws[set] = nullptr; }
     }
-    c->ws.clear();
-    for (auto& pl : plan) {
-        DevBuf b; b.n = pl.second * (size_t)want;
-        int rc = dev_alloc(c, &b.p, b.n);
-        if (rc) return rc;
-        c->ws[pl.first] = b;
+    const int nsets = (c->dual_stream && want >= c->dual_min / 2) ? 2 : 1;
+    for (int set = 0; set < nsets; ++set) {
+        for (auto& pl : plan) {
+            DevBuf b; b.n = pl.second * (size_t)want;
+            int rc = dev_alloc(c, &b.p, b.n);
+            if (rc) return rc;
+            c->wss[set][pl.first] = b;
+        }
+        void* ip = nullptr;
+        HIPCHK(c, hipMalloc(&ip, sizeof(int32_t) * (size_t)want));
+        c->idx_ws[set] = (int32_t*)ip;
     }
-    if (c->idx_ws) (void)hipFree(c->idx_ws);
-    void* ip = nullptr;
-    HIPCHK(c, hipMalloc(&ip, sizeof(int32_t) * (size_t)want));
-    c->idx_ws = (int32_t*)ip; c->idx_ws_n = want;
+    c->idx_ws_n = want;
     c->chunk = want;
     return 0;
 }
 
-float* WS(mocha_ctx* c, const char* n) { return c->ws.at(n).p; }
+float* WS(mocha_ctx* c, const char* n) { return c->wss[c->cur].at(n).p; }
 float* DW(mocha_ctx* c, const std::string& n) { return c->w.at(n); }
 
 // Every kernel launch goes through LAUNCH: error check, and when profiling is on a HIP event
@@ -475,6 +487,31 @@ int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s
     return 0;
 }
 
+// Run fn(b0, b, stream) over the batch.  Small batches: chunk by chunk on the caller's stream.  Large ones: the two
+// halves of the batch go to the caller's stream and to `aux` (forked / joined with events, capture-safe), each with its
+// own workspace set, so two independent kernel chains are in flight and fill each other's bubbles.
+template <class F>
+int for_chunks(mocha_ctx* c, int B, hipStream_t s, F&& fn) {
+    const bool dual = c->dual_stream && B >= c->dual_min && !c->wss[1].empty();
+    if (!dual) {
+        c->cur = 0;
+        for (int b0 = 0; b0 < B; b0 += c->chunk) { int rc = fn(b0, std::min(c->chunk, B - b0), s); if (rc) return rc; }
+        return 0;
+    }
+    HIPCHK(c, hipEventRecord(c->ev_fork, s));
+    HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    const int h = (B + 1) / 2;
+    int rc = 0;
+    c->cur = 0;
+    for (int b0 = 0; b0 < h && !rc; b0 += c->chunk) rc = fn(b0, std::min(c->chunk, h - b0), s);
+    c->cur = 1;
+    for (int b0 = h; b0 < B && !rc; b0 += c->chunk) rc = fn(b0, std::min(c->chunk, B - b0), c->aux);
+    c->cur = 0;
+    HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
+    HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
+    return rc;
+}
+
 int ready(mocha_ctx* c, int B) {
     if (!c) return MOCHA_ERR_ARG;
     if (!c->finalized) return fail(c, MOCHA_ERR_STATE, "weights not finalised: call mocha_finalize_weights first");
@@ -491,31 +528,34 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     // Few queries (streaming, one per frame) or a bf16 bank: HBM-bound bank scan, bank read once per
     // 8 queries.  Many queries against an fp32 bank: MFMA GEMM Q.Bank^T + arg-min.
     if (Q <= 8) {
+        const int set = c->cur;
         const size_t need_ws = match_stream_scratch(Q, N);
-        if (c->best_ws_n < need_ws) {
-            if (c->best_ws) (void)hipFree(c->best_ws);
+        if (c->best_ws_n[set] < need_ws) {
+            if (c->best_ws[set]) (void)hipFree(c->best_ws[set]);
             void* bp = nullptr;
             HIPCHK(c, hipMalloc(&bp, sizeof(unsigned long long) * need_ws));
-            c->best_ws = (unsigned long long*)bp; c->best_ws_n = need_ws;
+            c->best_ws[set] = (unsigned long long*)bp; c->best_ws_n[set] = need_ws;
         }
         const void* bank = c->bank_is_bf16 ? (const void*)c->bank_bf16 : (const void*)c->bank_cnt;
         const double passes = (Q + 7) / 8;
         LAUNCH(c, s, c->bank_is_bf16 ? "mocha_match_stream<bf16>" : "mocha_match_stream<f32>", "match.stream", 2.0 * Q * N * D,
                passes * N * D * (c->bank_is_bf16 ? 2.0 : 4.0) + 4.0 * Q * D,
-               launch_match_stream(bank, c->bank_is_bf16 ? 1 : 0, c->bank_norm, qnm, Q, N, D, c->best_ws, idx, dist, s));
+               launch_match_stream(bank, c->bank_is_bf16 ? 1 : 0, c->bank_norm, qnm, Q, N, D, c->best_ws[set], idx, dist, s));
         return 0;
     }
     const long long tiles = (long long)((Q + 127) / 128) * ((N + 127) / 128);
     int ksplit = (int)std::min<long long>(16, std::max<long long>(1, (768 + tiles - 1) / tiles));
     const size_t need = (size_t)ksplit * Q * N;
-    if (c->match_S.n < need) {
-        if (c->match_S.p) { (void)hipFree(c->match_S.p); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), c->match_S.p), c->owned.end()); }
-        c->match_S = DevBuf{};
-        int rc = dev_alloc(c, &c->match_S.p, need);
+    DevBuf& mS = c->match_S[c->cur];
+    if (mS.n < need) {
+        HIPCHK(c, hipDeviceSynchronize());
+        if (mS.p) { (void)hipFree(mS.p); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), mS.p), c->owned.end()); }
+        mS = DevBuf{};
+        int rc = dev_alloc(c, &mS.p, need);
         if (rc) return rc;
-        c->match_S.n = need;
+        mS.n = need;
     }
-    GemmParams g = plain(qnm, D, c->bank_cnt, c->match_S.p, (int)N, Q, (int)N, D);
+    GemmParams g = plain(qnm, D, c->bank_cnt, mS.p, (int)N, Q, (int)N, D);
     g.ksplit = ksplit; g.slab_stride = (long long)Q * N;
     if (c->bank_is_bf16) {
         // bf16 bank: exact fp32 queries (three bf16 planes) against the rounded bank on the bf16 matrix pipe
@@ -526,7 +566,7 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
         GEMM(c, s, "match.qk", g);
     }
     LAUNCH(c, s, "mocha_argmin", "match.argmin", 0.0, (double)ksplit * Q * N * 4,
-           launch_argmin(c->match_S.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_cnt, c->bank_is_bf16 ? c->bank_bf16 : nullptr,
+           launch_argmin(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_cnt, c->bank_is_bf16 ? c->bank_bf16 : nullptr,
                          Q, N, D, idx, dist, s));
     return 0;
 }
@@ -563,6 +603,10 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     if (e == hipSuccess) e = gemm_init();
     if (e == hipSuccess) e = gemm_split_init();
     if (e == hipSuccess) e = featurize_init();
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    if (getenv("MOCHA_DUAL_STREAM")) c->dual_stream = atoi(getenv("MOCHA_DUAL_STREAM")) != 0;
     if (e != hipSuccess) { delete c; return fail(nullptr, MOCHA_ERR_HIP, "device %d init failed: %s", device, hipGetErrorString(e)); }
     *out = c;
     return 0;
@@ -572,9 +616,11 @@ void mocha_destroy(mocha_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (float* p : c->owned) (void)hipFree(p);
-    if (c->idx_ws) (void)hipFree(c->idx_ws);
+    for (int set = 0; set < 2; ++set) { if (c->idx_ws[set]) (void)hipFree(c->idx_ws[set]); if (c->best_ws[set]) (void)hipFree(c->best_ws[set]); }
     if (c->bank_bf16) (void)hipFree(c->bank_bf16);
-    if (c->best_ws) (void)hipFree(c->best_ws);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->bone_parents) (void)hipFree(c->bone_parents);
     delete c;
 }
@@ -717,23 +763,17 @@ int mocha_graph_constants(mocha_ctx* c, float* A_j, float* A_b, float* pool, flo
 int mocha_embed(mocha_ctx* c, const float* X, int B, float* tokens, int add_pos, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
     const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in, ts = 90 * 256;
-    for (int b0 = 0; b0 < B; b0 += c->chunk) {
-        const int b = std::min(c->chunk, B - b0);
-        rc = run_embed(c, X + b0 * xs, b, tokens + b0 * ts, add_pos != 0, (hipStream_t)stream);
-        if (rc) return rc;
-    }
-    return 0;
+    return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
+        return run_embed(c, X + b0 * xs, b, tokens + b0 * ts, add_pos != 0, s);
+    });
 }
 
 int mocha_encoder(mocha_ctx* c, const float* tokens, int B, float* encoded, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
     const size_t ts = 90 * 256;
-    for (int b0 = 0; b0 < B; b0 += c->chunk) {
-        const int b = std::min(c->chunk, B - b0);
-        rc = run_encoder(c, tokens + b0 * ts, b, encoded + b0 * ts, (hipStream_t)stream);
-        if (rc) return rc;
-    }
-    return 0;
+    return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
+        return run_encoder(c, tokens + b0 * ts, b, encoded + b0 * ts, s);
+    });
 }
 
 int mocha_mvn(mocha_ctx* c, const float* encoded, int B, float* cnt, const float* cnt_mean, const float* cnt_std,
@@ -750,59 +790,48 @@ int mocha_mvn(mocha_ctx* c, const float* encoded, int B, float* cnt, const float
 int mocha_encode(mocha_ctx* c, const float* X, int B, float* encoded, float* cnt, const float* cnt_mean,
                  const float* cnt_std, float* cnt_nm, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
     const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in, ts = 90 * 256;
     const bool zn = cnt && cnt_nm && cnt_mean && cnt_std;
-    for (int b0 = 0; b0 < B; b0 += c->chunk) {
-        const int b = std::min(c->chunk, B - b0);
-        rc = run_embed(c, X + b0 * xs, b, WS(c, "x5"), true, s);      // x5 is free again once the body block has read it
-        if (rc) return rc;
-        rc = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s);
-        if (rc) return rc;
+    return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
+        int r = run_embed(c, X + b0 * xs, b, WS(c, "x5"), true, s);      // x5 is free again once the body block has read it
+        if (r) return r;
+        if ((r = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s))) return r;
         if (cnt)
             LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (zn ? 3 : 2),
                    launch_instnorm(encoded + b0 * ts, cnt + b0 * ts, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
                                    zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
-    }
-    return 0;
+        return 0;
+    });
 }
 
 int mocha_decoder(mocha_ctx* c, const float* src_enc, const float* cha_enc, int B, float* out, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
     const size_t ts = 90 * 256;
-    for (int b0 = 0; b0 < B; b0 += c->chunk) {
-        const int b = std::min(c->chunk, B - b0);
-        rc = run_decoder(c, src_enc + b0 * ts, cha_enc + b0 * ts, b, out + b0 * ts, (hipStream_t)stream);
-        if (rc) return rc;
-    }
-    return 0;
+    return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
+        return run_decoder(c, src_enc + b0 * ts, cha_enc + b0 * ts, b, out + b0 * ts, s);
+    });
 }
 
 int mocha_to_mot(mocha_ctx* c, const float* tokens, int B, float* Y, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
     const size_t ts = 90 * 256, ys = (size_t)60 * c->cfg.V * c->cfg.C_in;
-    for (int b0 = 0; b0 < B; b0 += c->chunk) {
-        const int b = std::min(c->chunk, B - b0);
-        rc = run_to_mot(c, tokens + b0 * ts, b, Y + b0 * ys, (hipStream_t)stream);
-        if (rc) return rc;
-    }
-    return 0;
+    return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
+        return run_to_mot(c, tokens + b0 * ts, b, Y + b0 * ys, s);
+    });
 }
 
 int mocha_forward(mocha_ctx* c, const float* src_X, const float* cha_X, int B, float* Y, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
     const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in;
-    for (int b0 = 0; b0 < B; b0 += c->chunk) {
-        const int b = std::min(c->chunk, B - b0);
-        if ((rc = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s))) return rc;
-        if ((rc = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return rc;
-        if ((rc = run_embed(c, cha_X + b0 * xs, b, WS(c, "x5"), true, s))) return rc;
-        if ((rc = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_c"), s))) return rc;
-        if ((rc = run_decoder(c, WS(c, "enc_s"), WS(c, "enc_c"), b, WS(c, "dec"), s))) return rc;
-        if ((rc = run_to_mot(c, WS(c, "dec"), b, Y + b0 * xs, s))) return rc;
-    }
-    return 0;
+    return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
+        int r;
+        if ((r = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s))) return r;
+        if ((r = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return r;
+        if ((r = run_embed(c, cha_X + b0 * xs, b, WS(c, "x5"), true, s))) return r;
+        if ((r = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_c"), s))) return r;
+        if ((r = run_decoder(c, WS(c, "enc_s"), WS(c, "enc_c"), b, WS(c, "dec"), s))) return r;
+        return run_to_mot(c, WS(c, "dec"), b, Y + b0 * xs, s);
+    });
 }
 
 int mocha_forward_features(mocha_ctx* c, const float* src_X, const float* cha_X, int B, float* src_enc, float* cha_enc,
@@ -839,12 +868,13 @@ int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int6
     c->bank_N = N;
     {                                                     // scratch of the streaming matcher for up to 8 queries
         const size_t need_ws = match_stream_scratch(8, N);  // (allocated here so a later single-query step is capture-safe)
-        if (c->best_ws_n < need_ws) {
-            if (c->best_ws) (void)hipFree(c->best_ws);
-            void* bp = nullptr;
-            HIPCHK(c, hipMalloc(&bp, sizeof(unsigned long long) * need_ws));
-            c->best_ws = (unsigned long long*)bp; c->best_ws_n = need_ws;
-        }
+        for (int set = 0; set < 2; ++set)
+            if (c->best_ws_n[set] < need_ws) {
+                if (c->best_ws[set]) (void)hipFree(c->best_ws[set]);
+                void* bp = nullptr;
+                HIPCHK(c, hipMalloc(&bp, sizeof(unsigned long long) * need_ws));
+                c->best_ws[set] = (unsigned long long*)bp; c->best_ws_n[set] = need_ws;
+            }
     }
     c->bank_is_bf16 = (flags & MOCHA_BANK_BF16) != 0;
     if (c->bank_is_bf16) {
@@ -883,21 +913,19 @@ static int characterize_impl(mocha_ctx* c, const float* src_X, int B, const floa
     int rc = ready(c, B); if (rc) return rc;
     if (!c->bank_cnt) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
     if (!cnt_mean || !cnt_std || !src_X || !Y) return fail(c, MOCHA_ERR_ARG, "null argument");
-    hipStream_t s = (hipStream_t)stream;
     const size_t ys = (size_t)60 * c->cfg.V * c->cfg.C_in;
     const size_t xs = raw ? (size_t)60 * (c->cfg.V + 1) * c->cfg.C_in : ys;
-    for (int b0 = 0; b0 < B; b0 += c->chunk) {
-        const int b = std::min(c->chunk, B - b0);
-        int32_t* ix = idx ? idx + b0 : c->idx_ws;
-        if ((rc = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s, raw))) return rc;
-        if ((rc = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return rc;
+    return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
+        int r;
+        int32_t* ix = idx ? idx + b0 : c->idx_ws[c->cur];
+        if ((r = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s, raw))) return r;
+        if ((r = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return r;
         LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * 3, launch_instnorm(WS(c, "enc_s"), WS(c, "cnt"), nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s));
-        if ((rc = do_match(c, WS(c, "qnm"), b, ix, nullptr, s))) return rc;
+        if ((r = do_match(c, WS(c, "qnm"), b, ix, nullptr, s))) return r;
         LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, b * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), b, 90 * 256, s));
-        if ((rc = run_decoder(c, WS(c, "enc_s"), WS(c, "sel"), b, WS(c, "dec"), s))) return rc;
-        if ((rc = run_to_mot(c, WS(c, "dec"), b, Y + b0 * ys, s, raw))) return rc;
-    }
-    return 0;
+        if ((r = run_decoder(c, WS(c, "enc_s"), WS(c, "sel"), b, WS(c, "dec"), s))) return r;
+        return run_to_mot(c, WS(c, "dec"), b, Y + b0 * ys, s, raw);
+    });
 }
 
 int mocha_characterize(mocha_ctx* c, const float* src_X, int B, const float* cnt_mean, const float* cnt_std, float* Y,
@@ -925,19 +953,18 @@ int mocha_set_pose_norm(mocha_ctx* c, const float* x_mean, const float* x_std, c
 int mocha_encode_raw(mocha_ctx* c, const float* X_raw, int B, float* encoded, float* cnt, const float* cnt_mean,
                      const float* cnt_std, float* cnt_nm, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
     const size_t xs = (size_t)60 * (c->cfg.V + 1) * c->cfg.C_in, ts = 90 * 256;
     const bool zn = cnt && cnt_nm && cnt_mean && cnt_std;
-    for (int b0 = 0; b0 < B; b0 += c->chunk) {
-        const int b = std::min(c->chunk, B - b0);
-        if ((rc = run_embed(c, X_raw + b0 * xs, b, WS(c, "x5"), true, s, true))) return rc;
-        if ((rc = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s))) return rc;
+    return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
+        int r;
+        if ((r = run_embed(c, X_raw + b0 * xs, b, WS(c, "x5"), true, s, true))) return r;
+        if ((r = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s))) return r;
         if (cnt)
             LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (zn ? 3 : 2),
                    launch_instnorm(encoded + b0 * ts, cnt + b0 * ts, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
                                    zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
-    }
-    return 0;
+        return 0;
+    });
 }
 
 // ------------------------------------------------------------------------------------------- CVAE sampler
@@ -1148,6 +1175,20 @@ int mocha_featurize(mocha_ctx* c, const float* Yrot, const float* Ypos, const fl
     return 0;
 }
 
+int mocha_set_option(mocha_ctx* c, const char* name, int value) {
+    if (!c || !name) return MOCHA_ERR_ARG;
+    const std::string n(name);
+    if (n == "dual_stream") {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipDeviceSynchronize());
+        c->dual_stream = value != 0;
+        c->chunk = 0;                              // workspaces are re-planned (one or two sets) on the next call
+        return 0;
+    }
+    if (n == "dual_min") { c->dual_min = value < 2 ? 2 : value; return 0; }
+    return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);
+}
+
 // debugging aid (not in the public header): copy a workspace buffer to the host after a device sync
 int mocha_debug_read(mocha_ctx* c, const char* name, float* host, int64_t count) {
     if (!c || !name || !host) return MOCHA_ERR_ARG;
@@ -1156,7 +1197,7 @@ int mocha_debug_read(mocha_ctx* c, const char* name, float* host, int64_t count)
     const std::string n(name);
     const DevBuf* b = nullptr;
     if (n.rfind("cvae.", 0) == 0 && c->cws.count(n.substr(5))) b = &c->cws.at(n.substr(5));
-    else if (c->ws.count(n)) b = &c->ws.at(n);
+    else if (c->wss[0].count(n)) b = &c->wss[0].at(n);
     if (!b || (size_t)count > b->n) return fail(c, MOCHA_ERR_ARG, "no such buffer or too many elements");
     HIPCHK(c, hipMemcpy(host, b->p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
     return 0;

@@ -185,6 +185,11 @@ class Generator:
         self._reserved = int(max_batch)
         return self
 
+    def set_option(self, name: str, value: int):
+        """Runtime options of the context, e.g. ``set_option("dual_stream", 1)`` (see include/mocha_hip.h)."""
+        self._ctx.call("mocha_set_option", name.encode(), int(value))
+        return self
+
     # ---- measurement support -----------------------------------------------------------
     def profile_start(self):
         """Bracket every kernel launch with HIP events until ``profile_stop`` (bench.py)."""

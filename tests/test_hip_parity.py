@@ -262,3 +262,23 @@ def test_fused_pose_normalisation():
     assert absmax(Y, Yo) < TOL * max(1.0, np.abs(Yo).max())
     with pytest.raises(RuntimeError, match="set_pose_norm"):
         Generator(device=dev()).load_state_dict(sd).encode(T(cha_raw), raw=True)
+
+
+def test_dual_stream_option_matches_single_stream():
+    """mocha_set_option("dual_stream", 1): the two halves of a large batch run on two streams; per window the result may
+    only differ by the kernel choice of a half-size batch (fp32 summation order), and a graph capture must still work."""
+    sd = weights.synthetic_state_dict(5, 1.3)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    mean, std = synthetic.cnt_norm(2)
+    src, cha = T(synthetic.pose_windows(3, 150)), T(synthetic.pose_windows(4, 40))
+    enc_c, _, nm_c = model.encode(cha, mean, std)
+    bank = ContextBank(model, nm_c.clone(), enc_c.clone())
+    Y1, i1 = bank.characterize(src, mean, std, return_index=True)
+    model.set_option("dual_stream", 1).set_option("dual_min", 64)
+    Y2, i2 = bank.characterize(src, mean, std, return_index=True)
+    Y3 = model(src[:130].contiguous(), src[20:150].contiguous())
+    model.set_option("dual_stream", 0)
+    Y4 = model(src[:130].contiguous(), src[20:150].contiguous())
+    assert torch.equal(i1, i2)
+    assert float((Y1 - Y2).abs().max()) < 2e-6 * max(1.0, float(Y1.abs().max()))
+    assert float((Y3 - Y4).abs().max()) < 2e-6 * max(1.0, float(Y4.abs().max()))
