@@ -150,6 +150,10 @@ int mocha_scale_shift(mocha_ctx* ctx, const float* x, const float* mean, const f
 int mocha_featurize(mocha_ctx* ctx, const float* Yrot, const float* Ypos, const float* Yvel, const float* Yang, int B,
                     float* X_raw, void* stream);
 
+/* Bank build statistics: cnt_mean, cnt_std = np.mean(cnt, 0), np.std(cnt, 0) over the N bank entries
+ * (compute_cnt_norm.py:174-175; population std), x (N, 90*256) -> mean, std (90*256). */
+int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, float* std_, void* stream);
+
 /* Runtime options.  "dual_stream" (default 0): batches of at least "dual_min" (default 128) windows are split in two
  * halves that run concurrently on the caller's stream and on an internal stream (forked / joined with events, so
  * the call keeps stream semantics and stays graph-capturable); the two kernel chains fill each other's prologue /

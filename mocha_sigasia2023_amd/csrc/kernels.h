@@ -100,6 +100,8 @@ hipError_t launch_scale_shift(const float* x, const float* mean, const float* sd
 hipError_t featurize_init();
 hipError_t launch_featurize(const float* Yrot, const float* Ypos, const float* Yvel, const float* Yang, const int* parents /*J, device*/,
                             float* X, int B, int T, int J, hipStream_t s);
+// per-column mean and population std over N rows (bank build: cnt_norm)
+hipError_t launch_column_stats(const float* x, int64_t N, int cols, float* mean, float* sd, hipStream_t s);
 // bank row squared norms
 hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, hipStream_t s);
 // per query: argmin_n (bnorm[n] - 2*sum_z S[z][q][n]); then exact distance to the winner

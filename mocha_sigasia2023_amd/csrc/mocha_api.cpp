@@ -1175,6 +1175,14 @@ int mocha_featurize(mocha_ctx* c, const float* Yrot, const float* Ypos, const fl
     return 0;
 }
 
+int mocha_column_stats(mocha_ctx* c, const float* x, int64_t N, float* mean, float* std_, void* stream) {
+    if (!c || !x || !mean || !std_ || N < 1) return fail(c, MOCHA_ERR_ARG, "bad column_stats arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(c, s, "mocha_column_stats", "bank.stats", 0.0, 8.0 * N * 23040, launch_column_stats(x, N, 90 * 256, mean, std_, s));
+    return 0;
+}
+
 int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (!c || !name) return MOCHA_ERR_ARG;
     const std::string n(name);

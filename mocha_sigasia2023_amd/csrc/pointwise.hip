@@ -441,4 +441,38 @@ hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------
+// column statistics over the bank entries (bank build, compute_cnt_norm.py:174-175):
+//   mean[j] = mean_n x[n][j] ;  std[j] = sqrt(mean_n (x[n][j] - mean[j])^2)      (numpy default: population std)
+// One thread per column, rows strided over the 4 waves of a workgroup is not needed: a column block of 64 adjacent
+// columns is read as coalesced 256-byte row segments; fp64 accumulation makes the result independent of N's size.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_column_stats(const float* __restrict__ x, long long N, int cols,
+                                                          float* __restrict__ mean, float* __restrict__ sd) {
+    __shared__ double s1[4][64], s2[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    if (col >= cols) return;
+    double a = 0.0;
+    for (long long n = w; n < N; n += 4) a += (double)x[(size_t)n * cols + col];
+    s1[w][lane] = a;
+    __syncthreads();
+    const double m = ((s1[0][lane] + s1[1][lane]) + (s1[2][lane] + s1[3][lane])) / (double)N;
+    double q = 0.0;
+    for (long long n = w; n < N; n += 4) { const double d = (double)x[(size_t)n * cols + col] - m; q += d * d; }
+    s2[w][lane] = q;
+    __syncthreads();
+    if (w == 0) {
+        mean[col] = (float)m;
+        sd[col] = (float)sqrt(((s2[0][lane] + s2[1][lane]) + (s2[2][lane] + s2[3][lane])) / (double)N);
+    }
+}
+
+hipError_t launch_column_stats(const float* x, int64_t N, int cols, float* mean, float* sd, hipStream_t s) {
+    if (N <= 0 || cols <= 0) return hipErrorInvalidValue;
+    if (cols % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_column_stats, dim3(cols / 64), dim3(256), 0, s, x, (long long)N, cols, mean, sd);
+    return hipGetLastError();
+}
+
 }  // namespace mocha
