@@ -150,6 +150,27 @@ int mocha_scale_shift(mocha_ctx* ctx, const float* x, const float* mean, const f
 int mocha_featurize(mocha_ctx* ctx, const float* Yrot, const float* Ypos, const float* Yvel, const float* Yang, int B,
                     float* X_raw, void* stream);
 
+/* Post-processing of decoded windows.
+ * mocha_pose_heads: Y (B,60,V,15) de-normalised -> heads (B,V,13) = [pos 3 | quat wxyz 4 | vel 3 | ang 3] of the last
+ *   frame (test_fullframework.py:304-308: slices + quat.from_xform_xy) and speed (B) = mean_t |Y[t,0,9:12]| (:338).
+ * mocha_postprocess: the sequential frame loop of the demo for n_clips independent clips of n_frames windows each
+ *   (:338-437 first frame, :492-632 after it): root integration from the source's root-local velocities, position
+ *   blending, foot-lock state machine (motion/Inertialization.py:300-377) and two-bone IK (motion/quat.py:295-343);
+ *   optionally the root merge + Euler channels of the BVH writer (:677-681, 697).  State is float64 as in the
+ *   reference.  heads (clips,frames,V,13), speed/src_speed (clips,frames), src_rvel/src_rang (clips,frames,3),
+ *   contact (clips,frames,n_contact) uint8 -> pos (clips,frames,V+1,3), rot / ik_rot (clips,frames,V+1,4) wxyz,
+ *   bvh_pos / bvh_euler (clips,frames,V,3; degrees; both NULL to skip).  cfg NULL = the demo's constants (:104-114). */
+typedef struct mocha_post_cfg {
+    double dt, ik_max_length_buffer, ik_foot_height, ik_unlock_radius, ik_blending_halflife;
+    int ik_enabled, n_contact;
+    int contact_bones[4];      /* toe bones, indices in the (V+1)-bone skeleton with the root bone in front */
+} mocha_post_cfg;
+void mocha_post_cfg_default(mocha_post_cfg* cfg);
+int mocha_pose_heads(mocha_ctx* ctx, const float* Y, int B, float* heads, float* speed, void* stream);
+int mocha_postprocess(mocha_ctx* ctx, const mocha_post_cfg* cfg, const float* heads, const float* speed, const float* src_rvel,
+                      const float* src_rang, const float* src_speed, const unsigned char* contact, int n_clips, int n_frames,
+                      double* pos, double* rot, double* ik_rot, double* bvh_pos, double* bvh_euler, void* stream);
+
 /* Bank build statistics: cnt_mean, cnt_std = np.mean(cnt, 0), np.std(cnt, 0) over the N bank entries
  * (compute_cnt_norm.py:174-175; population std), x (N, 90*256) -> mean, std (90*256). */
 int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, float* std_, void* stream);

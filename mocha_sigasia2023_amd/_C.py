@@ -54,6 +54,9 @@ SIGNATURES = {
     "mocha_cvae_condition": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mocha_scale_shift": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mocha_featurize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mocha_post_cfg_default": (None, [_vp]),
+    "mocha_pose_heads": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "mocha_postprocess": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocha_column_stats": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "mocha_set_option": (_i, [_vp, C.c_char_p, _i]),
     "mocha_graph_constants": (_i, [_vp, _vp, _vp, _vp, _vp]),

@@ -100,6 +100,26 @@ hipError_t launch_scale_shift(const float* x, const float* mean, const float* sd
 hipError_t featurize_init();
 hipError_t launch_featurize(const float* Yrot, const float* Ypos, const float* Yvel, const float* Yang, const int* parents /*J, device*/,
                             float* X, int B, int T, int J, hipStream_t s);
+// post-processing of decoded windows (postprocess.hip)
+#define MOCHA_MAX_CONTACT 4
+#define MOCHA_MAX_CHAIN 8
+#define MOCHA_MAX_BONES 32
+struct PostParams {
+    const float* heads;             // (clips, frames, V, 13)
+    const float* speed;             // (clips, frames)
+    const float* src_rvel;          // (clips, frames, 3)
+    const float* src_rang;          // (clips, frames, 3)
+    const float* src_speed;         // (clips, frames)
+    const unsigned char* contact;   // (clips, frames, n_contact)
+    double *pos, *rot, *ik_rot;     // (clips, frames, V+1, 3|4|4)
+    double *bvh_pos, *bvh_euler;    // (clips, frames, V, 3) or null
+    int n_clips, n_frames, V, n_contact, ik_enabled;
+    int parents[MOCHA_MAX_BONES];
+    int contact_bones[MOCHA_MAX_CONTACT];
+    double dt, max_length_buffer, foot_height, unlock_radius, halflife;
+};
+hipError_t launch_pose_heads(const float* Y, float* heads, float* speed, int B, int T, int V, hipStream_t s);
+hipError_t launch_post_clip(const PostParams& p, hipStream_t s);
 // per-column mean and population std over N rows (bank build: cnt_norm)
 hipError_t launch_column_stats(const float* x, int64_t N, int cols, float* mean, float* sd, hipStream_t s);
 // bank row squared norms

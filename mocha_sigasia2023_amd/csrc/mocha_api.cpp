@@ -1175,6 +1175,64 @@ int mocha_featurize(mocha_ctx* c, const float* Yrot, const float* Ypos, const fl
     return 0;
 }
 
+int mocha_pose_heads(mocha_ctx* c, const float* Y, int B, float* heads, float* speed, void* stream) {
+    if (!c || !Y || !heads || !speed || B < 0) return fail(c, MOCHA_ERR_ARG, "bad pose_heads arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(c, s, "mocha_pose_heads", "post.heads", 0.0, B * (60.0 * 12 + c->cfg.V * 28.0 * 4),
+           launch_pose_heads(Y, heads, speed, B, c->cfg.T, c->cfg.V, s));
+    return 0;
+}
+
+void mocha_post_cfg_default(mocha_post_cfg* cfg) {
+    if (!cfg) return;
+    *cfg = mocha_post_cfg{};
+    cfg->dt = 1.0 / 60.0;                   // test_fullframework.py:105
+    cfg->ik_max_length_buffer = 0.015;      // :109-114
+    cfg->ik_foot_height = 0.02;
+    cfg->ik_unlock_radius = 0.2;
+    cfg->ik_blending_halflife = 0.1;
+    cfg->ik_enabled = 1;
+    cfg->n_contact = 2;                     // :104
+    cfg->contact_bones[0] = 5;
+    cfg->contact_bones[1] = 24;
+}
+
+int mocha_postprocess(mocha_ctx* c, const mocha_post_cfg* cfg, const float* heads, const float* speed, const float* src_rvel,
+                      const float* src_rang, const float* src_speed, const unsigned char* contact, int n_clips, int n_frames,
+                      double* pos, double* rot, double* ik_rot, double* bvh_pos, double* bvh_euler, void* stream) {
+    if (!c || !heads || !speed || !src_rvel || !src_rang || !src_speed || !contact || !pos || !rot || !ik_rot || n_clips < 0 ||
+        n_frames < 0 || (!bvh_pos) != (!bvh_euler))
+        return fail(c, MOCHA_ERR_ARG, "bad postprocess arguments");
+    mocha_post_cfg d;
+    if (!cfg) { mocha_post_cfg_default(&d); cfg = &d; }
+    const int J = c->cfg.V + 1;
+    if (J > MOCHA_MAX_BONES) return fail(c, MOCHA_ERR_ARG, "postprocess: too many bones");
+    if (cfg->n_contact < 0 || cfg->n_contact > MOCHA_MAX_CONTACT) return fail(c, MOCHA_ERR_ARG, "postprocess: n_contact must be 0..4");
+    if (!(cfg->dt > 0.0)) return fail(c, MOCHA_ERR_ARG, "postprocess: dt must be positive");
+    PostParams p{};
+    p.heads = heads; p.speed = speed; p.src_rvel = src_rvel; p.src_rang = src_rang; p.src_speed = src_speed; p.contact = contact;
+    p.pos = pos; p.rot = rot; p.ik_rot = ik_rot; p.bvh_pos = bvh_pos; p.bvh_euler = bvh_euler;
+    p.n_clips = n_clips; p.n_frames = n_frames; p.V = c->cfg.V; p.n_contact = cfg->n_contact; p.ik_enabled = cfg->ik_enabled;
+    p.parents[0] = -1;                       // parents = [-1] + (joint parents + 1), test_fullframework.py:101-102
+    for (int i = 0; i < c->cfg.V; ++i) p.parents[i + 1] = c->sk.parents[i] + 1;
+    for (int i = 0; i < cfg->n_contact; ++i) {
+        const int toe = cfg->contact_bones[i];
+        if (toe < 1 || toe >= J) return fail(c, MOCHA_ERR_ARG, "postprocess: contact bone out of range");
+        int depth = 0;
+        for (int b = toe; b != -1; b = p.parents[b]) ++depth;
+        if (depth < 5 || depth > MOCHA_MAX_CHAIN) return fail(c, MOCHA_ERR_ARG, "postprocess: contact bone needs 4..7 ancestors");
+        p.contact_bones[i] = toe;
+    }
+    p.dt = cfg->dt; p.max_length_buffer = cfg->ik_max_length_buffer; p.foot_height = cfg->ik_foot_height;
+    p.unlock_radius = cfg->ik_unlock_radius; p.halflife = cfg->ik_blending_halflife;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(c, s, "mocha_post_clip", "post.clip", 0.0, (double)n_clips * n_frames * (c->cfg.V * 13.0 * 4 + J * 11.0 * 8),
+           launch_post_clip(p, s));
+    return 0;
+}
+
 int mocha_column_stats(mocha_ctx* c, const float* x, int64_t N, float* mean, float* std_, void* stream) {
     if (!c || !x || !mean || !std_ || N < 1) return fail(c, MOCHA_ERR_ARG, "bad column_stats arguments");
     HIPCHK(c, hipSetDevice(c->device));

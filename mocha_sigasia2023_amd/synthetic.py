@@ -52,3 +52,34 @@ def bone_windows(seed: int, B: int, J: int = 25, T: int = 60):
     vel = r.standard_normal((B, T, J, 3)).astype(np.float32)
     ang = r.standard_normal((B, T, J, 3)).astype(np.float32)
     return q, pos, vel, ang
+
+
+def postprocess_inputs(seed: int, N: int, V: int = 24, T: int = 60):
+    """Synthetic inputs of the demo's per-frame post-processing (test_fullframework.py:455-540): de-normalised decoded
+    windows Y (N,T,V,15) float32 whose last frames form a smooth pose sequence over a fixed random bone-offset
+    skeleton, the source's root-local velocities (N,3) x2, its hip velocities over each window (N,T,3) and contact
+    labels (N,2) uint8 in runs, so that locks, unlocks and radius-triggered unlocks all occur."""
+    r = _rng(seed)
+    offs = (0.25 * r.standard_normal((V, 3))).astype(np.float32)
+    offs[:, 1] -= 0.15                                   # bones mostly hang downwards
+    base = r.standard_normal((V, 4))
+    drift = 0.25 * r.standard_normal((V, 4))
+    t = np.arange(N, dtype=np.float64)[:, None, None]
+    q = base[None] + drift[None] * np.sin(0.07 * t + np.arange(V)[None, :, None])
+    q /= np.sqrt((q * q).sum(-1, keepdims=True))
+    w, x, y, z = (q[..., i] for i in range(4))
+    c0 = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y + w * z), 2 * (x * z - w * y)], -1)      # first / second matrix columns
+    c1 = np.stack([2 * (x * y - w * z), 1 - 2 * (x * x + z * z), 2 * (y * z + w * x)], -1)
+    xy = np.stack([c0, c1], -1).reshape(N, V, 6)                                                # (..., 3, 2) row-major
+    Y = np.empty((N, T, V, 15), np.float32)
+    Y[..., 0:3] = offs[None, None] + 0.01 * r.standard_normal((N, T, V, 3))
+    Y[..., 3:9] = xy[:, None] + 0.05 * r.standard_normal((N, T, V, 6))
+    Y[..., 9:12] = 0.5 * r.standard_normal((N, T, V, 3))
+    Y[..., 12:15] = r.standard_normal((N, T, V, 3))
+    src_rvel = (np.array([0.1, 0.0, 1.2]) + 0.1 * r.standard_normal((N, 3))).astype(np.float32)
+    src_rang = (np.array([0.0, 0.4, 0.0]) + 0.05 * r.standard_normal((N, 3))).astype(np.float32)
+    src_hipvel = (0.6 * r.standard_normal((N, T, 3))).astype(np.float32)
+    src_hipvel[N // 2] *= 0.05                           # one frame whose speed ratio leaves [0.33, 3] and is reset to 1
+    phase = (np.arange(N)[:, None] // 9 + np.array([0, 1])[None]) % 2
+    phase[N // 3: N // 3 + 30, 0] = 1                     # a long contact: exercised until the unlock radius trips
+    return Y, src_rvel, src_rang, src_hipvel, phase.astype(np.uint8)

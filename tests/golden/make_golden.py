@@ -189,6 +189,94 @@ def run_featurize():
     print("featurize", X.shape, X.dtype, float(np.abs(X).max()))
 
 
+def run_postprocess():
+    """The demo's per-frame post-processing (test_fullframework.py:303-437 for the first frame, :457-632 after it)
+    driven through the reference's own motion/quat.py and motion/Inertialization.py on synthetic decoded windows."""
+    cwd = os.getcwd(); os.chdir(REF)
+    try:
+        sys.path.insert(0, os.path.join(REF, "motion"))
+        import quat
+        import Inertialization as inert
+    finally:
+        os.chdir(cwd)
+    from mocha_sigasia2023_amd.skeleton import LAYOUTS
+    par = np.concatenate([[-1], np.asarray(LAYOUTS["mocha"]["parents"]) + 1])
+    feet = np.array([5, 24]); dt = 1.0 / 60.0
+    buf, foot_h, radius, half = 0.015, 0.02, 0.2, 0.1
+    N = 120
+    Y, rvel, rang, hipvel, contact = synthetic.postprocess_inputs(77, N)
+    ident = np.array([1, 0, 0, 0])
+    P, R, RIK = [], [], []
+    heads_rot, speeds = [], []
+    for i in range(N):
+        W = Y[i]
+        jp, jv, ja = W[-1, :, :3], W[..., 9:12], W[-1, :, 12:15]
+        jr = quat.from_xform_xy(W[-1, :, 3:9].reshape(jp.shape[0], 3, 2))
+        heads_rot.append(jr)
+        ratio = np.linalg.norm(jv[:, 0], axis=1).mean() / np.linalg.norm(hipvel[i], axis=1).mean()
+        speeds.append(np.linalg.norm(jv[:, 0], axis=1).mean())
+        if ratio > 3.0 or ratio < 0.33:
+            ratio = 1.0
+        q0, p0 = (ident, np.array([0, 0, 0])) if i == 0 else (R[-1][0], P[-1][0])
+        wv = quat.mul_vec(q0, rvel[i] * ratio); wa = quat.mul_vec(q0, rang[i])
+        pos = np.concatenate([(p0 + wv * dt)[None], jp]); vel = np.concatenate([wv[None], jv[-1]])
+        rot = np.concatenate([quat.mul(q0, quat.from_scaled_angle_axis(wa * dt))[None], jr]); ang = np.concatenate([wa[None], ja])
+        if i == 0:
+            nc = feet.size
+            st = dict(state=np.zeros(nc, bool), lock=np.zeros(nc, bool), pos=np.zeros((nc, 3)), vel=np.zeros((nc, 3)),
+                      point=np.zeros((nc, 3)), target=np.zeros((nc, 3)), ox=np.zeros((nc, 3)), ov=np.zeros((nc, 3)))
+            for b in range(nc):
+                bp, bv, _, _ = quat.fk_vel_bone(pos, vel, rot, ang, par, feet[b])
+                st["pos"][b] = bp; st["vel"][b] = bv; st["point"][b] = bp; st["target"][b] = bp
+            gpos, grot, done = np.zeros((len(par), 3)), np.zeros((len(par), 4)), np.zeros(len(par), bool)
+            P.append(pos); R.append(rot); RIK.append(rot)
+            continue
+        lpos = ((P[-1] + vel * dt) * 0.5 + pos * 0.5).copy()
+        arot = rot.copy()
+        for b in range(feet.size):
+            toe = feet[b]; heel = par[toe]; knee = par[heel]; hip = par[knee]; up = par[hip]
+            done[:] = False
+            quat.fk_partial(gpos, grot, done, lpos, rot, par, toe)
+            (st["state"][b], st["lock"][b], st["pos"][b], st["vel"][b], st["point"][b], st["target"][b], st["ox"][b], st["ov"][b]) = \
+                inert.contact_update(st["state"][b], st["lock"][b], st["pos"][b], st["vel"][b], st["point"][b], st["target"][b],
+                                     st["ox"][b], st["ov"][b], gpos[toe], bool(contact[i, b]), radius, foot_h, half, dt)
+            clamp = st["pos"][b]
+            clamp[1] = np.max([clamp[1], foot_h])
+            arot[hip], arot[knee] = quat.ik_two_bone(arot[hip], arot[knee], gpos[hip], gpos[knee], gpos[heel],
+                                                     clamp + (gpos[heel] - gpos[toe]),
+                                                     quat.mul_vec(grot[knee], np.array([0.0, 1.0, 0.0], dtype=np.float32)),
+                                                     grot[hip], grot[knee], grot[up], buf)
+        P.append(lpos); R.append(rot); RIK.append(arot)
+    P, R, RIK = np.stack(P), np.stack(R), np.stack(RIK)
+    grot_all, gpos_all = quat.fk(RIK, P, par)                           # root merge of :677-681 and Euler channels of :697
+    bp = P[:, 1:].copy(); bp[:, 0] = gpos_all[:, 1]
+    br = RIK[:, 1:].copy(); br[:, 0] = grot_all[:, 1]
+    np.savez(os.path.join(HERE, "postprocess.npz"), seed=np.array([77, N]), pos=P, rot=R, ik_rot=RIK,
+             heads_rot=np.stack(heads_rot).astype(np.float32), speed=np.asarray(speeds, np.float32),
+             bvh_pos=bp, bvh_euler=np.degrees(quat.to_euler(br)))
+    print("postprocess", P.shape, float(np.abs(P).max()), "ik changed rotations on",
+          int((np.abs(RIK - R).max(axis=(1, 2)) > 1e-9).sum()), "frames")
+
+
+def run_bvh():
+    """The reference writer (motion/bvh.py:179-224) on a small seeded animation; the produced text is the expected output."""
+    import tempfile
+    sys.path.insert(0, os.path.join(REF, "motion"))
+    import bvh
+    from mocha_sigasia2023_amd.skeleton import LAYOUTS
+    parents = np.asarray(LAYOUTS["mocha"]["parents"])
+    r = np.random.Generator(np.random.PCG64(5))
+    V, N = len(parents), 4
+    pos = r.standard_normal((N, V, 3)); rot = 90.0 * r.standard_normal((N, V, 3))
+    names = ["Bone%02d" % i for i in range(V)]
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "o.bvh")
+        bvh.save(path, {"rotations": rot, "positions": pos, "offsets": pos[0], "parents": parents, "names": names, "order": "zyx"})
+        text = open(path).read()
+    np.savez(os.path.join(HERE, "bvh_writer.npz"), pos=pos, rot=rot, text=np.array(text))
+    print("bvh", len(text), "chars")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     run_graph_constants()
@@ -198,3 +286,5 @@ if __name__ == "__main__":
     run_match()
     run_cvae()
     run_featurize()
+    run_postprocess()
+    run_bvh()
