@@ -178,7 +178,11 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
 /* Runtime options.  "dual_stream" (default 0): batches of at least "dual_min" (default 128) windows are split in two
  * halves that run concurrently on the caller's stream and on an internal stream (forked / joined with events, so
  * the call keeps stream semantics and stays graph-capturable); the two kernel chains fill each other's prologue /
- * epilogue / tail bubbles (+5 % on the demo step).  Results are unchanged except for the kernel choice per half. */
+ * epilogue / tail bubbles (+5 % on the demo step).  Results are unchanged except for the kernel choice per half.
+ * "fold_decoder" (default 1): the decoder's key and value projections are folded into its query and output weights at
+ * mocha_finalize_weights (possible because decoder_dim_head == dim; exact algebra, differences are fp32 rounding only),
+ * which removes two of the four projection GEMMs per decoder layer; 0 runs the four projections as written in
+ * net/transformer.py:62-76. */
 int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
 
 /* Introspection for tests and tooling. */

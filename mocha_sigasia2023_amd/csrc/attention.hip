@@ -43,8 +43,8 @@ __global__ __launch_bounds__(NQW * 64) void mocha_attention_f32(AttnParams p) {
     const int nq = p.nq, nk = p.nk;
 
     const float* qg = p.q + (size_t)b * nq * p.ldq + head * DH;
-    const float* kg = p.k + (size_t)b * nk * p.ldk + head * DH;
-    const float* vg = p.v + (size_t)b * nk * p.ldv + head * DH;
+    const float* kg = p.k + (size_t)b * nk * p.ldk + head * (p.hsk < 0 ? DH : p.hsk);
+    const float* vg = p.v + (size_t)b * nk * p.ldv + head * (p.hsv < 0 ? DH : p.hsv);
 
     // ---------------- phase 1: S^T[key][query] over DH in chunks of 32
     f32x16 st[NKT];

@@ -55,6 +55,7 @@ struct AttnParams {
     int ldq, ldk, ldv, ldo;       // row strides in floats
     int B, heads, dh, nq, nk;
     float scale;
+    int hsk = -1, hsv = -1;       // column offset per head of k / v (default dh; 0 = all heads share the same rows)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 

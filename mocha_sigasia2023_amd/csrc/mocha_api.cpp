@@ -134,6 +134,7 @@ struct mocha_ctx {
     bool cvae_ready = false;
     int cvae_depth = 2, cvae_heads = 4, cvae_nc = 180, cvae_nq = 90;
     std::map<std::string, DevBuf> cws; int cvae_B = 0;
+    bool fold_decoder = true;          // decoder key / value projections folded into the query / output weights
     int* bone_parents = nullptr;       // device: parents of the (V+1)-bone skeleton with the root bone in front
     float* pose_norm = nullptr;        // [x_mean | x_std | y_mean | y_std], (V+1)*C_in each (norm.npz of the reference)
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
@@ -390,8 +391,8 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
 
 // one transformer layer's attention output projection + FF (net/transformer.py:91-94), shared by enc/dec
 int run_out_ff(mocha_ctx* c, const std::string& p, const float* ao, int inner, const float* resid, int M, int mlp,
-               float* out, hipStream_t s) {
-    GemmParams o = plain(ao, inner, DW(c, p + ".Wo"), WS(c, "xb"), 256, M, 256, inner);
+               float* out, hipStream_t s, const char* wo = ".Wo") {
+    GemmParams o = plain(ao, inner, DW(c, p + wo), WS(c, "xb"), 256, M, 256, inner);
     o.bias = DW(c, p + ".bo"); o.residual = resid; o.ldr = 256;
     GEMM(c, s, "xf.out_proj", o);
     GemmParams f1 = plain(WS(c, "xb"), 256, DW(c, p + ".W1"), WS(c, "hff"), mlp, M, mlp, 256);
@@ -442,6 +443,21 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
         s2.bias = DW(c, p + ".bs2");
         GEMM(c, s, "dec.style2", s2);
         LAUNCH(c, s, "mocha_adain", "dec.adain", 0.0, b * 90.0 * 256 * 4 * 3, launch_adain(x, WS(c, "gb"), WS(c, "xad"), WS(c, "qin"), b, 90, s));
+        if (c->fold_decoder && DH == 256) {
+            // S_h = IN(x) (Wq_h^T Wk_h) IN(cha)^T and out = sum_h (P_h cha) (Wv_h^T Wo_h^T): with dim_head == dim the key and
+            // value projections fold into the query and output weights (exact algebra, net/transformer.py:62-76), so the
+            // attention reads IN(cha) / cha directly for every head and two of the four projection GEMMs disappear.
+            GemmParams gq = plain(WS(c, "qin"), 256, DW(c, p + ".Wqk"), qb, inner, M, inner, 256);
+            GEMM(c, s, "dec.q", gq);
+            AttnParams a{qb, WS(c, "kin"), cha, WS(c, "ao"), inner, 256, 256, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5), 0, 0};
+            LAUNCH(c, s, "mocha_attention_f32<256>", "dec.attn", 4.0 * b * H * 90.0 * 90 * DH, 4.0 * M * (2 * inner + 2 * 256),
+                   launch_attention(a, s));
+            float* out = (l == c->cfg.dec_depth - 1) ? outp : WS(c, "xa");
+            int rc = run_out_ff(c, p, WS(c, "ao"), inner, WS(c, "xad"), M, c->cfg.dec_mlp, out, s, ".Wvo");
+            if (rc) return rc;
+            x = out;
+            continue;
+        }
         GemmParams gq = plain(WS(c, "qin"), 256, DW(c, p + ".Wq"), qb, inner, M, inner, 256);
         GEMM(c, s, "dec.q", gq);
         GemmParams gk = plain(WS(c, "kin"), 256, DW(c, p + ".Wk"), kb, inner, M, inner, 256);
@@ -722,6 +738,32 @@ int mocha_finalize_weights(mocha_ctx* c) {
         up(d + ".Wo", W(c, s + ".1.to_out.0.weight")); up(d + ".bo", W(c, s + ".1.to_out.0.bias"));
         up(d + ".W1", W(c, s + ".2.net.0.weight")); up(d + ".b1", W(c, s + ".2.net.0.bias"));
         up(d + ".W2", W(c, s + ".2.net.3.weight")); up(d + ".b2", W(c, s + ".2.net.3.bias"));
+        const int H = c->cfg.dec_heads, DH = c->cfg.dec_dim_head, D = 256;
+        if (DH == D) {
+            // folded projections (see run_decoder), accumulated in fp64 and rounded once:
+            //   Wqk[h*D + j][i] = sum_d Wq[h*DH + d][i] * Wk[h*DH + d][j]        q' = IN(x) Wqk^T, keys = IN(cha)
+            //   Wvo[c][h*D + j] = sum_d Wo[c][h*DH + d] * Wv[h*DH + d][j]        out = [P_h cha]_h Wvo^T + bo
+            const auto& Wq = W(c, s + ".1.to_q.1.weight"); const auto& Wk = W(c, s + ".1.to_k.1.weight");
+            const auto& Wv = W(c, s + ".1.to_v.weight");   const auto& Wo = W(c, s + ".1.to_out.0.weight");
+            std::vector<double> qk((size_t)H * D * D, 0.0), vo((size_t)D * H * D, 0.0);
+            for (int h = 0; h < H; ++h)
+                for (int dd = 0; dd < DH; ++dd) {
+                    const float* q = &Wq[(size_t)(h * DH + dd) * D];
+                    const float* k = &Wk[(size_t)(h * DH + dd) * D];
+                    const float* v = &Wv[(size_t)(h * DH + dd) * D];
+                    for (int j = 0; j < D; ++j) {
+                        double* row = &qk[((size_t)h * D + j) * D];
+                        const double kj = k[j];
+                        for (int i = 0; i < D; ++i) row[i] += kj * (double)q[i];
+                    }
+                    for (int co = 0; co < D; ++co) {
+                        double* row = &vo[(size_t)co * H * D + (size_t)h * D];
+                        const double w = Wo[(size_t)co * H * DH + h * DH + dd];
+                        for (int j = 0; j < D; ++j) row[j] += w * (double)v[j];
+                    }
+                }
+            up(d + ".Wqk", f32(qk)); up(d + ".Wvo", f32(vo));
+        }
     }
     // ---- to_mot joint block + head
     up("mot.Wg2", W(c, "to_mot.4.blk.gcn.conv.weight")); up("mot.bg2", W(c, "to_mot.4.blk.gcn.conv.bias"));
@@ -1252,6 +1294,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
         return 0;
     }
     if (n == "dual_min") { c->dual_min = value < 2 ? 2 : value; return 0; }
+    if (n == "fold_decoder") { c->fold_decoder = value != 0; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);
 }
 

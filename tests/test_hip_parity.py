@@ -282,3 +282,18 @@ def test_dual_stream_option_matches_single_stream():
     assert torch.equal(i1, i2)
     assert float((Y1 - Y2).abs().max()) < 2e-6 * max(1.0, float(Y1.abs().max()))
     assert float((Y3 - Y4).abs().max()) < 2e-6 * max(1.0, float(Y4.abs().max()))
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_decoder_projection_folding_is_only_rounding(golden_dir, name):
+    """Default path: key / value projections folded into the query / output weights (mocha_set_option "fold_decoder").
+    Both the folded and the literal four-projection decoder must meet the fixture tolerance, and agree with each other
+    to fp32 rounding."""
+    z, meta, model, _ = load(golden_dir, name)
+    folded = model.decoder(T(z["src_encoded"]), T(z["cha_encoded"]))
+    model.set_option("fold_decoder", 0)
+    literal = model.decoder(T(z["src_encoded"]), T(z["cha_encoded"]))
+    model.set_option("fold_decoder", 1)
+    assert rel(folded, z["decoded"]) < RTOL and rel(literal, z["decoded"]) < RTOL
+    assert not torch.equal(folded, literal)                      # the option really switches the kernel chain
+    assert float((folded - literal).abs().max()) < 1e-5 * float(literal.abs().max())
