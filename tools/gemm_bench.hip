@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
         {"enc.qkv      ", B * 90, 1536, 256, 0},
         {"xf.out512    ", B * 90, 256, 512, 0},
         {"xf.ff1       ", B * 90, 512, 256, 0},
+        {"xf.ff1 1024  ", B * 90, 1024, 256, 0},
         {"dec.q        ", B * 90, 1024, 256, 0},
         {"dec.out1024  ", B * 90, 256, 1024, 0},
         {"emb.gcn_joint", B * 360, 256, 192, 0},
@@ -51,8 +52,9 @@ int main(int argc, char** argv) {
         int lda = sh.gather ? sh.lda : sh.K;
         size_t na = a_rows * lda, nw = (size_t)sh.N * sh.K, nc = (size_t)sh.M * sh.N;
         std::vector<float> ha(na), hw(nw);
-        for (auto& v : ha) v = (float)rand() / RAND_MAX * 2 - 1;
-        for (auto& v : hw) v = (float)rand() / RAND_MAX * 2 - 1;
+        const bool zero = getenv("MOCHA_BENCH_ZERO") != nullptr;      // zero operands: the clock the chip holds without data toggling
+        for (auto& v : ha) v = zero ? 0.f : (float)rand() / RAND_MAX * 2 - 1;
+        for (auto& v : hw) v = zero ? 0.f : (float)rand() / RAND_MAX * 2 - 1;
         float *dA, *dW, *dC, *dR;
         CK(hipMalloc(&dA, na * 4)); CK(hipMalloc(&dW, nw * 4)); CK(hipMalloc(&dC, nc * 4 * (sh.M == 585 && sh.N == 585 ? 16 : 1)));
         CK(hipMemcpy(dA, ha.data(), na * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hw.data(), nw * 4, hipMemcpyHostToDevice));

@@ -1,0 +1,176 @@
+// Where does the fp32 MFMA K-loop lose time?  Synthetic kernels that add the ingredients of the GEMM main loop one at a time.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/mfma_probe.hip -o tools/bin/mfma_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+constexpr int LDSK = 36;
+
+// MODE 0: registers only.  1: operands re-read from LDS each k-group (ds_read_b128, as the GEMM).  2: + the two barriers per
+// slab.  3: + global loads -> ds_write per slab (full GEMM loop without epilogue).
+template <int TM, int TN, int MODE>
+__global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float* out, int slabs, int ld) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const long long c_start = clock64(), w_start = wall_clock64();
+    constexpr int BMr = 128, BNr = (TM == 2 ? 128 : 64);
+    float* As = smem; float* Bs = smem + BMr * LDSK;
+    for (int i = tid; i < (BMr + BNr) * LDSK; i += 256) smem[i] = (float)(i % 7) * 0.125f;
+    __syncthreads();
+    const int wm = (TM == 2) ? wave / 2 : wave, wn = (TM == 2) ? wave % 2 : 0;
+    const float* Ab = As + (wm * TM * 32 + l31) * LDSK + 4 * hh;
+    const float* Bb = Bs + (wn * TN * 32 + l31) * LDSK + 4 * hh;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    constexpr int NA = BMr / 32, NB = BNr / 32;
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    const float* gp = g + ((size_t)blockIdx.x * 192 + lrow) * ld + lcol;
+    f32x4 ra[NA], rb[NB];
+    f32x4 a[TM], b[TN];
+    if (MODE == 0) { for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(Ab + i * 32 * LDSK); for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(Bb + j * 32 * LDSK); }
+    for (int s = 0; s < slabs; ++s) {
+        if (MODE >= 3) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = *(const f32x4*)(gp + (size_t)(32 * i) * ld + (s & 7) * 32);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = *(const f32x4*)(gp + (size_t)(128 + 32 * i) * ld + (s & 7) * 32);
+        }
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            if (MODE >= 1) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(Ab + i * 32 * LDSK + kg * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(Bb + j * 32 * LDSK + kg * 8);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][ks], a[i][ks], acc[i][j], 0, 0, 0);
+        }
+        if (MODE >= 2) __syncthreads();
+        if (MODE >= 3) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) *(f32x4*)(As + (lrow + 32 * i) * LDSK + lcol) = ra[i];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) *(f32x4*)(Bs + (lrow + 32 * i) * LDSK + lcol) = rb[i];
+        }
+        if (MODE >= 2) __syncthreads();
+    }
+    float sum = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (sum == 123.456f) out[0] = sum;
+    if (blockIdx.x == 0 && tid == 0) { ((long long*)out)[1] = clock64() - c_start; ((long long*)out)[2] = wall_clock64() - w_start; }
+}
+
+// glds variant: two unpadded XOR-swizzled LDS buffers filled by global_load_lds_dwordx4, one barrier per slab
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void probe_glds(const float* __restrict__ g, float* out, int slabs, int ld) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+    const long long c_start = clock64(), w_start = wall_clock64();
+    constexpr int BMr = 128, BNr = (TM == 2 ? 128 : 64), ROWS = BMr + BNr, NI = ROWS / 32;
+    const int wm = (TM == 2) ? wave / 2 : wave, wn = (TM == 2) ? wave % 2 : 0;
+    int off[4];
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) off[kg] = (((kg * 2 + hh) ^ (l31 & 7)) << 2);
+    const int arow = (wm * TM * 32 + l31) * 32, brow = (BMr + wn * TN * 32 + l31) * 32;
+    f32x16 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int lrow = tid >> 3, chunk = (lane & 7) ^ (lane >> 3);
+    const float* gp = g + ((size_t)blockIdx.x * 192 + lrow) * ld + chunk * 4;
+    auto fill = [&](int s, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            __builtin_amdgcn_global_load_lds(gp + (size_t)(32 * i) * ld + (s & 7) * 32,
+                                             (__attribute__((address_space(3))) void*)(smem + buf * ROWS * 32 + (32 * i + wave * 8) * 32), 16, 0, 0);
+    };
+    fill(0, 0);
+    __syncthreads();
+    for (int s = 0; s < slabs; ++s) {
+        const float* S = smem + (s & 1) * ROWS * 32;
+        if (s + 1 < slabs) fill(s + 1, (s + 1) & 1);
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(S + arow + i * 32 * 32 + off[kg]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(S + brow + j * 32 * 32 + off[kg]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][ks], a[i][ks], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float sum = 0.f;
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+    if (sum == 123.456f) out[0] = sum;
+    if (blockIdx.x == 0 && tid == 0) { ((long long*)out)[1] = clock64() - c_start; ((long long*)out)[2] = wall_clock64() - w_start; }
+}
+
+template <int TM, int TN>
+void run_glds(const char* name, int wg_per_cu, const float* g, float* out, int ld) {
+    const int slabs = 2048, grid = 256 * wg_per_cu;
+    const size_t lds = (size_t)2 * (128 + (TM == 2 ? 128 : 64)) * 32 * 4;
+    CK(hipFuncSetAttribute((const void*)probe_glds<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((probe_glds<TM, TN>), dim3(grid), dim3(256), lds, 0, g, out, 64, ld);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((probe_glds<TM, TN>), dim3(grid), dim3(256), lds, 0, g, out, slabs, ld);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)grid * 4 * slabs * 16 * TM * TN * 4096.0;
+    long long h[3]; CK(hipMemcpy(h, out, 24, hipMemcpyDeviceToHost));
+    const double ghz = (double)h[1] / ((double)h[2] * 10.0);      // s_memrealtime ticks at 100 MHz
+    printf("%-44s wg/cu=%d  %8.1f us  %7.1f TFLOP/s (%.1f%% of 157.3; clock %.3f GHz -> %.1f%% of the pipe at that clock)\n", name, wg_per_cu, ms * 1e3,
+           flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100, ghz, flops / ms / 1e9 / (157.3 * ghz / 2.4) * 100);
+}
+
+template <int TM, int TN, int MODE>
+void run(const char* name, int wg_per_cu, const float* g, float* out, int ld) {
+    const int slabs = 2048, grid = 256 * wg_per_cu;
+    const size_t lds = (size_t)(128 + (TM == 2 ? 128 : 64)) * LDSK * 4;
+    CK(hipFuncSetAttribute((const void*)probe<TM, TN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((probe<TM, TN, MODE>), dim3(grid), dim3(256), lds, 0, g, out, 64, ld);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((probe<TM, TN, MODE>), dim3(grid), dim3(256), lds, 0, g, out, slabs, ld);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)grid * 4 /*waves*/ * slabs * 16 /*k pairs*/ * TM * TN * 4096.0;
+    long long h[3]; CK(hipMemcpy(h, out, 24, hipMemcpyDeviceToHost));
+    const double ghz = (double)h[1] / ((double)h[2] * 10.0);      // s_memrealtime ticks at 100 MHz
+    printf("%-44s wg/cu=%d  %8.1f us  %7.1f TFLOP/s (%.1f%% of 157.3; clock %.3f GHz -> %.1f%% of the pipe at that clock)\n", name, wg_per_cu, ms * 1e3,
+           flops / ms / 1e9, flops / ms / 1e9 / 157.3 * 100, ghz, flops / ms / 1e9 / (157.3 * ghz / 2.4) * 100);
+}
+
+int main() {
+    const int ld = 1024;
+    float *g, *out;
+    CK(hipMalloc(&g, (size_t)256 * 4 * 192 * ld * 4)); CK(hipMemset(g, 0, (size_t)256 * 4 * 192 * ld * 4)); CK(hipMalloc(&out, 64)); CK(hipMemset(out, 0, 64));
+    for (int occ = 1; occ <= 3; ++occ) {
+        if (occ <= 2) run_glds<2, 2>("2x2 glds, 2 swizzled buffers, 1 barrier/slab", occ, g, out, ld);
+        run_glds<1, 2>("1x2 glds, 2 swizzled buffers, 1 barrier/slab", occ, g, out, ld);
+    }
+    for (int occ = 2; occ <= 3; ++occ) {
+        run<2, 2, 0>("2x2 tiles/wave, registers only", occ, g, out, ld);
+        run<2, 2, 1>("2x2 + ds_read_b128 operands", occ, g, out, ld);
+        run<2, 2, 2>("2x2 + ds_read + 2 barriers/slab", occ, g, out, ld);
+        if (occ <= 3) run<2, 2, 3>("2x2 + ds_read + barriers + global->LDS", occ, g, out, ld);
+        run<1, 2, 0>("1x2 tiles/wave, registers only", occ, g, out, ld);
+        run<1, 2, 1>("1x2 + ds_read_b128 operands", occ, g, out, ld);
+        run<1, 2, 2>("1x2 + ds_read + 2 barriers/slab", occ, g, out, ld);
+        run<1, 2, 3>("1x2 + ds_read + barriers + global->LDS", occ, g, out, ld);
+    }
+    return 0;
+}
