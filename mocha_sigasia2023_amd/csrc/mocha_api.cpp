@@ -821,6 +821,7 @@ int mocha_encoder(mocha_ctx* c, const float* tokens, int B, float* encoded, void
 int mocha_mvn(mocha_ctx* c, const float* encoded, int B, float* cnt, const float* cnt_mean, const float* cnt_std,
               float* cnt_nm, void* stream) {
     if (!c) return MOCHA_ERR_ARG;                      // needs no weights: usable on a bare context
+    if (B == 0) return 0;                              // empty batch: nothing to do, pointers may be null
     if (!encoded || !cnt || B < 0) return fail(c, MOCHA_ERR_ARG, "bad mvn arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const bool zn = cnt_nm && cnt_mean && cnt_std;
@@ -936,6 +937,7 @@ int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int6
 
 int mocha_match(mocha_ctx* c, const float* query_nm, int Q, int32_t* idx, float* dist, void* stream) {
     int rc = ready(c, 0); if (rc) return rc;
+    if (Q == 0) return 0;
     if (!query_nm || !idx || Q < 0) return fail(c, MOCHA_ERR_ARG, "bad match arguments");
     if (Q == 0) return 0;
     return do_match(c, query_nm, Q, idx, dist, (hipStream_t)stream);
@@ -944,6 +946,7 @@ int mocha_match(mocha_ctx* c, const float* query_nm, int Q, int32_t* idx, float*
 int mocha_bank_gather(mocha_ctx* c, const int32_t* idx, int Q, float* out, void* stream) {
     int rc = ready(c, 0); if (rc) return rc;
     if (!c->bank_enc) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
+    if (Q == 0) return 0;
     if (!idx || !out || Q < 0) return fail(c, MOCHA_ERR_ARG, "bad gather arguments");
     hipStream_t s = (hipStream_t)stream;
     LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, Q * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, idx, out, Q, 90 * 256, s));
@@ -954,6 +957,7 @@ static int characterize_impl(mocha_ctx* c, const float* src_X, int B, const floa
                              int32_t* idx, void* stream, bool raw) {
     int rc = ready(c, B); if (rc) return rc;
     if (!c->bank_cnt) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
+    if (B == 0) return 0;
     if (!cnt_mean || !cnt_std || !src_X || !Y) return fail(c, MOCHA_ERR_ARG, "null argument");
     const size_t ys = (size_t)60 * c->cfg.V * c->cfg.C_in;
     const size_t xs = raw ? (size_t)60 * (c->cfg.V + 1) * c->cfg.C_in : ys;
@@ -1147,6 +1151,7 @@ static int cvae_ff_block(mocha_ctx* c, hipStream_t s, const std::string& p, cons
 }
 
 int mocha_cvae_sample(mocha_ctx* c, const float* cond, int B, float* out, float* mu, float* logvar, const float* eps, void* stream) {
+    if (c && B == 0) return 0;
     if (!c || !cond || !out || B < 0) return fail(c, MOCHA_ERR_ARG, "bad CVAE arguments");
     if (!c->cvae_ready) return fail(c, MOCHA_ERR_STATE, "CVAE weights not finalised: call mocha_cvae_finalize first");
     if (B == 0) return 0;
@@ -1181,6 +1186,7 @@ int mocha_cvae_sample(mocha_ctx* c, const float* cond, int B, float* out, float*
 
 int mocha_cvae_condition(mocha_ctx* c, const float* src_cnt, const float* src_mean, const float* src_std, const float* prev_cha,
                          const float* cha_mean, const float* cha_std, int B, float* cond, void* stream) {
+    if (c && B == 0) return 0;
     if (!c || !src_cnt || !src_mean || !src_std || !prev_cha || !cha_mean || !cha_std || !cond || B < 0) return fail(c, MOCHA_ERR_ARG, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1190,6 +1196,7 @@ int mocha_cvae_condition(mocha_ctx* c, const float* src_cnt, const float* src_me
 }
 
 int mocha_scale_shift(mocha_ctx* c, const float* x, const float* mean, const float* std_, int B, float* out, void* stream) {
+    if (c && B == 0) return 0;
     if (!c || !x || !mean || !std_ || !out || B < 0) return fail(c, MOCHA_ERR_ARG, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1199,6 +1206,7 @@ int mocha_scale_shift(mocha_ctx* c, const float* x, const float* mean, const flo
 
 int mocha_featurize(mocha_ctx* c, const float* Yrot, const float* Ypos, const float* Yvel, const float* Yang, int B, float* X_raw,
                     void* stream) {
+    if (c && B == 0) return 0;
     if (!c || !Yrot || !Ypos || !Yvel || !Yang || !X_raw || B < 0) return fail(c, MOCHA_ERR_ARG, "bad featurize arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const int J = c->cfg.V + 1;
@@ -1218,6 +1226,7 @@ int mocha_featurize(mocha_ctx* c, const float* Yrot, const float* Ypos, const fl
 }
 
 int mocha_pose_heads(mocha_ctx* c, const float* Y, int B, float* heads, float* speed, void* stream) {
+    if (c && B == 0) return 0;
     if (!c || !Y || !heads || !speed || B < 0) return fail(c, MOCHA_ERR_ARG, "bad pose_heads arguments");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
@@ -1243,6 +1252,7 @@ void mocha_post_cfg_default(mocha_post_cfg* cfg) {
 int mocha_postprocess(mocha_ctx* c, const mocha_post_cfg* cfg, const float* heads, const float* speed, const float* src_rvel,
                       const float* src_rang, const float* src_speed, const unsigned char* contact, int n_clips, int n_frames,
                       double* pos, double* rot, double* ik_rot, double* bvh_pos, double* bvh_euler, void* stream) {
+    if (c && (n_clips == 0 || n_frames == 0)) return 0;
     if (!c || !heads || !speed || !src_rvel || !src_rang || !src_speed || !contact || !pos || !rot || !ik_rot || n_clips < 0 ||
         n_frames < 0 || (!bvh_pos) != (!bvh_euler))
         return fail(c, MOCHA_ERR_ARG, "bad postprocess arguments");

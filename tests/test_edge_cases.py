@@ -1,0 +1,116 @@
+"""Edge cases of the hot path through the C ABI: empty and single-element batches, a one-entry bank, more queries than
+bank rows, a batch that is not a multiple of the internal chunk, the largest bank of BASELINE configs[4] (16 384 rows,
+size-independent properties), and misuse that must fail loudly."""
+import numpy as np
+import pytest
+import torch
+
+from mocha_sigasia2023_amd import synthetic, weights
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    from mocha_sigasia2023_amd import Generator
+    return Generator(device="cuda:0").load_state_dict(weights.synthetic_state_dict(11, 1.0)).eval()
+
+
+def _norm():
+    m, s = synthetic.cnt_norm(3)
+    return torch.from_numpy(m).cuda(), torch.from_numpy(s).cuda()
+
+
+def test_empty_batches_return_empty(model):
+    from mocha_sigasia2023_amd import ContextBank, mean_variance_norm
+    from mocha_sigasia2023_amd.postprocess import PostProcessor, pose_heads
+    mean, std = _norm()
+    X0 = torch.empty((0, 60, 24, 15), device="cuda")
+    T0 = torch.empty((0, 90, 256), device="cuda")
+    assert model.mot_embedding(X0).shape == (0, 90, 256)
+    assert model.encoder(T0).shape == (0, 90, 256)
+    assert model.decoder(T0, T0).shape == (0, 90, 256)
+    assert model.to_mot(T0).shape == (0, 60, 24, 15)
+    assert model(X0, X0).shape == (0, 60, 24, 15)
+    assert mean_variance_norm(T0.permute(0, 2, 1)).shape == (0, 256, 90)
+    enc, cnt, nm = model.encode(X0, mean, std)
+    assert enc.shape == cnt.shape == nm.shape == (0, 90, 256)
+    e1, c1, n1 = model.encode(torch.from_numpy(synthetic.pose_windows(1, 3)), mean, std)
+    bank = ContextBank(model, n1, e1)
+    Y, idx = bank.characterize(X0, mean, std, return_index=True)
+    assert Y.shape == (0, 60, 24, 15) and idx.shape == (0,)
+    d, i = bank.query(T0, k=1)
+    assert d.shape == (0, 1) and i.shape == (0, 1)
+    h, s = pose_heads(model, X0)
+    assert h.shape == (0, 24, 13) and s.shape == (0,)
+    out = PostProcessor(model).run(np.zeros((0, 24, 13), np.float32), np.zeros(0, np.float32), np.zeros((0, 3), np.float32),
+                                   np.zeros((0, 3), np.float32), np.zeros(0, np.float32), np.zeros((0, 2), np.uint8))
+    assert out["pos"].shape == (0, 25, 3)
+
+
+def test_single_window_and_one_entry_bank(model):
+    from mocha_sigasia2023_amd import ContextBank
+    from oracle import mocha_oracle as O
+    mean, std = _norm()
+    sd = O.to_torch_state(weights.synthetic_state_dict(11, 1.0))
+    src = torch.from_numpy(synthetic.pose_windows(5, 1)); cha = torch.from_numpy(synthetic.pose_windows(6, 1))
+    e, c, n = model.encode(cha, mean, std)
+    bank = ContextBank(model, n, e)
+    Y, idx = bank.characterize(src, mean, std, return_index=True)
+    assert idx.tolist() == [0]
+    with torch.no_grad():
+        Yo = O.generator_forward(sd, src, cha)          # a one-entry bank makes the NN branch equal Generator.forward
+    assert float((Y.cpu() - Yo).abs().max()) < 1e-4
+    # more queries than bank rows
+    q = torch.from_numpy(synthetic.token_features(9, 7)).cuda()
+    d, i = bank.query(q, k=1)
+    assert i[:, 0].tolist() == [0] * 7
+    ref = torch.sqrt(((q.reshape(7, -1) - n.reshape(1, -1)) ** 2).sum(1))
+    assert torch.allclose(d[:, 0], ref, rtol=1e-5)
+
+
+def test_batch_not_a_multiple_of_the_chunk(model):
+    """1 031 windows with the default 1 024-window chunk: a 7-window tail goes through the skinny kernels."""
+    mean, std = _norm()
+    X = torch.from_numpy(synthetic.pose_windows(8, 1031)).cuda()
+    enc, cnt, nm = model.encode(X, mean, std)
+    e2, c2, n2 = model.encode(X[1020:].contiguous(), mean, std)
+    assert float((enc[1020:] - e2).abs().max()) < 3e-6 * float(e2.abs().max())
+    assert torch.isfinite(enc).all()
+
+
+def test_largest_bank_properties(model):
+    """BASELINE configs[4]: a 16 384-entry bank.  Size-independent properties: every bank row finds itself at distance 0,
+    the fp32 scan and the many-query GEMM path agree, a perturbed row still finds its origin."""
+    from mocha_sigasia2023_amd import ContextBank
+    N = 16384
+    g = torch.Generator(device="cuda").manual_seed(3)
+    nm = torch.randn((N, 90, 256), device="cuda", generator=g)
+    enc = torch.empty((1, 90, 256), device="cuda").expand(N, 90, 256)          # never gathered here
+    bank = ContextBank(model, nm, nm)
+    rows = torch.tensor([0, 1, 4095, 8192, 16383, 777, 12345, 9999, 31, 16000], device="cuda")
+    d, i = bank.query(nm[rows].contiguous(), k=1)                               # 10 queries: GEMM path
+    assert torch.equal(i[:, 0].long(), rows) and float(d.abs().max()) < 1e-3
+    for r in (0, 16383, 5000):                                                  # 1 query: streaming scan
+        d1, i1 = bank.query((nm[r:r + 1] + 0.01).contiguous(), k=1)
+        assert int(i1[0, 0]) == r
+        assert abs(float(d1[0, 0]) - 0.01 * (90 * 256) ** 0.5) < 1e-3
+    del enc
+
+
+def test_misuse_fails_loudly(model):
+    from mocha_sigasia2023_amd import ContextBank, Generator
+    mean, std = _norm()
+    with pytest.raises(TypeError):
+        model.encoder(torch.zeros((2, 90, 256), dtype=torch.float64, device="cuda"))
+    with pytest.raises(ValueError):
+        model.mot_embedding(torch.zeros((2, 60, 22, 15), device="cuda"))      # wrong joint count for this layout
+    with pytest.raises(ValueError):
+        model.decoder(torch.zeros((2, 90, 256), device="cuda"), torch.zeros((3, 90, 256), device="cuda"))
+    fresh = Generator(device="cuda:0")
+    with pytest.raises(RuntimeError, match="load_state_dict"):
+        fresh.encoder(torch.zeros((1, 90, 256), device="cuda"))
+    with pytest.raises(RuntimeError):
+        Generator(device="cpu")
+    with pytest.raises((RuntimeError, ValueError)):
+        ContextBank(model, torch.zeros((0, 90, 256), device="cuda"), torch.zeros((0, 90, 256), device="cuda"))
