@@ -13,7 +13,9 @@ One step = one pass of the demo's NN ("cm_") pipeline over the pair
     bank build : encode the character clip (mot_embedding, +pos_emb, encoder, cnt, z-score), row norms
     characterize: encode the source clip, z-score, exact 1-NN match against the bank, gather the
                   matched character features, decoder, to_mot  -> 585 characterized pose windows
-and yields 585 characterized frames (one output pose per window, the [-1] slice).
+and yields 585 characterized frames (one output pose per window, the [-1] slice).  By default the step runs through
+mocha_characterize_pair (both clips share the mot_embedding / encoder / cnt launches; same arithmetic, bit-identical
+output); --three-calls runs it as encode(cha) + ContextBank + characterize(src).
 
 Multi-GPU (weak scaling, one process per GPU): every rank runs the same step on its own source
 clip; the character clip and the cnt norm are owned by rank 0 and broadcast once over RCCL
@@ -52,6 +54,8 @@ def parse():
     ap.add_argument("--joints", type=int, default=22, choices=(24, 22),
                     help="22 = BASELINE.json's metric (the reference's 'mixamo' layout); 24 = the shipped 'mocha' model")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--three-calls", action="store_true",
+                    help="run the step as encode(cha) + ContextBank + characterize(src) instead of the fused characterize_pair")
     ap.add_argument("--dual-stream", action="store_true",
                     help="add a second timing of the same step with the opt-in two-stream overlap (reported beside the headline, "
                          "never as it; off by default so that a rocprofv3 run of the default command sees only the headline kernels)")
@@ -187,10 +191,16 @@ def main():
         torch.cuda.synchronize()
         bcast_ms = (time.perf_counter() - t0) * 1e3
 
-    def step():
+    def step_three_calls():
         enc_c, cnt_c, nm_c = model.encode(cha, mean, std)               # bank build
-        bank = ContextBank(model, nm_c, enc_c)                          # borrow + row norms
+        bank = ContextBank(model, nm_c, enc_c)                          # borrow + centroid + row norms
         return bank.characterize(src, mean, std, return_index=True)     # src encode, match, gather, decode, to_mot
+
+    def step_pair():
+        # the same work through mocha_characterize_pair: both clips share the mot_embedding / encoder / cnt launches
+        return model.characterize_pair(src, cha, mean, std, return_index=True)
+
+    step = step_three_calls if (a.three_calls or 2 * W > 1280) else step_pair
 
     def sync_all():
         torch.cuda.synchronize()
@@ -261,7 +271,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"demo pair (BASELINE configs[1]): {W} src x {W} cha windows, T=60, V={V}, C=15, "
-                                   f"bank build + encode/match/decode/to_mot per step", "windows_per_gpu": W,
+                                   f"bank build + encode/match/decode/to_mot per step "
+                                   f"({'encode + ContextBank + characterize' if step is step_three_calls else 'characterize_pair'})",
+                       "windows_per_gpu": W,
                        "joints": V, "bank_entries": W, "parallelism": f"dp{world} (independent windows, no in-step collective)"},
             "roofline": roofline,
             "kernel_breakdown": breakdown,

@@ -125,6 +125,18 @@ int mocha_encode_raw(mocha_ctx* ctx, const float* X_raw, int B, float* encoded, 
 int mocha_characterize_raw(mocha_ctx* ctx, const float* src_X_raw, int B, const float* cnt_mean, const float* cnt_std,
                            float* Y_denorm, int32_t* idx, void* stream);
 
+/* The demo pair in one pass: the character clip (B_cha windows) becomes the bank, the B_src source windows are characterized
+ * against it — mocha_encode(cha) + mocha_bank_set + mocha_characterize(src) with both clips sharing every launch of
+ * mot_embedding / encoder / cnt (test_fullframework.py:188-194, 271-277 for the two clips; :293-296, 438-443, 465-467).
+ * The bank is transient (it lives in the workspace during the call); the context's own bank is left untouched.  Optional
+ * outputs cha_encoded / cha_cnt_nm (B_cha,90,256) receive the bank for later mocha_bank_set; idx (B_src) the matches.
+ * B_src + B_cha must fit the workspace limit (default 1280 windows, mocha_reserve).  *_raw: as mocha_characterize_raw. */
+int mocha_characterize_pair(mocha_ctx* ctx, const float* src_X, int B_src, const float* cha_X, int B_cha, const float* cnt_mean,
+                            const float* cnt_std, float* Y, int32_t* idx, float* cha_encoded, float* cha_cnt_nm, void* stream);
+int mocha_characterize_pair_raw(mocha_ctx* ctx, const float* src_X_raw, int B_src, const float* cha_X_raw, int B_cha,
+                                const float* cnt_mean, const float* cnt_std, float* Y, int32_t* idx, float* cha_encoded,
+                                float* cha_cnt_nm, void* stream);
+
 /* CVAE character-feature sampler: CVAE.sample(c) of model_CVAE.py:44-46, i.e.
  * PriorNet (:49-92) then Decoder (:138-165).  Weights by their reference state_dict names
  * ("prior_net.encoder.layers.0.self_attn.in_proj_weight", ...; test_fullframework.py:52-58); the

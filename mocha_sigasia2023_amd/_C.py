@@ -48,6 +48,8 @@ SIGNATURES = {
     "mocha_set_pose_norm": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mocha_encode_raw": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocha_characterize_raw": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mocha_characterize_pair": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mocha_characterize_pair_raw": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocha_cvae_load_weight": (_i, [_vp, C.c_char_p, _vp, C.POINTER(_i64), _i]),
     "mocha_cvae_finalize": (_i, [_vp]),
     "mocha_cvae_sample": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),

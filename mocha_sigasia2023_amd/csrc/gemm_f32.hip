@@ -132,6 +132,11 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + k0);
+        if (p.wsub) {                               // matcher: bank rows are centred on the fly (the bank itself may be borrowed)
+            const f32x4 cv = *reinterpret_cast<const f32x4*>(p.wsub + k0 + lcol);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] -= cv;
+        }
     };
     auto store_slab = [&]() __attribute__((always_inline)) {
         float* Ab = As;
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_skinny(GemmParams p) {
 
 // true when the tiled kernel would leave most of the chip idle and the shape fits the skinny kernel
 bool gemm_is_skinny(const GemmParams& p) {
-    if (p.ksplit > 1 || (p.N & 3) || (p.ldc & 3) || (p.residual && (p.ldr & 3)) || (p.gather && p.R != 1)) return false;
+    if (p.wsub || p.ksplit > 1 || (p.N & 3) || (p.ldc & 3) || (p.residual && (p.ldr & 3)) || (p.gather && p.R != 1)) return false;
     const long long wide_tiles = (long long)((p.M + BM - 1) / BM) * ((p.N + 63) / 64);
     return wide_tiles < 96;
 }

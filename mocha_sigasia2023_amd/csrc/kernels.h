@@ -20,6 +20,7 @@ namespace mocha {
 struct GemmParams {
     const float* A = nullptr;     // source activations
     const float* W = nullptr;     // [N][K], k contiguous (nn.Linear / repacked conv layout)
+    const float* wsub = nullptr;              // [K] vector subtracted from every W row while it is staged (centred bank)
     const unsigned short* Wsplit = nullptr;   // [planes][N][K] bf16 planes of W (gemm_split.hip), or a bf16 bank
     float* C = nullptr;
     const float* bias = nullptr;      // [N] or null
@@ -124,7 +125,8 @@ hipError_t launch_post_clip(const PostParams& p, hipStream_t s);
 // per-column mean and population std over N rows (bank build: cnt_norm)
 hipError_t launch_column_stats(const float* x, int64_t N, int cols, float* mean, float* sd, hipStream_t s);
 // bank row squared norms
-hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, hipStream_t s);
+hipError_t launch_rownorm2(const float* x, const float* sub /*or null*/, float* out, int64_t rows, int cols, hipStream_t s);
+hipError_t launch_sub_rows(const float* x, const float* sub, float* out, int64_t rows, int cols, hipStream_t s);
 // per query: argmin_n (bnorm[n] - 2*sum_z S[z][q][n]); then exact distance to the winner
 hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm,
                          const float* query, const float* bank, const void* bank16 /*bf16 bank or null*/, int Q, int64_t N, int D,
@@ -132,9 +134,9 @@ hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int 
 // streaming matcher for few queries against a large bank (HBM-bound): bank fp32 or bf16;
 // partial = match_stream_scratch(Q, N) u64 words of scratch
 size_t match_stream_scratch(int Q, int64_t N);
-hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* bnorm, const float* query, int Q, int64_t N, int D,
+hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* query, int Q, int64_t N, int D,
                                unsigned long long* partial, int32_t* idx, float* dist, hipStream_t s);
-hipError_t launch_to_bf16(const float* x, void* y, int64_t n, hipStream_t s);
+hipError_t launch_to_bf16(const float* x, const float* sub /*per-column, or null*/, int cols, void* y, int64_t n, hipStream_t s);
 hipError_t launch_rownorm2_bf16(const void* x, float* out, int64_t rows, int cols, hipStream_t s);
 // out[q] = src[idx[q]] rows of `cols` floats
 hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, int Q, int cols, hipStream_t s);

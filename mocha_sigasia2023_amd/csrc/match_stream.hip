@@ -1,7 +1,10 @@
 // Context matching for FEW queries against a LARGE bank: the HBM-bound regime (streaming one query
 // per frame against a 4k-16k entry bank, BASELINE configs[4]; SURVEY.md §8d "bank scan").
 //
-// exact 1-NN = argmin_b ( ||b||^2 - 2 q.b )          (test_fullframework.py:296,443)
+// exact 1-NN = argmin_b sum_d (q_d - b_d)^2          (test_fullframework.py:296,443)
+// in the DIRECT form: the scan is HBM-bound, so the subtraction is free, and it has none of the cancellation of
+// ||b||^2 - 2 q.b (feature rows of one character sit close together far from the origin: ||b||^2 ~ 1e5, gaps between the
+// best candidates ~ 1e-2).
 // The bank is read exactly once per launch, 16 bytes per lane per load, straight to registers
 // (no LDS round trip for streamed-once data); the <= 8 query vectors of a launch are staged through
 // LDS one D-chunk at a time and reused by every bank row of the workgroup.  Each wave owns whole
@@ -16,6 +19,7 @@ namespace mocha {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 static constexpr int MS_ROWS_PER_WAVE = 4;      // rows a wave carries through the D loop together
 static constexpr int MS_WAVES = 4;
@@ -28,7 +32,7 @@ __device__ __forceinline__ unsigned long long pack_key(float v, unsigned row) {
 }
 
 template <int Q, bool BF16>
-__global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict__ bank, const float* __restrict__ bnorm,
+__global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict__ bank,
                                                           const float* __restrict__ query, int nq, long long N, int D,
                                                           unsigned long long* __restrict__ partial /*[Q8][gridDim.x]*/) {
     __shared__ __attribute__((aligned(16))) float qs[Q * MS_CHUNK];
@@ -36,11 +40,13 @@ __global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const long long row0 = ((long long)blockIdx.x * MS_WAVES + wave) * MS_ROWS_PER_WAVE;
 
-    float acc[MS_ROWS_PER_WAVE][Q];
+    // two partial sums per (row, query) so that the squares accumulate with packed fp32 math (v_pk_fma_f32): with
+    // several queries the scan is VALU-bound, not HBM-bound
+    f32x2 acc[MS_ROWS_PER_WAVE][Q];
 #pragma unroll
     for (int r = 0; r < MS_ROWS_PER_WAVE; ++r)
 #pragma unroll
-        for (int q = 0; q < Q; ++q) acc[r][q] = 0.f;
+        for (int q = 0; q < Q; ++q) acc[r][q] = f32x2{0.f, 0.f};
 
     const int nchunks = D / MS_CHUNK;
     for (int ch = 0; ch < nchunks; ++ch) {
@@ -71,10 +77,10 @@ __global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict
                     const f32x4 qv = reinterpret_cast<const f32x4*>(qs)[q * (MS_CHUNK / 4) + lane + 64 * i];
 #pragma unroll
                     for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
-                        acc[r][q] = fmaf(bv[r][i][0], qv[0], acc[r][q]);
-                        acc[r][q] = fmaf(bv[r][i][1], qv[1], acc[r][q]);
-                        acc[r][q] = fmaf(bv[r][i][2], qv[2], acc[r][q]);
-                        acc[r][q] = fmaf(bv[r][i][3], qv[3], acc[r][q]);
+                        const f32x4 d = bv[r][i] - qv;
+                        const f32x2 dl = {d[0], d[1]}, dh = {d[2], d[3]};
+                        acc[r][q] = __builtin_elementwise_fma(dl, dl, acc[r][q]);
+                        acc[r][q] = __builtin_elementwise_fma(dh, dh, acc[r][q]);
                     }
                 }
         } else {
@@ -103,14 +109,15 @@ __global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict
 #pragma unroll
                         for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
                             const u32x4 w = bv[r][i];      // 8 bf16: element 2j in the low half of word j
-                            acc[r][q] = fmaf(__uint_as_float(w[0] << 16), q0[0], acc[r][q]);
-                            acc[r][q] = fmaf(__uint_as_float(w[0] & 0xffff0000u), q0[1], acc[r][q]);
-                            acc[r][q] = fmaf(__uint_as_float(w[1] << 16), q0[2], acc[r][q]);
-                            acc[r][q] = fmaf(__uint_as_float(w[1] & 0xffff0000u), q0[3], acc[r][q]);
-                            acc[r][q] = fmaf(__uint_as_float(w[2] << 16), q1[0], acc[r][q]);
-                            acc[r][q] = fmaf(__uint_as_float(w[2] & 0xffff0000u), q1[1], acc[r][q]);
-                            acc[r][q] = fmaf(__uint_as_float(w[3] << 16), q1[2], acc[r][q]);
-                            acc[r][q] = fmaf(__uint_as_float(w[3] & 0xffff0000u), q1[3], acc[r][q]);
+                            f32x2 d;
+                            d = f32x2{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u)} - f32x2{q0[0], q0[1]};
+                            acc[r][q] = __builtin_elementwise_fma(d, d, acc[r][q]);
+                            d = f32x2{__uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)} - f32x2{q0[2], q0[3]};
+                            acc[r][q] = __builtin_elementwise_fma(d, d, acc[r][q]);
+                            d = f32x2{__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xffff0000u)} - f32x2{q1[0], q1[1]};
+                            acc[r][q] = __builtin_elementwise_fma(d, d, acc[r][q]);
+                            d = f32x2{__uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xffff0000u)} - f32x2{q1[2], q1[3]};
+                            acc[r][q] = __builtin_elementwise_fma(d, d, acc[r][q]);
                         }
                     }
                 }
@@ -124,11 +131,11 @@ __global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict
 #pragma unroll
         for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
             const long long row = row0 + r;
-            float v = acc[r][q];
+            float v = acc[r][q][0] + acc[r][q][1];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
             if (row < N) {
-                const unsigned long long k = pack_key(bnorm[row] - 2.f * v, (unsigned)row);
+                const unsigned long long k = pack_key(v, (unsigned)row);      // v = squared distance
                 kmin = k < kmin ? k : kmin;
             }
         }
@@ -184,7 +191,7 @@ size_t match_stream_scratch(int Q, int64_t N) {        // u64 words of partial[]
     return (size_t)((Q + 7) / 8) * 8 * nwg;
 }
 
-hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* bnorm, const float* query, int Q, int64_t N, int D,
+hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* query, int Q, int64_t N, int D,
                                unsigned long long* partial, int32_t* idx, float* dist, hipStream_t s) {
     if (Q <= 0) return hipSuccess;
     if (D % MS_CHUNK != 0) return hipErrorInvalidValue;
@@ -196,8 +203,8 @@ hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* bno
         unsigned long long* pp = partial + (size_t)q0 * grid;      // partial[q][wg], q global
 #define MS_LAUNCH(QQ)                                                                                          \
         do {                                                                                                   \
-            if (bank_bf16) hipLaunchKernelGGL((mocha_match_stream<QQ, true>), dim3(grid), dim3(256), 0, s, bank, bnorm, qp, nq, (long long)N, D, pp); \
-            else hipLaunchKernelGGL((mocha_match_stream<QQ, false>), dim3(grid), dim3(256), 0, s, bank, bnorm, qp, nq, (long long)N, D, pp);          \
+            if (bank_bf16) hipLaunchKernelGGL((mocha_match_stream<QQ, true>), dim3(grid), dim3(256), 0, s, bank, qp, nq, (long long)N, D, pp); \
+            else hipLaunchKernelGGL((mocha_match_stream<QQ, false>), dim3(grid), dim3(256), 0, s, bank, qp, nq, (long long)N, D, pp);          \
         } while (0)
         if (nq == 1) MS_LAUNCH(1);
         else if (nq == 2) MS_LAUNCH(2);
@@ -212,10 +219,12 @@ hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* bno
 
 // fp32 -> bf16 (round to nearest even) copy of the matching bank, and its squared row norms are then
 // taken from the rounded values (launch_rownorm2_bf16) so that value and norm stay consistent
-__global__ __launch_bounds__(256) void mocha_to_bf16(const float* __restrict__ x, unsigned short* __restrict__ y, long long n4) {
+__global__ __launch_bounds__(256) void mocha_to_bf16(const float* __restrict__ x, const float* __restrict__ sub, int cols4,
+                                                     unsigned short* __restrict__ y, long long n4) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
-    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    if (sub) v -= reinterpret_cast<const f32x4*>(sub)[i % cols4];          // centred bank: the rounding acts on b - centre
     unsigned short o[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -240,11 +249,11 @@ __global__ __launch_bounds__(256) void mocha_rownorm2_bf16(const unsigned short*
     if (threadIdx.x == 0) out[row] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-hipError_t launch_to_bf16(const float* x, void* y, int64_t n, hipStream_t s) {
+hipError_t launch_to_bf16(const float* x, const float* sub, int cols, void* y, int64_t n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    if (n % 4) return hipErrorInvalidValue;
+    if (n % 4 || cols % 4) return hipErrorInvalidValue;
     const long long n4 = n / 4;
-    hipLaunchKernelGGL(mocha_to_bf16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, (unsigned short*)y, n4);
+    hipLaunchKernelGGL(mocha_to_bf16, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, x, sub, cols / 4, (unsigned short*)y, n4);
     return hipGetLastError();
 }
 

@@ -110,7 +110,7 @@ struct mocha_ctx {
 
     // workspaces: sized for `chunk` windows; larger batches are processed chunk by chunk
     int chunk = 0;
-    int max_chunk = 1024;
+    int max_chunk = 1280;
     // Two workspace sets: large batches are split in two halves that run on two HIP streams (the caller's and
     // `aux`), so that the prologue / epilogue / tail of one half's kernels overlaps the other half's MFMA phases
     // (+5..10 % measured); `cur` selects the set the pipelines below write to.
@@ -126,6 +126,9 @@ struct mocha_ctx {
     const float* bank_enc = nullptr;
     float* bank_cnt_own = nullptr; float* bank_enc_own = nullptr; size_t bank_cap = 0;
     float* bank_norm = nullptr; size_t bank_norm_cap = 0;
+    float* bank_center = nullptr;                           // centroid of the matching bank (90*256), see do_match
+    DevBuf match_qc[2];                                     // queries minus the centroid
+    float* pair_norm = nullptr; size_t pair_norm_cap = 0;      // row norms of the transient bank of mocha_characterize_pair
     int64_t bank_N = 0;
     // CVAE sampler (row N1): weights under "cvae.<reference key>", workspace for cvae_B conditions
     std::map<std::string, std::vector<int64_t>> cvae_expect;
@@ -358,7 +361,10 @@ GemmParams plain(const float* A, int lda, const float* Wt, float* C, int ldc, in
 
 // ---------------------------------------------------------------- stage pipelines on one chunk
 // mot_embedding (model.py:42-50) for b windows: X -> tokens (b*90, 256)
-int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, hipStream_t s, bool raw = false) {
+// X2 / b2: an optional second clip whose windows follow the first one's in every workspace (pair step: both clips of a
+// demo pair share the launches from the gcn conv on, so each launch has twice the tiles)
+int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, hipStream_t s, bool raw = false,
+              const float* X2 = nullptr, int b2 = 0) {
     const int V = c->cfg.V;
     const int nn = (V + 1) * c->cfg.C_in;
     if (raw && !c->pose_norm) return fail(c, MOCHA_ERR_STATE, "raw input needs mocha_set_pose_norm first");
@@ -366,6 +372,12 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     LAUNCH(c, s, "mocha_embed_front", "emb.front", b * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b * 60.0 * (V * 15 + 6 * 192) * 4,
            launch_embed_front(X, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar"), b * 60, V, c->cfg.C_in,
                               raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s));
+    if (X2 && b2 > 0) {
+        LAUNCH(c, s, "mocha_embed_front", "emb.front", b2 * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b2 * 60.0 * (V * 15 + 6 * 192) * 4,
+               launch_embed_front(X2, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar") + (size_t)b * 360 * 192, b2 * 60, V,
+                                  c->cfg.C_in, raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s));
+        b += b2;
+    }
     // gcn 1x1 conv on the pooled operand: (b*360, 192) x (256,192)^T + pooled bias
     GemmParams g1 = plain(WS(c, "hbar"), 192, DW(c, "emb.Wg"), WS(c, "ybar"), 256, b * 360, 256, 192);
     g1.rowbias = DW(c, "emb.rbg"); g1.rb_mod = 6;
@@ -537,14 +549,36 @@ int ready(mocha_ctx* c, int B) {
     return 0;
 }
 
+// Nearest bank entry of every query (BallTree.query(k=1), test_fullframework.py:296,443).
+// Precision: the rows of one character's bank sit close together far from the origin (||b||^2 ~ 1e5, gaps between the
+// best candidates ~ 1e-2), so ||b||^2 - 2 q.b in fp32 cannot rank them.  Few queries: the HBM-bound scan evaluates
+// sum (q-b)^2 directly.  Many queries: the GEMM runs on operands centred on the bank centroid c (distances are
+// translation invariant; the centred norms are of the size of the distances themselves) and the arg-min re-ranks its
+// four best candidates by their exact direct distances.
+int grow(mocha_ctx* c, DevBuf& b, size_t need) {
+    if (b.n >= need) return 0;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (b.p) { (void)hipFree(b.p); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), b.p), c->owned.end()); }
+    b = DevBuf{};
+    int rc = dev_alloc(c, &b.p, need);
+    if (rc) return rc;
+    b.n = need;
+    return 0;
+}
+
 int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, hipStream_t s) {
     if (!c->bank_cnt || c->bank_N <= 0) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
     const int D = 90 * 256;
     const int64_t N = c->bank_N;
-    // Few queries (streaming, one per frame) or a bf16 bank: HBM-bound bank scan, bank read once per
-    // 8 queries.  Many queries against an fp32 bank: MFMA GEMM Q.Bank^T + arg-min.
+    const int set = c->cur;
+    int rc;
+    const bool need_qc = c->bank_is_bf16 || Q > 8;       // the bf16 bank holds bf16(b - c); the GEMM works on centred operands
+    if (need_qc) {
+        if ((rc = grow(c, c->match_qc[set], (size_t)Q * D))) return rc;
+        LAUNCH(c, s, "mocha_sub_rows", "match.center", 0.0, 8.0 * Q * D, launch_sub_rows(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
+    }
+    const float* qc = need_qc ? c->match_qc[set].p : nullptr;
     if (Q <= 8) {
-        const int set = c->cur;
         const size_t need_ws = match_stream_scratch(Q, N);
         if (c->best_ws_n[set] < need_ws) {
             if (c->best_ws[set]) (void)hipFree(c->best_ws[set]);
@@ -554,36 +588,29 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
         }
         const void* bank = c->bank_is_bf16 ? (const void*)c->bank_bf16 : (const void*)c->bank_cnt;
         const double passes = (Q + 7) / 8;
-        LAUNCH(c, s, c->bank_is_bf16 ? "mocha_match_stream<bf16>" : "mocha_match_stream<f32>", "match.stream", 2.0 * Q * N * D,
+        LAUNCH(c, s, c->bank_is_bf16 ? "mocha_match_stream<bf16>" : "mocha_match_stream<f32>", "match.stream", 3.0 * Q * N * D,
                passes * N * D * (c->bank_is_bf16 ? 2.0 : 4.0) + 4.0 * Q * D,
-               launch_match_stream(bank, c->bank_is_bf16 ? 1 : 0, c->bank_norm, qnm, Q, N, D, c->best_ws[set], idx, dist, s));
+               launch_match_stream(bank, c->bank_is_bf16 ? 1 : 0, c->bank_is_bf16 ? qc : qnm, Q, N, D, c->best_ws[set], idx, dist, s));
         return 0;
     }
     const long long tiles = (long long)((Q + 127) / 128) * ((N + 127) / 128);
     int ksplit = (int)std::min<long long>(16, std::max<long long>(1, (768 + tiles - 1) / tiles));
-    const size_t need = (size_t)ksplit * Q * N;
-    DevBuf& mS = c->match_S[c->cur];
-    if (mS.n < need) {
-        HIPCHK(c, hipDeviceSynchronize());
-        if (mS.p) { (void)hipFree(mS.p); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), mS.p), c->owned.end()); }
-        mS = DevBuf{};
-        int rc = dev_alloc(c, &mS.p, need);
-        if (rc) return rc;
-        mS.n = need;
-    }
-    GemmParams g = plain(qnm, D, c->bank_cnt, mS.p, (int)N, Q, (int)N, D);
+    DevBuf& mS = c->match_S[set];
+    if ((rc = grow(c, mS, (size_t)ksplit * Q * N))) return rc;
+    GemmParams g = plain(qc, D, c->bank_cnt, mS.p, (int)N, Q, (int)N, D);
     g.ksplit = ksplit; g.slab_stride = (long long)Q * N;
     if (c->bank_is_bf16) {
-        // bf16 bank: exact fp32 queries (three bf16 planes) against the rounded bank on the bf16 matrix pipe
+        // bf16 bank: exact fp32 (centred) queries as three bf16 planes against the rounded centred bank on the bf16 matrix pipe
         g.Wsplit = (const unsigned short*)c->bank_bf16;
         LAUNCH(c, s, "mocha_gemm_split<128,2,2,2,2,3,1,2>", "match.qk_bf16", 2.0 * Q * (double)N * D,
                4.0 * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit, launch_gemm_split(g, 31, s));
     } else {
+        g.wsub = c->bank_center;
         GEMM(c, s, "match.qk", g);
     }
-    LAUNCH(c, s, "mocha_argmin", "match.argmin", 0.0, (double)ksplit * Q * N * 4,
-           launch_argmin(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_cnt, c->bank_is_bf16 ? c->bank_bf16 : nullptr,
-                         Q, N, D, idx, dist, s));
+    LAUNCH(c, s, "mocha_argmin", "match.argmin", 0.0, (double)ksplit * Q * N * 4 * 4,
+           launch_argmin(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, c->bank_is_bf16 ? qc : qnm, c->bank_cnt,
+                         c->bank_is_bf16 ? c->bank_bf16 : nullptr, Q, N, D, idx, dist, s));
     return 0;
 }
 
@@ -920,6 +947,11 @@ int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int6
             }
     }
     c->bank_is_bf16 = (flags & MOCHA_BANK_BF16) != 0;
+    // centroid of the bank: the many-query GEMM and the bf16 copy work on b - centroid (see do_match)
+    if (!c->bank_center && (rc = dev_alloc(c, &c->bank_center, D))) return rc;
+    for (int set = 0; set < 2; ++set)                    // centred queries of a <= 8-query step: allocated here (capture-safe later)
+        if ((rc = grow(c, c->match_qc[set], (size_t)8 * D))) return rc;
+    LAUNCH(c, s, "mocha_column_stats", "bank.center", 0.0, 4.0 * N * D, launch_column_stats(c->bank_cnt, N, (int)D, c->bank_center, nullptr, s));
     if (c->bank_is_bf16) {
         if (c->bank_bf16_cap < (size_t)N) {
             if (c->bank_bf16) (void)hipFree(c->bank_bf16);
@@ -927,10 +959,10 @@ int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int6
             HIPCHK(c, hipMalloc(&c->bank_bf16, (size_t)N * D * 2));
             c->bank_bf16_cap = (size_t)N;
         }
-        LAUNCH(c, s, "mocha_to_bf16", "bank.to_bf16", 0.0, 6.0 * N * D, launch_to_bf16(c->bank_cnt, c->bank_bf16, (int64_t)N * D, s));
+        LAUNCH(c, s, "mocha_to_bf16", "bank.to_bf16", 0.0, 6.0 * N * D, launch_to_bf16(c->bank_cnt, c->bank_center, (int)D, c->bank_bf16, (int64_t)N * D, s));
         LAUNCH(c, s, "mocha_rownorm2_bf16", "bank.norms", 2.0 * N * D, 2.0 * N * D, launch_rownorm2_bf16(c->bank_bf16, c->bank_norm, N, (int)D, s));
     } else {
-        LAUNCH(c, s, "mocha_rownorm2", "bank.norms", 2.0 * N * D, 4.0 * N * D, launch_rownorm2(c->bank_cnt, c->bank_norm, N, (int)D, s));
+        LAUNCH(c, s, "mocha_rownorm2", "bank.norms", 2.0 * N * D, 4.0 * N * D, launch_rownorm2(c->bank_cnt, c->bank_center, c->bank_norm, N, (int)D, s));
     }
     return 0;
 }
@@ -982,6 +1014,61 @@ int mocha_characterize(mocha_ctx* c, const float* src_X, int B, const float* cnt
 int mocha_characterize_raw(mocha_ctx* c, const float* src_X_raw, int B, const float* cnt_mean, const float* cnt_std, float* Y,
                            int32_t* idx, void* stream) {
     return characterize_impl(c, src_X_raw, B, cnt_mean, cnt_std, Y, idx, stream, true);
+}
+
+// Demo pair in one pass (test_fullframework.py:188-194 for both clips, then :293-296, 438-443, 465-467): the character clip
+// becomes the bank, the source clip is characterized against it.  Both clips go through mot_embedding / encoder / cnt in the
+// same launches (twice the tiles per launch: less tile rounding, fewer prologue / epilogue phases); the bank lives in the
+// workspace for the duration of the call and the context's own bank (mocha_bank_set) is left untouched.
+static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, const float* cha_X, int B_cha, const float* cnt_mean,
+                                  const float* cnt_std, float* Y, int32_t* idx, float* cha_encoded, float* cha_cnt_nm, void* stream,
+                                  bool raw) {
+    if (!c) return MOCHA_ERR_ARG;
+    if (B_src < 0 || B_cha < 1) return fail(c, MOCHA_ERR_ARG, "characterize_pair: needs B_src >= 0 and B_cha >= 1");
+    const long long total = (long long)B_src + B_cha;
+    if (total > c->max_chunk)
+        return fail(c, MOCHA_ERR_ARG, "characterize_pair: %lld windows exceed the workspace limit of %d (raise it with mocha_reserve, or "
+                    "use mocha_encode + mocha_bank_set + mocha_characterize)", total, c->max_chunk);
+    int rc = ready(c, (int)total); if (rc) return rc;
+    if (!cnt_mean || !cnt_std || !cha_X || (B_src > 0 && (!src_X || !Y))) return fail(c, MOCHA_ERR_ARG, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    c->cur = 0;
+    const size_t T = 90 * 256;
+    const int B = (int)total;
+    // character windows first: rows [0, B_cha) of every buffer are the bank, rows [B_cha, B) the queries
+    if ((rc = run_embed(c, cha_X, B_cha, WS(c, "x5"), true, s, raw, src_X, B_src))) return rc;
+    if ((rc = run_encoder(c, WS(c, "x5"), B, WS(c, "enc_s"), s))) return rc;
+    LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * 3,
+           launch_instnorm(WS(c, "enc_s"), WS(c, "cnt"), nullptr, cnt_mean, cnt_std, WS(c, "qnm"), B, 90, s));
+    if (cha_encoded) HIPCHK(c, hipMemcpyAsync(cha_encoded, WS(c, "enc_s"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (cha_cnt_nm) HIPCHK(c, hipMemcpyAsync(cha_cnt_nm, WS(c, "qnm"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (B_src == 0) return 0;
+    // transient bank: swap the context's bank state out, borrow the workspace rows, restore afterwards
+    struct Saved { const float *cnt, *enc; int64_t N; bool bf16; float* norm; size_t norm_cap; } sv{c->bank_cnt, c->bank_enc, c->bank_N,
+                                                                                                c->bank_is_bf16, c->bank_norm, c->bank_norm_cap};
+    c->bank_norm = c->pair_norm; c->bank_norm_cap = c->pair_norm_cap;
+    rc = mocha_bank_set(c, WS(c, "qnm"), WS(c, "enc_s"), B_cha, MOCHA_BANK_BORROW, stream);
+    int32_t* ix = idx ? idx : c->idx_ws[0];
+    if (!rc) rc = do_match(c, WS(c, "qnm") + (size_t)B_cha * T, B_src, ix, nullptr, s);
+    if (!rc) rc = [&]() -> int {
+        LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, B_src * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), B_src, 90 * 256, s));
+        return 0;
+    }();
+    c->pair_norm = c->bank_norm; c->pair_norm_cap = c->bank_norm_cap;
+    c->bank_cnt = sv.cnt; c->bank_enc = sv.enc; c->bank_N = sv.N; c->bank_is_bf16 = sv.bf16; c->bank_norm = sv.norm; c->bank_norm_cap = sv.norm_cap;
+    if (rc) return rc;
+    if ((rc = run_decoder(c, WS(c, "enc_s") + (size_t)B_cha * T, WS(c, "sel"), B_src, WS(c, "dec"), s))) return rc;
+    return run_to_mot(c, WS(c, "dec"), B_src, Y, s, raw);
+}
+
+int mocha_characterize_pair(mocha_ctx* c, const float* src_X, int B_src, const float* cha_X, int B_cha, const float* cnt_mean,
+                            const float* cnt_std, float* Y, int32_t* idx, float* cha_encoded, float* cha_cnt_nm, void* stream) {
+    return characterize_pair_impl(c, src_X, B_src, cha_X, B_cha, cnt_mean, cnt_std, Y, idx, cha_encoded, cha_cnt_nm, stream, false);
+}
+
+int mocha_characterize_pair_raw(mocha_ctx* c, const float* src_X_raw, int B_src, const float* cha_X_raw, int B_cha, const float* cnt_mean,
+                                const float* cnt_std, float* Y, int32_t* idx, float* cha_encoded, float* cha_cnt_nm, void* stream) {
+    return characterize_pair_impl(c, src_X_raw, B_src, cha_X_raw, B_cha, cnt_mean, cnt_std, Y, idx, cha_encoded, cha_cnt_nm, stream, true);
 }
 
 int mocha_set_pose_norm(mocha_ctx* c, const float* x_mean, const float* x_std, const float* y_mean, const float* y_std) {

@@ -335,13 +335,16 @@ hipError_t launch_window_sums(const float* y, float* u, int rows, hipStream_t s)
 // ---------------------------------------------------------------------------------------
 // bank utilities
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mocha_rownorm2(const float* __restrict__ x, float* __restrict__ out, int cols) {
+// out[row] = ||x[row] - sub||^2 (sub may be null)
+__global__ __launch_bounds__(256) void mocha_rownorm2(const float* __restrict__ x, const float* __restrict__ sub, float* __restrict__ out,
+                                                      int cols) {
     __shared__ float red[4];
     const size_t row = blockIdx.x;
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * cols);
     float a = 0.f;
     for (int i = threadIdx.x; i < cols / 4; i += 256) {
-        const f32x4 v = xr[i];
+        f32x4 v = xr[i];
+        if (sub) v -= reinterpret_cast<const f32x4*>(sub)[i];
         a = fmaf(v[0], v[0], a); a = fmaf(v[1], v[1], a); a = fmaf(v[2], v[2], a); a = fmaf(v[3], v[3], a);
     }
     a = wave_sum(a);
@@ -350,78 +353,117 @@ __global__ __launch_bounds__(256) void mocha_rownorm2(const float* __restrict__ 
     if (threadIdx.x == 0) out[row] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-hipError_t launch_rownorm2(const float* x, float* out, int64_t rows, int cols, hipStream_t s) {
+hipError_t launch_rownorm2(const float* x, const float* sub, float* out, int64_t rows, int cols, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (cols % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_rownorm2, dim3((unsigned)rows), dim3(256), 0, s, x, out, cols);
+    hipLaunchKernelGGL(mocha_rownorm2, dim3((unsigned)rows), dim3(256), 0, s, x, sub, out, cols);
     return hipGetLastError();
 }
 
-// argmin over the bank of ||b||^2 - 2 q·b (||q||^2 is constant per query), ties to the lowest
-// index; then the Euclidean distance to the winner in the direct (q-b)^2 form.
-// (semantics of BallTree.query(k=1), test_fullframework.py:296,443)
+// out[row] = x[row] - sub   (queries centred on the bank centroid)
+__global__ __launch_bounds__(256) void mocha_sub_rows(const float* __restrict__ x, const float* __restrict__ sub, float* __restrict__ out,
+                                                      int cols4) {
+    const size_t row = blockIdx.x;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x) + row * cols4;
+    f32x4* o = reinterpret_cast<f32x4*>(out) + row * cols4;
+    for (int i = threadIdx.x; i < cols4; i += 256) o[i] = xr[i] - reinterpret_cast<const f32x4*>(sub)[i];
+}
+
+hipError_t launch_sub_rows(const float* x, const float* sub, float* out, int64_t rows, int cols, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (cols % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_sub_rows, dim3((unsigned)rows), dim3(256), 0, s, x, sub, out, cols / 4);
+    return hipGetLastError();
+}
+
+// 1-NN from the score matrix S = (q - c)·(b - c)^T of the GEMM path (c = bank centroid, bnorm = ||b - c||^2):
+//   1. the RERANK smallest approximate scores ||b-c||^2 - 2 (q-c)·(b-c) in (value, index) order — fp32 GEMM sums over 23 040
+//      terms carry an error of ~1e-5 of the centred norms, which can exceed the gap between near-duplicate bank rows
+//      (consecutive windows of one clip);
+//   2. their exact squared distances in the direct (q-b)^2 form; the smallest wins, ties to the lowest index
+// (semantics of BallTree.query(k=1), test_fullframework.py:296,443).  qexact / bank (or bank16) are the operands of the
+// direct form: the original fp32 rows, or the centred queries and the centred bf16 bank.
+static constexpr int RERANK = 4;
+
 __global__ __launch_bounds__(256) void mocha_argmin(const float* __restrict__ S, int ksplit, long long slab_stride,
                                                     int lds, const float* __restrict__ bnorm,
-                                                    const float* __restrict__ query, const float* __restrict__ bank,
+                                                    const float* __restrict__ qexact, const float* __restrict__ bank,
                                                     const unsigned short* __restrict__ bank16,
                                                     long long N, int D, int32_t* __restrict__ idx,
                                                     float* __restrict__ dist) {
     __shared__ float rv[4];
     __shared__ int ri[4];
-    __shared__ int win;
+    __shared__ float cand_v;
+    __shared__ int cand_i;
     const int q = blockIdx.x, tid = threadIdx.x;
-    float best = INFINITY;
-    int bi = 0x7fffffff;
-    for (long long nn = tid; nn < N; nn += 256) {
-        float dot = 0.f;
-        for (int z = 0; z < ksplit; ++z) dot += S[(size_t)z * slab_stride + (size_t)q * lds + nn];
-        const float v = bnorm[nn] - 2.f * dot;
-        if (v < best) { best = v; bi = (int)nn; }       // strided ascending: first hit is the lowest index
-    }
+    float prev_v = -INFINITY;
+    int prev_i = -1;
+    float best_d = INFINITY;
+    int best_i = 0x7fffffff;
+    const int rounds = N < RERANK ? (int)N : RERANK;
+    for (int round = 0; round < rounds; ++round) {
+        // next (value, index) after (prev_v, prev_i) in lexicographic order
+        float best = INFINITY;
+        int bi = 0x7fffffff;
+        for (long long nn = tid; nn < N; nn += 256) {
+            float dot = 0.f;
+            for (int z = 0; z < ksplit; ++z) dot += S[(size_t)z * slab_stride + (size_t)q * lds + nn];
+            const float v = bnorm[nn] - 2.f * dot;
+            const bool after = v > prev_v || (v == prev_v && (int)nn > prev_i);
+            if (after && (v < best || (v == best && (int)nn < bi))) { best = v; bi = (int)nn; }
+        }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(best, o);
-        const int oi = __shfl_xor(bi, o);
-        if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float b = rv[0]; int i = ri[0];
+            for (int w = 1; w < 4; ++w)
+                if (rv[w] < b || (rv[w] == b && ri[w] < i)) { b = rv[w]; i = ri[w]; }
+            cand_v = b; cand_i = i;
+        }
+        __syncthreads();
+        prev_v = cand_v; prev_i = cand_i;
+        if (prev_i == 0x7fffffff) break;                 // fewer finite candidates than rounds (uniform)
+        // exact squared distance of this candidate
+        float a = 0.f;
+        if (bank16) {
+            const unsigned short* b16 = bank16 + (size_t)prev_i * D;
+            for (int i = tid; i < D; i += 256) {
+                const float d = qexact[(size_t)q * D + i] - __uint_as_float((unsigned)b16[i] << 16);
+                a = fmaf(d, d, a);
+            }
+        } else {
+            const f32x4* qr = reinterpret_cast<const f32x4*>(qexact + (size_t)q * D);
+            const f32x4* br = reinterpret_cast<const f32x4*>(bank + (size_t)prev_i * D);
+            for (int i = tid; i < D / 4; i += 256) {
+                const f32x4 d = qr[i] - br[i];
+                a = fmaf(d[0], d[0], a); a = fmaf(d[1], d[1], a); a = fmaf(d[2], d[2], a); a = fmaf(d[3], d[3], a);
+            }
+        }
+        a = wave_sum(a);
+        __syncthreads();
+        if ((tid & 63) == 0) rv[tid >> 6] = a;
+        __syncthreads();
+        const float d2 = (rv[0] + rv[1]) + (rv[2] + rv[3]);
+        if (d2 < best_d || (d2 == best_d && prev_i < best_i)) { best_d = d2; best_i = prev_i; }
+        __syncthreads();
     }
-    if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
-    __syncthreads();
     if (tid == 0) {
-        float b = rv[0]; int i = ri[0];
-        for (int w = 1; w < 4; ++w)
-            if (rv[w] < b || (rv[w] == b && ri[w] < i)) { b = rv[w]; i = ri[w]; }
-        win = i;
-        idx[q] = i;
+        idx[q] = best_i;
+        if (dist) dist[q] = sqrtf(best_d);
     }
-    __syncthreads();
-    if (!dist) return;
-    const f32x4* qr = reinterpret_cast<const f32x4*>(query + (size_t)q * D);
-    const f32x4* br = reinterpret_cast<const f32x4*>(bank + (size_t)win * D);
-    float a = 0.f;
-    if (bank16) {                                   // distance to the bf16-rounded entry that was matched
-        const unsigned short* b16 = bank16 + (size_t)win * D;
-        for (int i = tid; i < D; i += 256) {
-            const float d = query[(size_t)q * D + i] - __uint_as_float((unsigned)b16[i] << 16);
-            a = fmaf(d, d, a);
-        }
-    } else {
-        for (int i = tid; i < D / 4; i += 256) {
-            const f32x4 d = qr[i] - br[i];
-            a = fmaf(d[0], d[0], a); a = fmaf(d[1], d[1], a); a = fmaf(d[2], d[2], a); a = fmaf(d[3], d[3], a);
-        }
-    }
-    a = wave_sum(a);
-    __syncthreads();
-    if ((tid & 63) == 0) rv[tid >> 6] = a;
-    __syncthreads();
-    if (tid == 0) dist[q] = sqrtf((rv[0] + rv[1]) + (rv[2] + rv[3]));
 }
 
 hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm,
-                         const float* query, const float* bank, const void* bank16, int Q, int64_t N, int D, int32_t* idx,
+                         const float* qexact, const float* bank, const void* bank16, int Q, int64_t N, int D, int32_t* idx,
                          float* dist, hipStream_t s) {
     if (Q <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mocha_argmin, dim3(Q), dim3(256), 0, s, S, ksplit, slab_stride, lds, bnorm, query, bank,
+    hipLaunchKernelGGL(mocha_argmin, dim3(Q), dim3(256), 0, s, S, ksplit, slab_stride, lds, bnorm, qexact, bank,
                        (const unsigned short*)bank16, (long long)N, D, idx, dist);
     return hipGetLastError();
 }
@@ -458,6 +500,10 @@ __global__ __launch_bounds__(256) void mocha_column_stats(const float* __restric
     s1[w][lane] = a;
     __syncthreads();
     const double m = ((s1[0][lane] + s1[1][lane]) + (s1[2][lane] + s1[3][lane])) / (double)N;
+    if (!sd) {                                         // mean only (bank centroid); uniform per launch
+        if (w == 0) mean[col] = (float)m;
+        return;
+    }
     double q = 0.0;
     for (long long n = w; n < N; n += 4) { const double d = (double)x[(size_t)n * cols + col] - m; q += d * d; }
     s2[w][lane] = q;

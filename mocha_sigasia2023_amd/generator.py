@@ -290,6 +290,30 @@ class Generator:
         self._ctx.call("mocha_featurize", _ptr(r), _ptr(ps[0]), _ptr(ps[1]), _ptr(ps[2]), B, _ptr(X), _stream())
         return X
 
+    def characterize_pair(self, src_X, cha_X, cnt_mean, cnt_std, return_index: bool = False, return_bank: bool = False,
+                          raw: bool = False):
+        """The demo pair in one pass: the character clip becomes the bank and the source clip is characterized against
+        it — ``encode(cha)`` + ``ContextBank`` + ``characterize(src)`` with both clips sharing every launch of
+        mot_embedding / encoder / cnt (test_fullframework.py:188-194, 271-277, 293-296, 438-443, 465-467).  The bank is
+        transient; ``return_bank`` also returns (cha_encoded, cha_cnt_nm) for a later ``ContextBank``.
+        Result order: Y[, idx][, cha_encoded, cha_cnt_nm]."""
+        self._need()
+        conv = (lambda X, n: self._xraw(X, n)) if raw else (lambda X, n: self._x(X, n))
+        s, c = conv(src_X, "src_X"), conv(cha_X, "cha_X")
+        mean = _dev_f32(cnt_mean, self.device, (NTOK, DIM), "cnt_mean")
+        std = _dev_f32(cnt_std, self.device, (NTOK, DIM), "cnt_std")
+        Bs, Bc = s.shape[0], c.shape[0]
+        Y = torch.empty((Bs, self.cfg["nframes"], self.V, self.cfg["mot_in_dim"]), dtype=torch.float32, device=self.device)
+        idx = torch.empty((Bs,), dtype=torch.int32, device=self.device)
+        enc = nm = None
+        if return_bank:
+            enc = torch.empty((Bc, NTOK, DIM), dtype=torch.float32, device=self.device)
+            nm = torch.empty_like(enc)
+        self._ctx.call("mocha_characterize_pair_raw" if raw else "mocha_characterize_pair", _ptr(s), Bs, _ptr(c), Bc, _ptr(mean), _ptr(std),
+                       _ptr(Y), _ptr(idx), _ptr(enc) if return_bank else None, _ptr(nm) if return_bank else None, _stream())
+        out = (Y,) + ((idx,) if return_index else ()) + ((enc, nm) if return_bank else ())
+        return out[0] if len(out) == 1 else out
+
     def _xraw(self, X, name):
         return _dev_f32(X, self.device, (self.cfg["nframes"], self.V + 1, self.cfg["mot_in_dim"]), name)
 

@@ -70,10 +70,14 @@ def test_single_window_and_one_entry_bank(model):
 
 
 def test_batch_not_a_multiple_of_the_chunk(model):
-    """1 031 windows with the default 1 024-window chunk: a 7-window tail goes through the skinny kernels."""
+    """1 031 windows with a 512-window chunk: two full chunks and a 7-window tail that goes through the skinny kernels."""
     mean, std = _norm()
     X = torch.from_numpy(synthetic.pose_windows(8, 1031)).cuda()
-    enc, cnt, nm = model.encode(X, mean, std)
+    model.reserve(512)
+    try:
+        enc, cnt, nm = model.encode(X, mean, std)
+    finally:
+        model.reserve(1280)
     e2, c2, n2 = model.encode(X[1020:].contiguous(), mean, std)
     assert float((enc[1020:] - e2).abs().max()) < 3e-6 * float(e2.abs().max())
     assert torch.isfinite(enc).all()

@@ -194,11 +194,35 @@ def test_streaming_matcher(golden_dir, Q, bf16):
     cha_nm, src_nm = O.znorm(cha, mean, std), O.znorm(src, mean, std)
     bank = ContextBank(model, T(cha_nm), T(cha), bf16=bf16)
     dist, idx = bank.query(T(src_nm), k=1)
-    ref_bank = _bf16_round(np.ascontiguousarray(cha_nm)) if bf16 else cha_nm
-    ridx, rdist = O.match_bruteforce(src_nm, ref_bank)
+    if bf16:       # the bf16 bank stores bf16(b - centroid); queries are centred the same way (distances are translation invariant)
+        c = cha_nm.astype(np.float64).mean(0).astype(np.float32)
+        ridx, rdist = O.match_bruteforce(src_nm - c, _bf16_round(np.ascontiguousarray(cha_nm - c)))
+    else:
+        ridx, rdist = O.match_bruteforce(src_nm, cha_nm)
     assert np.array_equal(idx[:, 0].cpu().numpy().astype(np.int64), ridx)
     assert np.allclose(dist[:, 0].cpu().numpy(), rdist, rtol=1e-5)
     assert idx[0, 0].item() == nb - 1
+
+
+@pytest.mark.parametrize("Q", [1, 5, 8, 9, 37, 200])
+def test_matcher_ranks_near_duplicate_rows_far_from_the_origin(Q):
+    """The hard case for an fp32 matcher: one character's bank rows sit close together far from the origin
+    (||b||^2 ~ 2e5, nearest-neighbour gaps ~ 1e-2 in d^2), where ||b||^2 - 2 q.b cannot rank in fp32.  The scan evaluates
+    (q-b)^2 directly and the GEMM path centres its operands and re-ranks its best candidates exactly: indices must equal the
+    float64 brute-force search for every query count (scan: Q <= 8, GEMM: Q > 8)."""
+    _, _, model, _ = load(os.path.join(os.path.dirname(__file__), "golden"), "mocha24_g1")
+    r = np.random.Generator(np.random.PCG64(77))
+    N = 157
+    offset = (3.0 * r.standard_normal((1, 90 * 256))).astype(np.float32)
+    bank = (offset + 0.02 * r.standard_normal((N, 90 * 256))).astype(np.float32).reshape(N, 90, 256)
+    q = (offset + 0.02 * r.standard_normal((Q, 90 * 256))).astype(np.float32).reshape(Q, 90, 256)
+    q[0] = bank[N - 1] + 0.001 * r.standard_normal((90, 256)).astype(np.float32)
+    ridx, rdist = O.match_bruteforce(q, bank)                      # float64
+    b = ContextBank(model, T(bank), T(bank))
+    dist, idx = b.query(T(q), k=1)
+    assert np.array_equal(idx[:, 0].cpu().numpy().astype(np.int64), ridx)
+    assert np.allclose(dist[:, 0].cpu().numpy(), rdist, rtol=2e-4)
+    assert idx[0, 0].item() == N - 1
 
 
 def test_bf16_bank_many_queries_agrees_with_fp32():
@@ -297,3 +321,39 @@ def test_decoder_projection_folding_is_only_rounding(golden_dir, name):
     assert rel(folded, z["decoded"]) < RTOL and rel(literal, z["decoded"]) < RTOL
     assert not torch.equal(folded, literal)                      # the option really switches the kernel chain
     assert float((folded - literal).abs().max()) < 1e-5 * float(literal.abs().max())
+
+
+def test_characterize_pair_matches_the_three_call_path():
+    """mocha_characterize_pair = encode(cha) + bank_set + characterize(src) with shared launches: same indices, outputs equal
+    up to the kernel choice of a larger batch (<= 2e-6 relative), the context's own bank untouched, oracle parity."""
+    sd = weights.synthetic_state_dict(21, 1.2)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    mean, std = synthetic.cnt_norm(4)
+    src, cha = T(synthetic.pose_windows(5, 37)), T(synthetic.pose_windows(6, 53))
+    enc_c, _, nm_c = model.encode(cha, mean, std)
+    bank = ContextBank(model, nm_c.clone(), enc_c.clone())
+    Y1, i1 = bank.characterize(src, mean, std, return_index=True)
+    other = ContextBank(model, nm_c[:5].clone(), enc_c[:5].clone())              # the context's own bank before the pair call
+    other.activate()
+    Y2, i2, enc2, nm2 = model.characterize_pair(src, cha, mean, std, return_index=True, return_bank=True)
+    assert torch.equal(i1, i2)
+    scale = max(1.0, float(Y1.abs().max()))
+    assert float((Y1 - Y2).abs().max()) < 2e-6 * scale
+    assert float((enc2 - enc_c).abs().max()) < 3e-6 * float(enc_c.abs().max())
+    assert float((nm2 - nm_c).abs().max()) < 3e-5 * float(nm_c.abs().max())
+    d, i = other.query(nm_c[:5], k=1)                                            # still the 5-entry bank
+    assert i[:, 0].tolist() == [0, 1, 2, 3, 4]
+    ost = O.to_torch_state(sd)
+    with torch.no_grad():
+        Yo, io = O.characterize(ost, src.cpu(), cha.cpu(), mean, std)
+        # random windows give near-equidistant bank rows: where the arg-min differs from the oracle's, it must be a tie to fp32 rounding
+        qs = O.znorm(O.encode(ost, src.cpu())[1].numpy(), mean, std).reshape(len(src), -1).astype(np.float64)
+        ks = O.znorm(O.encode(ost, cha.cpu())[1].numpy(), mean, std).reshape(len(cha), -1).astype(np.float64)
+    ours = i2.cpu().numpy()
+    d_ours = np.sqrt(((qs - ks[ours]) ** 2).sum(1)); d_best = np.sqrt(((qs - ks[io]) ** 2).sum(1))
+    assert np.all(d_ours <= d_best * (1 + 1e-9))
+    same = ours == io
+    assert same.all()
+    assert absmax(Y2[torch.from_numpy(same).to(Y2.device)], Yo.numpy()[same]) < TOL * max(1.0, float(Yo.abs().max()))
+    with pytest.raises(RuntimeError, match="workspace limit"):
+        model.characterize_pair(T(synthetic.pose_windows(7, 700)), T(synthetic.pose_windows(8, 700)), mean, std)

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""A/B of the demo-pair step: three calls (encode cha, bank, characterize src) vs mocha_characterize_pair."""
+import sys, time, torch
+sys.path.insert(0, __file__.rsplit('/', 2)[0])
+from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, synthetic_state_dict
+dev = torch.device('cuda:0')
+for V, layout in ((22, 'mixamo'), (24, 'mocha')):
+    model = Generator(layout=layout, device=dev).load_state_dict(synthetic_state_dict(1777, 1.0, layout)).eval()
+    W = 585
+    src = torch.from_numpy(synthetic.pose_windows(1, W, V)).to(dev); cha = torch.from_numpy(synthetic.pose_windows(2, W, V)).to(dev)
+    m_, s_ = synthetic.cnt_norm(7); mean, std = torch.from_numpy(m_).to(dev), torch.from_numpy(s_).to(dev)
+    def three():
+        enc_c, cnt_c, nm_c = model.encode(cha, mean, std)
+        return ContextBank(model, nm_c, enc_c).characterize(src, mean, std, return_index=True)
+    def pair():
+        return model.characterize_pair(src, cha, mean, std, return_index=True)
+    Y1, i1 = three(); Y2, i2 = pair()
+    print(f"V={V}: idx equal {bool(torch.equal(i1, i2))}, max |dY| {float((Y1 - Y2).abs().max()):.2e}")
+    for name, fn in (("three-call", three), ("pair", pair), ("three-call", three), ("pair", pair)):
+        for _ in range(3): fn()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(20): fn()
+        torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 20 * 1e3
+        print(f"  {name:10s}: {ms:.3f} ms/step  {W / ms * 1e3:.0f} frames/s")
