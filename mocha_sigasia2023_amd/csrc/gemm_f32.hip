@@ -32,6 +32,16 @@ static constexpr int BM = 128;
 static constexpr int BK = 32;
 static constexpr int LDSK = BK + 4;
 
+// 16-byte buffer load: base in SGPRs (resource), per-lane 32-bit byte offset, per-slab scalar byte offset.  Measured in
+// tools/mfma_probe.hip: global_load_dwordx4 with 64-bit VGPR addresses costs the K loop 11-17 % of the matrix pipe (one
+// 64-bit VALU add per load on top of the load's own issue); the same loads as buffer loads cost 6-13 %.
+__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);     // raw buffer, 2 GiB window, no swizzle
+}
+
 __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * x; }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -73,8 +83,13 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
     // ---- loader: 8 threads cover one 128-byte row segment of a slab
     const int lrow = tid >> 3;
     const int lcol = (tid & 7) * 4;
+    // plain A: the resource starts at the tile's first row, lane offsets are (row - m0) * lda + lcol (always < 2 GiB);
+    // gathered A: the resource is the whole source tensor (checked < 2 GiB on the host), lane offsets are recomputed per tap;
+    // W: the resource starts at the tile's first weight row.
     int a_rb[NA], a_t[NA];
-    const float* wrow[NB];
+    unsigned a_off[NA], w_off[NB];
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.gather ? p.A : p.A + (size_t)(m0 < p.M ? m0 : 0) * p.lda);
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.W + (size_t)n0 * p.K);
     {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -87,16 +102,18 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
                 const int b = bt / p.T_out;
                 a_rb[i] = b * p.T_src * p.V + v;
                 a_t[i] = t;
+                a_off[i] = 0;
             } else {
                 a_rb[i] = m;
                 a_t[i] = 0;
+                a_off[i] = ((unsigned)(m - m0) * (unsigned)p.lda + lcol) * 4u;
             }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             int n = n0 + lrow + 32 * i;
             n = n < p.N ? n : p.N - 1;
-            wrow[i] = p.W + (size_t)n * p.K + lcol;
+            w_off[i] = ((unsigned)(n - n0) * (unsigned)p.K + lcol) * 4u;
         }
     }
 
@@ -105,11 +122,10 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
         const int k0 = s * BK;
         if (!p.gather) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i)
-                ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)a_rb[i] * p.lda + k0 + lcol);
+            for (int i = 0; i < NA; ++i) ra[i] = bload(rsA, a_off[i], (unsigned)k0 * 4u);
         } else {
             const int tap = k0 / p.Cc;
-            const int c0 = k0 - tap * p.Cc + lcol;
+            const unsigned c0 = (unsigned)(k0 - tap * p.Cc + lcol) * 4u;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
                     tf = tf < 0 ? -tf : tf;
                     tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
                     const int row = a_rb[i] + (tf >> p.tshift) * p.V;
-                    acc4 += *reinterpret_cast<const f32x4*>(p.A + (size_t)row * p.lda + c0);
+                    acc4 += bload(rsA, (unsigned)row * (unsigned)p.lda * 4u + c0, 0u);
                 }
                 ra[i] = p.R > 1 ? acc4 * p.ascale : acc4;
             }
@@ -131,7 +147,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + k0);
+        for (int i = 0; i < NB; ++i) rb[i] = bload(rsW, w_off[i], (unsigned)k0 * 4u);
         if (p.wsub) {                               // matcher: bank rows are centred on the fly (the bank itself may be borrowed)
             const f32x4 cv = *reinterpret_cast<const f32x4*>(p.wsub + k0 + lcol);
 #pragma unroll
@@ -371,6 +387,9 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (p.K % BK != 0) return hipErrorInvalidValue;
     if (p.gather && (p.Cc % BK != 0)) return hipErrorInvalidValue;
+    // 32-bit buffer offsets: a gathered source is addressed from its base, a tile of plain A / W from the tile's first row
+    if (p.gather && (long long)p.M / p.T_out * p.T_src * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
+    if (128ll * p.lda * 4 >= (1ll << 31) || 128ll * p.K * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     if (gemm_is_skinny(p)) {
         dim3 grid(((p.M + 31) / 32) * ((p.N + 31) / 32));
         hipLaunchKernelGGL(mocha_gemm_skinny, grid, dim3(256), 0, s, p);

@@ -28,14 +28,33 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float*
     const int lrow = tid >> 3, lcol = (tid & 7) * 4;
     const float* gp = g + ((size_t)blockIdx.x * 192 + lrow) * ld + lcol;
     f32x4 ra[NA], rb[NB];
+    f32x4 ra5[MODE == 5 ? 4 : 1][NA], rb5[MODE == 5 ? 4 : 1][NB];
     f32x4 a[TM], b[TN];
     if (MODE == 0) { for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(Ab + i * 32 * LDSK); for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(Bb + j * 32 * LDSK); }
+    // buffer resource over the whole g allocation (MODE 4): base in SGPRs, 32-bit byte offsets in VGPRs
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0x7fffffff, 0x00020000);
+    const unsigned boff = (unsigned)((((size_t)blockIdx.x * 192 + lrow) * ld + lcol) * 4);
     for (int s = 0; s < slabs; ++s) {
-        if (MODE >= 3) {
+        if (MODE == 3 || MODE == 6) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) ra[i] = *(const f32x4*)(gp + (size_t)(32 * i) * ld + (s & 7) * 32);
 #pragma unroll
             for (int i = 0; i < NB; ++i) rb[i] = *(const f32x4*)(gp + (size_t)(128 + 32 * i) * ld + (s & 7) * 32);
+        }
+        if (MODE == 4) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) { auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, boff + (unsigned)((32 * i) * ld + (s & 7) * 32) * 4, 0, 0); ra[i] = *(f32x4*)&v; }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) { auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, boff + (unsigned)((128 + 32 * i) * ld + (s & 7) * 32) * 4, 0, 0); rb[i] = *(f32x4*)&v; }
+        }
+        if (MODE == 5 && wave == 0) {      // one wave fetches the whole slab (4x the loads), the others only multiply
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) ra5[w][i] = *(const f32x4*)(gp + (size_t)(32 * i + w * 8) * ld + (s & 7) * 32);
+#pragma unroll
+                for (int i = 0; i < NB; ++i) rb5[w][i] = *(const f32x4*)(gp + (size_t)(128 + 32 * i + w * 8) * ld + (s & 7) * 32);
+            }
         }
 #pragma unroll
         for (int kg = 0; kg < 4; ++kg) {
@@ -53,11 +72,20 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float*
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][ks], a[i][ks], acc[i][j], 0, 0, 0);
         }
         if (MODE >= 2) __syncthreads();
-        if (MODE >= 3) {
+        if (MODE == 3 || MODE == 4 || MODE == 6) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) *(f32x4*)(As + (lrow + 32 * i) * LDSK + lcol) = ra[i];
 #pragma unroll
             for (int i = 0; i < NB; ++i) *(f32x4*)(Bs + (lrow + 32 * i) * LDSK + lcol) = rb[i];
+        }
+        if (MODE == 5 && wave == 0) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) *(f32x4*)(As + (lrow + 32 * i + w * 8) * LDSK + lcol) = ra5[w][i];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) *(f32x4*)(Bs + (lrow + 32 * i + w * 8) * LDSK + lcol) = rb5[w][i];
+            }
         }
         if (MODE >= 2) __syncthreads();
     }
@@ -167,10 +195,14 @@ int main() {
         run<2, 2, 1>("2x2 + ds_read_b128 operands", occ, g, out, ld);
         run<2, 2, 2>("2x2 + ds_read + 2 barriers/slab", occ, g, out, ld);
         if (occ <= 3) run<2, 2, 3>("2x2 + ds_read + barriers + global->LDS", occ, g, out, ld);
+        if (occ <= 3) run<2, 2, 4>("2x2 ... with buffer_load (SGPR base)", occ, g, out, ld);
+        if (occ <= 2) run<2, 2, 5>("2x2 ... all loads from wave 0", occ, g, out, ld);
         run<1, 2, 0>("1x2 tiles/wave, registers only", occ, g, out, ld);
         run<1, 2, 1>("1x2 + ds_read_b128 operands", occ, g, out, ld);
         run<1, 2, 2>("1x2 + ds_read + 2 barriers/slab", occ, g, out, ld);
         run<1, 2, 3>("1x2 + ds_read + barriers + global->LDS", occ, g, out, ld);
+        run<1, 2, 4>("1x2 ... with buffer_load (SGPR base)", occ, g, out, ld);
+        if (occ <= 3) run<1, 2, 5>("1x2 ... all loads from wave 0", occ, g, out, ld);
     }
     return 0;
 }
