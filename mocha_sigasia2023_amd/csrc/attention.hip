@@ -13,6 +13,7 @@
 //      leaves the register file.  V is staged through LDS 64 head-dims at a time.
 // Tokens are padded 90 -> 96 with zero rows; padded keys are masked to -inf.
 #include "kernels.h"
+#include "device_utils.h"
 
 namespace mocha {
 
@@ -45,6 +46,8 @@ __global__ __launch_bounds__(NQW * 64) void mocha_attention_f32(AttnParams p) {
     const float* qg = p.q + (size_t)b * nq * p.ldq + head * DH;
     const float* kg = p.k + (size_t)b * nk * p.ldk + head * (p.hsk < 0 ? DH : p.hsk);
     const float* vg = p.v + (size_t)b * nk * p.ldv + head * (p.hsv < 0 ? DH : p.hsv);
+    // operand fetches as buffer loads: (window, head) base in SGPRs, 32-bit lane offsets (<= 192 rows x ld x 4 B)
+    const __amdgpu_buffer_rsrc_t rsq = make_rsrc(qg), rsk = make_rsrc(kg), rsv = make_rsrc(vg);
 
     // ---------------- phase 1: S^T[key][query] over DH in chunks of 32
     f32x16 st[NKT];
@@ -62,14 +65,14 @@ __global__ __launch_bounds__(NQW * 64) void mocha_attention_f32(AttnParams p) {
             const int f = tid + NTHR * i;
             const int row = f >> 3, c4 = (f & 7) * 4;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            kr[i] = row < nk ? *reinterpret_cast<const f32x4*>(kg + (size_t)row * p.ldk + c * 32 + c4) : z;
+            kr[i] = row < nk ? bload(rsk, (unsigned)(row * p.ldk + c4) * 4u, (unsigned)c * 128u) : z;
         }
 #pragma unroll
         for (int i = 0; i < QPT; ++i) {
             const int f = tid + NTHR * i;
             const int row = f >> 3, c4 = (f & 7) * 4;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            qr[i] = row < nq ? *reinterpret_cast<const f32x4*>(qg + (size_t)row * p.ldq + c * 32 + c4) : z;
+            qr[i] = row < nq ? bload(rsq, (unsigned)(row * p.ldq + c4) * 4u, (unsigned)c * 128u) : z;
         }
     };
     auto stage_kq = [&]() __attribute__((always_inline)) {
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(NQW * 64) void mocha_attention_f32(AttnParams p) {
             const int f = tid + NTHR * i;
             const int row = f >> 4, c4 = (f & 15) * 4;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            vr[i] = row < nk ? *reinterpret_cast<const f32x4*>(vg + (size_t)row * p.ldv + dp * DV + c4) : z;
+            vr[i] = row < nk ? bload(rsv, (unsigned)(row * p.ldv + c4) * 4u, (unsigned)dp * (DV * 4u)) : z;
         }
     };
     auto stage_v = [&]() __attribute__((always_inline)) {

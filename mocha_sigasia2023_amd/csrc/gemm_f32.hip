@@ -22,6 +22,7 @@
 // The A operand can be gathered on the fly (temporal conv as GEMM, reflect padding, folded
 // average pooling / nearest upsampling), see kernels.h.
 #include "kernels.h"
+#include "device_utils.h"
 
 namespace mocha {
 
@@ -31,16 +32,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int BM = 128;
 static constexpr int BK = 32;
 static constexpr int LDSK = BK + 4;
-
-// 16-byte buffer load: base in SGPRs (resource), per-lane 32-bit byte offset, per-slab scalar byte offset.  Measured in
-// tools/mfma_probe.hip: global_load_dwordx4 with 64-bit VGPR addresses costs the K loop 11-17 % of the matrix pipe (one
-// 64-bit VALU add per load on top of the load's own issue); the same loads as buffer loads cost 6-13 %.
-__device__ __forceinline__ f32x4 bload(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);     // raw buffer, 2 GiB window, no swizzle
-}
 
 __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * x; }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float*
 }
 
 // glds variant: two unpadded XOR-swizzled LDS buffers filled by global_load_lds_dwordx4, one barrier per slab
-template <int TM, int TN>
+template <int TM, int TN, int BUF>
 __global__ __launch_bounds__(256) void probe_glds(const float* __restrict__ g, float* out, int slabs, int ld) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
@@ -111,11 +111,18 @@ __global__ __launch_bounds__(256) void probe_glds(const float* __restrict__ g, f
     for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int lrow = tid >> 3, chunk = (lane & 7) ^ (lane >> 3);
     const float* gp = g + ((size_t)blockIdx.x * 192 + lrow) * ld + chunk * 4;
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g, 0, 0x7fffffff, 0x00020000);
+    const unsigned boff = (unsigned)((((size_t)blockIdx.x * 192 + lrow) * ld + chunk * 4) * 4);
     auto fill = [&](int s, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
-            __builtin_amdgcn_global_load_lds(gp + (size_t)(32 * i) * ld + (s & 7) * 32,
-                                             (__attribute__((address_space(3))) void*)(smem + buf * ROWS * 32 + (32 * i + wave * 8) * 32), 16, 0, 0);
+        for (int i = 0; i < NI; ++i) {
+            if (BUF)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(smem + buf * ROWS * 32 + (32 * i + wave * 8) * 32), 16,
+                                                     boff + (unsigned)(32 * i * ld) * 4, (unsigned)((s & 7) * 32) * 4, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds(gp + (size_t)(32 * i) * ld + (s & 7) * 32,
+                                                 (__attribute__((address_space(3))) void*)(smem + buf * ROWS * 32 + (32 * i + wave * 8) * 32), 16, 0, 0);
+        }
     };
     fill(0, 0);
     __syncthreads();
@@ -144,16 +151,16 @@ __global__ __launch_bounds__(256) void probe_glds(const float* __restrict__ g, f
     if (blockIdx.x == 0 && tid == 0) { ((long long*)out)[1] = clock64() - c_start; ((long long*)out)[2] = wall_clock64() - w_start; }
 }
 
-template <int TM, int TN>
+template <int TM, int TN, int BUF>
 void run_glds(const char* name, int wg_per_cu, const float* g, float* out, int ld) {
     const int slabs = 2048, grid = 256 * wg_per_cu;
     const size_t lds = (size_t)2 * (128 + (TM == 2 ? 128 : 64)) * 32 * 4;
-    CK(hipFuncSetAttribute((const void*)probe_glds<TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CK(hipFuncSetAttribute((const void*)probe_glds<TM, TN, BUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((probe_glds<TM, TN>), dim3(grid), dim3(256), lds, 0, g, out, 64, ld);
+    hipLaunchKernelGGL((probe_glds<TM, TN, BUF>), dim3(grid), dim3(256), lds, 0, g, out, 64, ld);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL((probe_glds<TM, TN>), dim3(grid), dim3(256), lds, 0, g, out, slabs, ld);
+    hipLaunchKernelGGL((probe_glds<TM, TN, BUF>), dim3(grid), dim3(256), lds, 0, g, out, slabs, ld);
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double flops = (double)grid * 4 * slabs * 16 * TM * TN * 4096.0;
@@ -187,8 +194,10 @@ int main() {
     float *g, *out;
     CK(hipMalloc(&g, (size_t)256 * 4 * 192 * ld * 4)); CK(hipMemset(g, 0, (size_t)256 * 4 * 192 * ld * 4)); CK(hipMalloc(&out, 64)); CK(hipMemset(out, 0, 64));
     for (int occ = 1; occ <= 3; ++occ) {
-        if (occ <= 2) run_glds<2, 2>("2x2 glds, 2 swizzled buffers, 1 barrier/slab", occ, g, out, ld);
-        run_glds<1, 2>("1x2 glds, 2 swizzled buffers, 1 barrier/slab", occ, g, out, ld);
+        if (occ <= 2) run_glds<2, 2, 0>("2x2 glds, 2 swizzled buffers, 1 barrier/slab", occ, g, out, ld);
+        if (occ <= 2) run_glds<2, 2, 1>("2x2 buffer_load..lds, same structure", occ, g, out, ld);
+        run_glds<1, 2, 0>("1x2 glds, 2 swizzled buffers, 1 barrier/slab", occ, g, out, ld);
+        run_glds<1, 2, 1>("1x2 buffer_load..lds, same structure", occ, g, out, ld);
     }
     for (int occ = 2; occ <= 3; ++occ) {
         run<2, 2, 0>("2x2 tiles/wave, registers only", occ, g, out, ld);
