@@ -16,4 +16,9 @@ __device__ __forceinline__ f32x4_t bload(__amdgpu_buffer_rsrc_t r, unsigned voff
     return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
+__device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, f32x4_t v, unsigned voff, unsigned soff) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, 0);
+}
+
 }  // namespace mocha

@@ -193,34 +193,47 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: acc[i][j] holds C^T of MFMA tile (i, j): lane&31 = row, regs 4g..4g+3 = 4 columns
+    // ---- epilogue: acc[i][j] holds C^T of MFMA tile (i, j): lane&31 = row, regs 4g..4g+3 = 4 columns.
+    // Every access goes through a buffer resource anchored at the tile (SGPR base), so a lane needs one 32-bit row offset per
+    // row block and the (j, g) column steps are instruction immediates: no 64-bit address arithmetic next to the
+    // co-resident workgroups' MFMAs.
     float* Cz = p.C + (size_t)blockIdx.z * p.slab_stride;
     const bool raw = p.ksplit > 1;
     const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) && ((p.N & 3) == 0 || raw);
+    const __amdgpu_buffer_rsrc_t rsC = make_rsrc(Cz + (size_t)m0 * p.ldc + n0);
+    const __amdgpu_buffer_rsrc_t rsBias = make_rsrc((!raw && p.bias) ? p.bias + n0 : p.W);
+    const __amdgpu_buffer_rsrc_t rsRb = make_rsrc((!raw && p.rowbias) ? p.rowbias + n0 : p.W);
+    const __amdgpu_buffer_rsrc_t rsRes = make_rsrc((!raw && p.residual) ? p.residual + (size_t)m0 * p.ldr + n0 : p.W);
+    const unsigned colb = (unsigned)(wn * TN * 32 + 4 * hh) * 4u;            // this lane's first column in the tile, bytes
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int row = m0 + (wm * TM + i) * 32 + l31;
+        const int rloc = (wm * TM + i) * 32 + l31;
+        const int row = m0 + rloc;
         if (row >= p.M) continue;
         const float* rbrow = (!raw && p.rowbias) ? p.rowbias + (size_t)(row % p.rb_mod) * p.N : nullptr;
         const float* rsrow = (!raw && p.residual) ? p.residual + (size_t)row * p.ldr : nullptr;
         float* crow = Cz + (size_t)row * p.ldc;
+        const unsigned c_off = (unsigned)rloc * (unsigned)p.ldc * 4u + colb;
+        const unsigned rb_off = rbrow ? (unsigned)(row % p.rb_mod) * (unsigned)p.N * 4u + colb : 0u;
+        const unsigned rs_off = rsrow ? (unsigned)rloc * (unsigned)p.ldr * 4u + colb : 0u;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int col = n0 + (wn * TN + j) * 32 + 8 * g + 4 * hh;
                 if (col >= p.N) continue;
+                const unsigned cstep = (unsigned)(j * 32 + 8 * g) * 4u;       // compile-time: folds into the instruction offset
                 f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (vec_ok && col + 3 < p.N) {
                     if (!raw) {
-                        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-                        if (rbrow) v += *reinterpret_cast<const f32x4*>(rbrow + col);
+                        if (p.bias) v += bload(rsBias, colb + cstep, 0u);
+                        if (rbrow) v += bload(rsRb, rb_off + cstep, 0u);
                         if (p.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
                         else if (p.act == 2) { v[0] = lrelu02(v[0]); v[1] = lrelu02(v[1]); v[2] = lrelu02(v[2]); v[3] = lrelu02(v[3]); }
                         else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                        if (rsrow) v += *reinterpret_cast<const f32x4*>(rsrow + col);
+                        if (rsrow) v += bload(rsRes, rs_off + cstep, 0u);
                     }
-                    *reinterpret_cast<f32x4*>(crow + col) = v;
+                    bstore(rsC, v, c_off + cstep, 0u);
                 } else {                             // ragged N (split-K slabs of the matcher): scalar tail
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
