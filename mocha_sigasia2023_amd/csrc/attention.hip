@@ -132,10 +132,11 @@ __global__ __launch_bounds__(NQW * 64) void mocha_attention_f32(AttnParams p) {
             sum += e;
         }
     sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;                   // one IEEE division per query, then 16*NKT multiplies (<= 1 ulp from e / sum)
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] / sum;
+        for (int r = 0; r < 16; ++r) st[t][r] = st[t][r] * inv;
 
     // ---------------- phase 3: O^T[d][query] = sum_key V[key][d] * P^T[key][query]
     const int query = wave * 32 + l31;
