@@ -284,7 +284,11 @@ __global__ __launch_bounds__(256) void mocha_gemm_skinny(GemmParams p) {
     }
     int n = n0 + l31;
     n = n < p.N ? n : p.N - 1;
-    const float* wrow = p.W + (size_t)n * p.K;
+    // buffer loads (device_utils.h): tile-anchored resources, 32-bit lane offsets, the k position as the scalar offset
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.gather ? p.A : p.A + (size_t)(m0 < p.M ? m0 : 0) * p.lda);
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.W + (size_t)n0 * p.K);
+    const unsigned a_off = p.gather ? 0u : ((unsigned)(m - m0) * (unsigned)p.lda + 4u * hh) * 4u;
+    const unsigned w_off = ((unsigned)(n - n0) * (unsigned)p.K + 4u * hh) * 4u;
 
     const int groups = p.K / 8;                     // k groups of 8 (4 per lane half)
     const int gper = (groups + 3) / 4;
@@ -299,21 +303,22 @@ __global__ __launch_bounds__(256) void mocha_gemm_skinny(GemmParams p) {
         f32x4 a4[8], b4[8];
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            const int k = (g0 + g) * 8 + 4 * hh;
+            const int kb = (g0 + g) * 8;             // wave-uniform
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             a4[g] = z; b4[g] = z;
             if (g0 + g < g_end) {
                 if (!p.gather) {
-                    a4[g] = *reinterpret_cast<const f32x4*>(p.A + (size_t)a_rb * p.lda + k);
+                    a4[g] = bload(rsA, a_off, (unsigned)kb * 4u);
                 } else {
+                    const int k = kb + 4 * hh;
                     const int tap = k / p.Cc;
                     const int cc = k - tap * p.Cc;
                     int tf = a_t * p.stride + tap - p.pad;
                     tf = tf < 0 ? -tf : tf;
                     tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
-                    a4[g] = *reinterpret_cast<const f32x4*>(p.A + (size_t)(a_rb + (tf >> p.tshift) * p.V) * p.lda + cc);
+                    a4[g] = bload(rsA, ((unsigned)(a_rb + (tf >> p.tshift) * p.V) * (unsigned)p.lda + (unsigned)cc) * 4u, 0u);
                 }
-                b4[g] = *reinterpret_cast<const f32x4*>(wrow + k);
+                b4[g] = bload(rsW, w_off, (unsigned)kb * 4u);
             }
         }
         if (p.a_lrelu) {

@@ -15,6 +15,7 @@
 // k a lane feeds to the MFMA is conflict-free per 16-lane group (20*i mod 64 = 16 distinct
 // multiples of 4).  Operands are swapped like in gemm_f32.hip (C^T accumulators, 16-B epilogue).
 #include "kernels.h"
+#include "device_utils.h"
 #include <cstring>
 
 namespace mocha {
@@ -97,7 +98,10 @@ __global__ __launch_bounds__(256) void mocha_gemm_split(GemmParams p) {
     // ---- A loader: 8 threads cover one 128-byte fp32 row segment (as in gemm_f32.hip)
     const int lrow = tid >> 3;
     const int lcol = (tid & 7) * 4;
+    // operand fetches are buffer loads (device_utils.h): SGPR base, 32-bit lane offsets, scalar slab offset
     int a_rb[NA], a_t[NA];
+    unsigned a_off[NA];
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.gather ? p.A : p.A + (size_t)(m0 < p.M ? m0 : 0) * p.lda);
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         int m = m0 + lrow + 32 * i;
@@ -109,22 +113,27 @@ __global__ __launch_bounds__(256) void mocha_gemm_split(GemmParams p) {
             const int b = bt / p.T_out;
             a_rb[i] = b * p.T_src * p.V + v;
             a_t[i] = t;
+            a_off[i] = 0;
         } else {
             a_rb[i] = m;
             a_t[i] = 0;
+            a_off[i] = ((unsigned)(m - m0) * (unsigned)p.lda + lcol) * 4u;
         }
     }
     // ---- W loader: plane tile = BN rows x 64 bytes; 4 threads per row, 16 bytes each
     const int wr = tid >> 2;                        // 0..63
     const int wc = (tid & 3) * 8;                   // bf16 offset within the 32-wide slab
-    const unsigned short* wsrc[NBL];
+    unsigned w_off[NBL];
 #pragma unroll
     for (int i = 0; i < NBL; ++i) {
         int n = n0 + wr + 64 * i;
         n = n < p.N ? n : p.N - 1;
-        wsrc[i] = p.Wsplit + (size_t)n * p.K + wc;
+        w_off[i] = ((unsigned)(n - n0) * (unsigned)p.K + wc) * 2u;
     }
     const size_t wplane = (size_t)p.N * p.K;
+    __amdgpu_buffer_rsrc_t rsW[NPB];                 // one resource per plane, anchored at the tile's first row
+#pragma unroll
+    for (int pl = 0; pl < NPB; ++pl) rsW[pl] = make_rsrc(p.Wsplit + pl * wplane + (size_t)n0 * p.K);
 
     f32x4 ra[NA];
     u32x4 rb[NPB][NBL];
@@ -132,18 +141,17 @@ __global__ __launch_bounds__(256) void mocha_gemm_split(GemmParams p) {
         const int k0 = s * SBK;
         if (!p.gather) {
 #pragma unroll
-            for (int i = 0; i < NA; ++i)
-                ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)a_rb[i] * p.lda + k0 + lcol);
+            for (int i = 0; i < NA; ++i) ra[i] = bload(rsA, a_off[i], (unsigned)k0 * 4u);
         } else {
             const int tap = k0 / p.Cc;
-            const int c0 = k0 - tap * p.Cc + lcol;
+            const unsigned c0 = (unsigned)(k0 - tap * p.Cc + lcol) * 4u;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 int tf = a_t[i] * p.stride + tap - p.pad;
                 tf = tf < 0 ? -tf : tf;
                 tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
                 const int row = a_rb[i] + (tf >> p.tshift) * p.V;
-                ra[i] = *reinterpret_cast<const f32x4*>(p.A + (size_t)row * p.lda + c0);
+                ra[i] = bload(rsA, (unsigned)row * (unsigned)p.lda * 4u + c0, 0u);
             }
         }
         if (p.a_lrelu) {
@@ -157,7 +165,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_split(GemmParams p) {
         for (int pl = 0; pl < NPB; ++pl)
 #pragma unroll
             for (int i = 0; i < NBL; ++i)
-                rb[pl][i] = *reinterpret_cast<const u32x4*>(wsrc[i] + pl * wplane + k0);
+                rb[pl][i] = __builtin_bit_cast(u32x4, bload(rsW[pl], w_off[i], (unsigned)k0 * 2u));
     };
     auto store_slab = [&]() __attribute__((always_inline)) {
 #pragma unroll
