@@ -15,8 +15,10 @@ W = a.windows
 src = torch.from_numpy(synthetic.pose_windows(1, W)).to(dev); cha = torch.from_numpy(synthetic.pose_windows(2, W)).to(dev)
 m_, s_ = synthetic.cnt_norm(7); mean, std = torch.from_numpy(m_).to(dev), torch.from_numpy(s_).to(dev)
 def step():
-    enc_c, cnt_c, nm_c = model.encode(cha, mean, std)
-    return ContextBank(model, nm_c, enc_c).characterize(src, mean, std)
+    if os.environ.get("THREE_CALLS"):
+        enc_c, cnt_c, nm_c = model.encode(cha, mean, std)
+        return ContextBank(model, nm_c, enc_c).characterize(src, mean, std)
+    return model.characterize_pair(src, cha, mean, std)
 for _ in range(2): step()
 torch.cuda.synchronize()
 import time
