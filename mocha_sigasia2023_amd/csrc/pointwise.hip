@@ -18,55 +18,107 @@ __device__ __forceinline__ float wave_sum(float v) {
 // ---------------------------------------------------------------------------------------
 // embed_front: model.py:43-46 up to (and including) the joint->body-part pool, which is linear
 // and is commuted in front of the two convolutions of the joint ST-GCN block.
-//   h[v][c]   = lrelu( sum_i X[v][i] W1[c][i] + b1[c] )                 (model.py:44, blocks.py:131)
-//   out[p][k*64+c] = sum_v AP[k][v][p] h[v][c],   AP[k] = A_j[k] · Pool  (blocks.py:64, graph.py:463-465)
-// One workgroup walks FPB frames; thread (c = tid&63, g = tid>>6).
+//   h[v][c]        = lrelu( sum_i X[v][i] W1[c][i] + b1[c] )                 (model.py:44, blocks.py:131)
+//   out[pk][c]     = sum_v AP'[pk][v] h[v][c],  pk = 3 p + k,  AP'[3p+k][v] = (A_j[k] · Pool)[v][p]   (blocks.py:64, graph.py:463-465)
+// Both contractions run on the fp32 matrix pipe, one frame per wave at a time (the scalar version spent 5x the HBM time in
+// LDS-fed FMAs):
+//   1. D1[joint][channel] = X_f (32 x 16, zero padded) · W1^T: 8 MFMA steps per 32-channel tile; X_f goes through a per-wave
+//      LDS tile so that each lane's 8 features are two ds_read_b128;
+//   2. the accumulator D1 (lane = channel, register s = joint (s&3) + 8 (s>>2) + 4 hh) IS the B operand of the second
+//      contraction register by register, exactly as P^T in attention.hip: D2[pk][channel] = sum_s AP'[pk][joint(s, hh)] h[...]:
+//      16 MFMA steps per tile with the AP' coefficients as per-lane constants.
 // ---------------------------------------------------------------------------------------
-static constexpr int EF_FPB = 4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict__ X, const float* __restrict__ W1,
                                                          const float* __restrict__ b1, const float* __restrict__ AP,
                                                          float* __restrict__ out, int nframes, int V, int Cin,
                                                          const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
-    __shared__ float xs[32 * 16];
-    __shared__ float hs[32 * 64];
-    __shared__ float aps[3 * 32 * 6];
-    const int tid = threadIdx.x;
-    const int c = tid & 63, g = tid >> 6;
-    float w[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) w[i] = i < Cin ? W1[c * Cin + i] : 0.f;
-    const float bc = b1[c];
-    for (int i = tid; i < 3 * V * 6; i += 256) aps[i] = AP[i];
+    __shared__ __attribute__((aligned(16))) float xs_all[4][32 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    float* xs = xs_all[wave];
 
-    for (int f = 0; f < EF_FPB; ++f) {
-        const int frame = blockIdx.x * EF_FPB + f;
-        if (frame >= nframes) break;
-        __syncthreads();
-        // raw_root = 1: frames carry the root bone in front (V+1 joints) and are z-scored here,
-        // X = (X[:,:,1:] - X_mean[:,:,1:]) / X_std[:,:,1:]   (test_fullframework.py:186)
-        const float* xf = X + (size_t)frame * (V + raw_root) * Cin + raw_root * Cin;
-        for (int i = tid; i < V * Cin; i += 256) {
-            const int v = i / Cin, ci = i - v * Cin;
-            float x = xf[i];
-            if (xmean) x = (x - xmean[raw_root * Cin + i]) / xstd[raw_root * Cin + i];
-            xs[v * 16 + ci] = x;
-        }
-        __syncthreads();
-        for (int v = g; v < V; v += 4) {
-            float a = 0.f;
+    // ---- per-lane constants
+    float wb[2][8], bias[2], apv[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (i < Cin) a = fmaf(xs[v * 16 + i], w[i], a);
-            hs[v * 64 + c] = lrelu02(a + bc);
+    for (int t = 0; t < 2; ++t) {
+        const int c = t * 32 + l31;
+        bias[t] = b1[c];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int feat = 2 * s + hh;
+            wb[t][s] = feat < Cin ? W1[c * Cin + feat] : 0.f;
         }
-        __syncthreads();
-        float* of = out + (size_t)frame * 6 * 192;
-        for (int j = g; j < 18; j += 4) {
-            const int p = j / 3, k = j - p * 3;
-            float a = 0.f;
-            for (int v = 0; v < V; ++v) a = fmaf(aps[(k * V + v) * 6 + p], hs[v * 64 + c], a);
-            of[p * 192 + k * 64 + c] = a;
+    }
+    {
+        const int pk = l31, pp = pk / 3, kk = pk - pp * 3;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int joint = (s & 3) + 8 * (s >> 2) + 4 * hh;
+            apv[s] = (pk < 18 && joint < V) ? AP[(kk * V + joint) * 6 + pp] : 0.f;
+        }
+    }
+    // staging map of this lane's (at most 8) elements of a frame: element e = lane + 64 i -> joint e / Cin, feature e % Cin,
+    // stored at joint * 16 + (feature & 1) * 8 + (feature >> 1) so that a lane's 8 features of one parity are contiguous
+    const int nelem = V * Cin;
+    int slot[8];
+    float zm[8], zs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = lane + 64 * i;
+        const int v = e / Cin, ci = e - v * Cin;
+        slot[i] = e < nelem ? v * 16 + (ci & 1) * 8 + (ci >> 1) : -1;
+        zm[i] = (xmean && e < nelem) ? xmean[raw_root * Cin + e] : 0.f;
+        zs[i] = (xmean && e < nelem) ? xstd[raw_root * Cin + e] : 1.f;
+    }
+    for (int i = lane; i < 32 * 16; i += 64) xs[i] = 0.f;          // padding joints / the padding feature stay zero
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const int stride = gridDim.x * 4;
+    int frame = blockIdx.x * 4 + wave;
+    float xr[8];
+    auto fetch = [&](int f) __attribute__((always_inline)) {
+        // raw_root = 1: frames carry the root bone in front (V+1 joints), X = (X[:,:,1:] - mean) / std   (test_fullframework.py:186)
+        const float* xf = X + (size_t)f * (V + raw_root) * Cin + raw_root * Cin;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr[i] = slot[i] >= 0 ? xf[lane + 64 * i] : 0.f;
+    };
+    if (frame < nframes) fetch(frame);
+    for (; frame < nframes; frame += stride) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (slot[i] >= 0) xs[slot[i]] = xmean ? (xr[i] - zm[i]) / zs[i] : xr[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xs + l31 * 16 + hh * 8);
+        const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xs + l31 * 16 + hh * 8 + 4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (frame + stride < nframes) fetch(frame + stride);       // next frame's loads fly under this frame's MFMAs
+        const float xa[8] = {xa0[0], xa0[1], xa0[2], xa0[3], xa1[0], xa1[1], xa1[2], xa1[3]};
+        float* of = out + (size_t)frame * 18 * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) h = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], wb[t][s], h, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[r] = lrelu02(h[r] + bias[t]);
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_32x32x2f32(apv[s], h[s], o, 0, 0, 0);
+            // o[r] = out[pk = (r&3) + 8 (r>>2) + 4 hh][channel t*32 + l31]; rows 18..31 are padding
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+                const int pk = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (pk < 18) of[pk * 64 + t * 32 + l31] = o[r];
+            }
         }
     }
 }
@@ -74,8 +126,9 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
 hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP, float* out,
                               int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root, hipStream_t s) {
     if (nframes <= 0) return hipSuccess;
-    if (V > 32 || Cin > 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_embed_front, dim3((nframes + EF_FPB - 1) / EF_FPB), dim3(256), 0, s, X, W1, b1, AP, out,
+    if (V > 32 || Cin > 16 || V * Cin > 512) return hipErrorInvalidValue;
+    const int wgs = (nframes + 3) / 4;
+    hipLaunchKernelGGL(mocha_embed_front, dim3(wgs < 2048 ? wgs : 2048), dim3(256), 0, s, X, W1, b1, AP, out,
                        nframes, V, Cin, xmean, xstd, raw_root);
     return hipGetLastError();
 }
