@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
+#include <algorithm>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
@@ -17,7 +19,7 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float*
     const long long c_start = clock64(), w_start = wall_clock64();
     constexpr int BMr = 128, BNr = (TM == 2 ? 128 : 64);
     float* As = smem; float* Bs = smem + BMr * LDSK;
-    for (int i = tid; i < (BMr + BNr) * LDSK; i += 256) smem[i] = (float)(i % 7) * 0.125f;
+    for (int i = tid; i < (BMr + BNr) * LDSK; i += 256) smem[i] = g[(i * 37 + blockIdx.x * 11) & 0xfffff];       // operand values come from g (zeros or random)
     __syncthreads();
     const int wm = (TM == 2) ? wave / 2 : wave, wn = (TM == 2) ? wave % 2 : 0;
     const float* Ab = As + (wm * TM * 32 + l31) * LDSK + 4 * hh;
@@ -192,7 +194,14 @@ void run(const char* name, int wg_per_cu, const float* g, float* out, int ld) {
 int main() {
     const int ld = 1024;
     float *g, *out;
-    CK(hipMalloc(&g, (size_t)256 * 4 * 192 * ld * 4)); CK(hipMemset(g, 0, (size_t)256 * 4 * 192 * ld * 4)); CK(hipMalloc(&out, 64)); CK(hipMemset(out, 0, 64));
+    const size_t gn = (size_t)256 * 4 * 192 * ld;
+    CK(hipMalloc(&g, gn * 4)); CK(hipMemset(g, 0, gn * 4)); CK(hipMalloc(&out, 64)); CK(hipMemset(out, 0, 64));
+    if (getenv("PROBE_RANDOM")) {              // random +-1 operands: what clock does the chip hold when the data toggles?
+        std::vector<float> h(1 << 22);
+        for (auto& v : h) v = (float)rand() / RAND_MAX * 2 - 1;
+        for (size_t o = 0; o < gn; o += h.size()) CK(hipMemcpy(g + o, h.data(), std::min(h.size(), gn - o) * 4, hipMemcpyHostToDevice));
+        printf("operands: random in [-1, 1]\n");
+    } else printf("operands: zeros\n");
     for (int occ = 1; occ <= 3; ++occ) {
         if (occ <= 2) run_glds<2, 2, 0>("2x2 glds, 2 swizzled buffers, 1 barrier/slab", occ, g, out, ld);
         if (occ <= 2) run_glds<2, 2, 1>("2x2 buffer_load..lds, same structure", occ, g, out, ld);
