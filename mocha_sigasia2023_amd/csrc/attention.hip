@@ -40,7 +40,13 @@ __global__ __launch_bounds__(NQW * 64) void mocha_attention_f32(AttnParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
-    const int head = blockIdx.x, b = blockIdx.y;
+    // XCD-aware order (workgroup id % 8 = XCD): the heads of one window run on the same XCD, so keys / values that the heads
+    // share (the folded decoder: IN(cha) and cha for all four heads) are fetched from HBM once and then hit that XCD's L2
+    const int id = blockIdx.x;
+    const int slot = id >> 3;
+    const int head = slot % p.heads;
+    const int b = (slot / p.heads) * 8 + (id & 7);
+    if (b >= p.B) return;
     const int nq = p.nq, nk = p.nk;
 
     const float* qg = p.q + (size_t)b * nq * p.ldq + head * DH;
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(NQW * 64) void mocha_attention_f32(AttnParams p) {
 hipError_t launch_attention(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     if (p.nq < 1 || p.nk < 1 || p.nq > 192 || p.nk > 192) return hipErrorInvalidValue;
-    dim3 grid(p.heads, p.B);
+    dim3 grid((unsigned)(((p.B + 7) / 8) * 8 * p.heads));
     const bool small = p.nq <= 96 && p.nk <= 96;
     if (p.dh == 128 && small) hipLaunchKernelGGL((mocha_attention_f32<128, 3, 3>), grid, dim3(192), 0, s, p);
     else if (p.dh == 256 && small) hipLaunchKernelGGL((mocha_attention_f32<256, 3, 3>), grid, dim3(192), 0, s, p);

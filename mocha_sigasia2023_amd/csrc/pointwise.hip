@@ -205,39 +205,50 @@ hipError_t launch_joint_expand(const float* g, const float* AU, float* out, int 
 }
 
 // ---------------------------------------------------------------------------------------
-// final_proj: Y[m][o] = sum_c lrelu(z[m][c]) W6[o][c] + b6[o]     (model.py:77-79)
-// 64 rows per workgroup, staged through LDS so both the z read and the Y write are coalesced.
+// final_proj: Y[m][o] = sum_c lrelu(z[m][c]) W6[o][c] + b6[o]     (model.py:77-79), optionally de-normalised.
+// On the fp32 matrix pipe: a wave owns 32 rows; lane (row, k-half) fetches its row's 8 float4 straight into MFMA operand
+// layout (the k permutation is shared with the per-lane W6 constants), 32 MFMA steps give D[row][o] with the lane on o;
+// the 128 x 15 results of a workgroup go through LDS so that the Y rows (60 bytes each) leave as one contiguous run.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mocha_final_proj(const float* __restrict__ z, const float* __restrict__ W6,
                                                         const float* __restrict__ b6, float* __restrict__ Y, int rows,
                                                         int Cout, int V, const float* __restrict__ ymean,
                                                         const float* __restrict__ ystd) {
-    __shared__ float zs[64 * 65];
-    __shared__ float ws[16 * 64];
-    __shared__ float ys[64 * 16];
-    const int tid = threadIdx.x;
-    const int r0 = blockIdx.x * 64;
-    for (int i = tid; i < Cout * 64; i += 256) ws[i] = W6[i];
-    for (int i = tid; i < 64 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const int row = r0 + r;
-        zs[r * 65 + c] = row < rows ? lrelu02(z[(size_t)row * 64 + c]) : 0.f;
+    __shared__ float ys[128 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int r0 = blockIdx.x * 128;
+    const int row = r0 + wave * 32 + l31;
+    f32x4 a[8], w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        a[q] = row < rows ? *reinterpret_cast<const f32x4*>(z + (size_t)row * 64 + 8 * q + 4 * hh) : zero;
+        w[q] = l31 < Cout ? *reinterpret_cast<const f32x4*>(W6 + l31 * 64 + 8 * q + 4 * hh) : zero;
     }
-    __syncthreads();
-    const int r = tid & 63;
-    for (int o = tid >> 6; o < Cout; o += 4) {
-        float a = 0.f;
-#pragma unroll 16
-        for (int c = 0; c < 64; ++c) a = fmaf(zs[r * 65 + c], ws[o * 64 + c], a);
-        float y = a + b6[o];
-        if (ymean) {       // de-normalise, Y * Y_std[0,:,1:] + Y_mean[0,:,1:] (test_fullframework.py:303,457); norms carry the root row
-            const int v = (r0 + r) % V;
-            y = y * ystd[(v + 1) * Cout + o] + ymean[(v + 1) * Cout + o];
+    f32x16 d;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d = __builtin_amdgcn_mfma_f32_32x32x2f32(lrelu02(a[q][e]), w[q][e], d, 0, 0, 0);
+    // d[r] = sum for (row = wave*32 + (r&3) + 8 (r>>2) + 4 hh, o = l31)
+    if (l31 < Cout) {
+        const float bo = b6[l31];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rl = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            float y = d[r] + bo;
+            if (ymean) {   // de-normalise, Y * Y_std[0,:,1:] + Y_mean[0,:,1:] (test_fullframework.py:303,457); norms carry the root row
+                const int v = (r0 + rl) % V;
+                y = y * ystd[(v + 1) * Cout + l31] + ymean[(v + 1) * Cout + l31];
+            }
+            ys[rl * Cout + l31] = y;
         }
-        ys[r * Cout + o] = y;
     }
     __syncthreads();
-    const int nrow = (rows - r0) < 64 ? (rows - r0) : 64;
+    const int nrow = (rows - r0) < 128 ? (rows - r0) : 128;
     for (int i = tid; i < nrow * Cout; i += 256) Y[(size_t)r0 * Cout + i] = ys[i];
 }
 
@@ -245,7 +256,7 @@ hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, f
                              const float* ymean, const float* ystd, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (Cout > 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_final_proj, dim3((rows + 63) / 64), dim3(256), 0, s, z, W6, b6, Y, rows, Cout, V, ymean, ystd);
+    hipLaunchKernelGGL(mocha_final_proj, dim3((rows + 127) / 128), dim3(256), 0, s, z, W6, b6, Y, rows, Cout, V, ymean, ystd);
     return hipGetLastError();
 }
 
