@@ -457,30 +457,30 @@ __global__ __launch_bounds__(256) void mocha_argmin(const float* __restrict__ S,
                                                     float* __restrict__ dist) {
     __shared__ float rv[4];
     __shared__ int ri[4];
-    __shared__ float cand_v;
-    __shared__ int cand_i;
+    __shared__ int cand[RERANK];
+    __shared__ float dsum[RERANK][4];
     const int q = blockIdx.x, tid = threadIdx.x;
+    // ---- 1. the RERANK smallest approximate scores, in (value, index) order
     float prev_v = -INFINITY;
     int prev_i = -1;
-    float best_d = INFINITY;
-    int best_i = 0x7fffffff;
     const int rounds = N < RERANK ? (int)N : RERANK;
-    for (int round = 0; round < rounds; ++round) {
-        // next (value, index) after (prev_v, prev_i) in lexicographic order
+    for (int round = 0; round < RERANK; ++round) {
         float best = INFINITY;
         int bi = 0x7fffffff;
-        for (long long nn = tid; nn < N; nn += 256) {
-            float dot = 0.f;
-            for (int z = 0; z < ksplit; ++z) dot += S[(size_t)z * slab_stride + (size_t)q * lds + nn];
-            const float v = bnorm[nn] - 2.f * dot;
-            const bool after = v > prev_v || (v == prev_v && (int)nn > prev_i);
-            if (after && (v < best || (v == best && (int)nn < bi))) { best = v; bi = (int)nn; }
-        }
+        if (round < rounds) {
+            for (long long nn = tid; nn < N; nn += 256) {
+                float dot = 0.f;
+                for (int z = 0; z < ksplit; ++z) dot += S[(size_t)z * slab_stride + (size_t)q * lds + nn];
+                const float v = bnorm[nn] - 2.f * dot;
+                const bool after = v > prev_v || (v == prev_v && (int)nn > prev_i);
+                if (after && (v < best || (v == best && (int)nn < bi))) { best = v; bi = (int)nn; }
+            }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bi, o);
-            if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(best, o);
+                const int oi = __shfl_xor(bi, o);
+                if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
         }
         if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
         __syncthreads();
@@ -488,36 +488,54 @@ __global__ __launch_bounds__(256) void mocha_argmin(const float* __restrict__ S,
             float b = rv[0]; int i = ri[0];
             for (int w = 1; w < 4; ++w)
                 if (rv[w] < b || (rv[w] == b && ri[w] < i)) { b = rv[w]; i = ri[w]; }
-            cand_v = b; cand_i = i;
+            cand[round] = i;                             // 0x7fffffff when there is no further candidate
+            rv[0] = b;
         }
         __syncthreads();
-        prev_v = cand_v; prev_i = cand_i;
-        if (prev_i == 0x7fffffff) break;                 // fewer finite candidates than rounds (uniform)
-        // exact squared distance of this candidate
-        float a = 0.f;
-        if (bank16) {
-            const unsigned short* b16 = bank16 + (size_t)prev_i * D;
-            for (int i = tid; i < D; i += 256) {
-                const float d = qexact[(size_t)q * D + i] - __uint_as_float((unsigned)b16[i] << 16);
-                a = fmaf(d, d, a);
-            }
-        } else {
-            const f32x4* qr = reinterpret_cast<const f32x4*>(qexact + (size_t)q * D);
-            const f32x4* br = reinterpret_cast<const f32x4*>(bank + (size_t)prev_i * D);
-            for (int i = tid; i < D / 4; i += 256) {
-                const f32x4 d = qr[i] - br[i];
-                a = fmaf(d[0], d[0], a); a = fmaf(d[1], d[1], a); a = fmaf(d[2], d[2], a); a = fmaf(d[3], d[3], a);
-            }
-        }
-        a = wave_sum(a);
-        __syncthreads();
-        if ((tid & 63) == 0) rv[tid >> 6] = a;
-        __syncthreads();
-        const float d2 = (rv[0] + rv[1]) + (rv[2] + rv[3]);
-        if (d2 < best_d || (d2 == best_d && prev_i < best_i)) { best_d = d2; best_i = prev_i; }
+        prev_v = rv[0]; prev_i = cand[round];
         __syncthreads();
     }
+    // ---- 2. exact squared distances of all candidates in one pass over the query row
+    int ci[RERANK];
+#pragma unroll
+    for (int c = 0; c < RERANK; ++c) ci[c] = cand[c] == 0x7fffffff ? cand[0] : cand[c];     // pad with the best (harmless duplicate)
+    float a[RERANK];
+#pragma unroll
+    for (int c = 0; c < RERANK; ++c) a[c] = 0.f;
+    if (bank16) {
+        for (int i = tid; i < D; i += 256) {
+            const float qv = qexact[(size_t)q * D + i];
+#pragma unroll
+            for (int c = 0; c < RERANK; ++c) {
+                const float d = qv - __uint_as_float((unsigned)bank16[(size_t)ci[c] * D + i] << 16);
+                a[c] = fmaf(d, d, a[c]);
+            }
+        }
+    } else {
+        const f32x4* qr = reinterpret_cast<const f32x4*>(qexact + (size_t)q * D);
+        for (int i = tid; i < D / 4; i += 256) {
+            const f32x4 qv = qr[i];
+#pragma unroll
+            for (int c = 0; c < RERANK; ++c) {
+                const f32x4 d = qv - reinterpret_cast<const f32x4*>(bank + (size_t)ci[c] * D)[i];
+                a[c] = fmaf(d[0], d[0], a[c]); a[c] = fmaf(d[1], d[1], a[c]); a[c] = fmaf(d[2], d[2], a[c]); a[c] = fmaf(d[3], d[3], a[c]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < RERANK; ++c) {
+        a[c] = wave_sum(a[c]);
+        if ((tid & 63) == 0) dsum[c][tid >> 6] = a[c];
+    }
+    __syncthreads();
     if (tid == 0) {
+        float best_d = INFINITY;
+        int best_i = 0x7fffffff;
+        for (int c = 0; c < RERANK; ++c) {
+            if (cand[c] == 0x7fffffff) continue;
+            const float d2 = (dsum[c][0] + dsum[c][1]) + (dsum[c][2] + dsum[c][3]);
+            if (d2 < best_d || (d2 == best_d && cand[c] < best_i)) { best_d = d2; best_i = cand[c]; }
+        }
         idx[q] = best_i;
         if (dist) dist[q] = sqrtf(best_d);
     }
