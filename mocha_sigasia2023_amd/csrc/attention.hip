@@ -117,23 +117,26 @@ __global__ __launch_bounds__(NQW * 64) void mocha_attention_f32(AttnParams p) {
 
     // ---------------- phase 2: softmax over keys for this lane's query
     // st[t][r] = S[query = 32*wave + l31][key = 32t + (r&3) + 8(r>>2) + 4hh]
+    // masking is only needed in tiles that can hold padded keys; scores stay unscaled until the exponent:
+    // softmax(scale * s) = exp2((s - max s) * scale * log2 e) / sum   (scale > 0), one fma + v_exp_f32 per element
     float mx = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const float sv = key < nk ? st[t][r] * p.scale : -INFINITY;
-            st[t][r] = sv;
-            mx = fmaxf(mx, sv);
+            if (key >= nk) st[t][r] = -INFINITY;              // uniform per (t, r, half): cheap select, no effect on valid keys
+            mx = fmaxf(mx, st[t][r]);
         }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float c2 = p.scale * 1.44269504088896340736f;
+    const float mb = -mx * c2;
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = expf(st[t][r] - mx);
+            const float e = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, mb));     // exp2(-inf) = 0 for masked keys
             st[t][r] = e;
             sum += e;
         }
