@@ -46,6 +46,12 @@ int main(int argc, char** argv) {
         {"match 585    ", 585, 585, 23040, 0},
         {"square 4096  ", 4096, 4096, 4096, 0},
     };
+    if (getenv("MOCHA_BENCH_KSWEEP")) {            // time vs K at fixed M, N: intercept = per-launch fixed cost
+        shapes.clear();
+        static const int ks[] = {32, 64, 128, 256, 384, 512, 768, 1024, 1536, 2048};
+        const int n = atoi(getenv("MOCHA_BENCH_KSWEEP"));
+        for (int k : ks) shapes.push_back({"ksweep       ", B * 90, n, k, 0});
+    }
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& sh : shapes) {
         size_t a_rows = sh.gather ? (size_t)(sh.M / (sh.T_out * sh.V)) * sh.T_src * sh.V : sh.M;
