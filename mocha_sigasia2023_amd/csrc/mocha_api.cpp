@@ -128,7 +128,8 @@ struct mocha_ctx {
     float* bank_norm = nullptr; size_t bank_norm_cap = 0;
     float* bank_center = nullptr;                           // centroid of the matching bank (90*256), see do_match
     DevBuf match_qc[2];                                     // queries minus the centroid
-    float* pair_norm = nullptr; size_t pair_norm_cap = 0;      // row norms of the transient bank of mocha_characterize_pair
+    float* pair_norm = nullptr; size_t pair_norm_cap = 0;
+    float* pair_center = nullptr;                           // ... and its centroid      // row norms of the transient bank of mocha_characterize_pair
     int64_t bank_N = 0;
     // CVAE sampler (row N1): weights under "cvae.<reference key>", workspace for cvae_B conditions
     std::map<std::string, std::vector<int64_t>> cvae_expect;
@@ -1044,9 +1045,9 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     if (cha_cnt_nm) HIPCHK(c, hipMemcpyAsync(cha_cnt_nm, WS(c, "qnm"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (B_src == 0) return 0;
     // transient bank: swap the context's bank state out, borrow the workspace rows, restore afterwards
-    struct Saved { const float *cnt, *enc; int64_t N; bool bf16; float* norm; size_t norm_cap; } sv{c->bank_cnt, c->bank_enc, c->bank_N,
-                                                                                                c->bank_is_bf16, c->bank_norm, c->bank_norm_cap};
-    c->bank_norm = c->pair_norm; c->bank_norm_cap = c->pair_norm_cap;
+    struct Saved { const float *cnt, *enc; int64_t N; bool bf16; float* norm; size_t norm_cap; float* center; } sv{
+        c->bank_cnt, c->bank_enc, c->bank_N, c->bank_is_bf16, c->bank_norm, c->bank_norm_cap, c->bank_center};
+    c->bank_norm = c->pair_norm; c->bank_norm_cap = c->pair_norm_cap; c->bank_center = c->pair_center;
     rc = mocha_bank_set(c, WS(c, "qnm"), WS(c, "enc_s"), B_cha, MOCHA_BANK_BORROW, stream);
     int32_t* ix = idx ? idx : c->idx_ws[0];
     if (!rc) rc = do_match(c, WS(c, "qnm") + (size_t)B_cha * T, B_src, ix, nullptr, s);
@@ -1054,8 +1055,9 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
         LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, B_src * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), B_src, 90 * 256, s));
         return 0;
     }();
-    c->pair_norm = c->bank_norm; c->pair_norm_cap = c->bank_norm_cap;
+    c->pair_norm = c->bank_norm; c->pair_norm_cap = c->bank_norm_cap; c->pair_center = c->bank_center;
     c->bank_cnt = sv.cnt; c->bank_enc = sv.enc; c->bank_N = sv.N; c->bank_is_bf16 = sv.bf16; c->bank_norm = sv.norm; c->bank_norm_cap = sv.norm_cap;
+    c->bank_center = sv.center;
     if (rc) return rc;
     if ((rc = run_decoder(c, WS(c, "enc_s") + (size_t)B_cha * T, WS(c, "sel"), B_src, WS(c, "dec"), s))) return rc;
     return run_to_mot(c, WS(c, "dec"), B_src, Y, s, raw);

@@ -343,6 +343,12 @@ def test_characterize_pair_matches_the_three_call_path():
     assert float((nm2 - nm_c).abs().max()) < 3e-5 * float(nm_c.abs().max())
     d, i = other.query(nm_c[:5], k=1)                                            # still the 5-entry bank
     assert i[:, 0].tolist() == [0, 1, 2, 3, 4]
+    # ... with its own centroid and norms: a many-query search (GEMM path on centred operands) must still be exact
+    far = ContextBank(model, (nm_c[:40] + 50.0).contiguous(), enc_c[:40].clone())
+    far.activate()
+    model.characterize_pair(src, cha, mean, std)
+    qs_far = (nm_c[:40] + 50.0 + 1e-3 * torch.randn_like(nm_c[:40])).contiguous()
+    assert far.query(qs_far, return_distance=False)[:, 0].tolist() == list(range(40))
     ost = O.to_torch_state(sd)
     with torch.no_grad():
         Yo, io = O.characterize(ost, src.cpu(), cha.cpu(), mean, std)
