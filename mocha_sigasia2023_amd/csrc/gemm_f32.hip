@@ -205,6 +205,58 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
     const __amdgpu_buffer_rsrc_t rsRb = make_rsrc((!raw && p.rowbias) ? p.rowbias + n0 : p.W);
     const __amdgpu_buffer_rsrc_t rsRes = make_rsrc((!raw && p.residual) ? p.residual + (size_t)m0 * p.ldr + n0 : p.W);
     const unsigned colb = (unsigned)(wn * TN * 32 + 4 * hh) * 4u;            // this lane's first column in the tile, bytes
+
+    if (vec_ok && n0 + BN <= p.N) {
+        // Full-width tile: the accumulators (lane = row, 4 columns per register group) are transposed through LDS, 64 rows
+        // at a time, so that every store instruction writes whole 128-byte lines and bias / residual are read the same way.
+        // Measured with PMC on M = 105 300, N = 256: storing straight from the C^T layout (32 contiguous bytes per row and
+        // instruction) wrote 150-170 MB to HBM for a 108 MB result.
+        constexpr int LDP = BN + 4;                  // row pitch in floats: 8 consecutive rows cover all banks for b128 accesses
+        constexpr int C4 = BN / 4;                   // float4 per row
+        static_assert(64 * LDP <= (BM + BN) * LDSK, "epilogue staging fits the operand stages");
+        float* stage = smem;
+#pragma unroll
+        for (int h = 0; h < BM / 64; ++h) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int rblk = wm * TM + i;        // 32-row block of the tile
+                if ((rblk >> 1) != h) continue;      // compile-time per wave position: uniform
+                float* srow = stage + ((rblk & 1) * 32 + l31) * LDP + wn * TN * 32 + 4 * hh;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(srow + j * 32 + 8 * g) = v;
+                    }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 64 * C4 / 256; ++it) {
+                const int e = tid + 256 * it;
+                const int r = e / C4, c4 = e - r * C4;
+                const int rloc = 64 * h + r;
+                const int row = m0 + rloc;
+                if (row < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4);
+                    const unsigned cb = (unsigned)c4 * 16u;
+                    if (!raw) {
+                        if (p.bias) v += bload(rsBias, cb, 0u);
+                        if (p.rowbias) v += bload(rsRb, (unsigned)(row % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);
+                        if (p.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+                        else if (p.act == 2) { v[0] = lrelu02(v[0]); v[1] = lrelu02(v[1]); v[2] = lrelu02(v[2]); v[3] = lrelu02(v[3]); }
+                        else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                        if (p.residual) v += bload(rsRes, (unsigned)rloc * (unsigned)p.ldr * 4u + cb, 0u);
+                    }
+                    bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
+                }
+            }
+            if (h + 1 < BM / 64) __syncthreads();
+        }
+        return;
+    }
+
+    // ragged tiles (the matcher's split-K slabs, N not a multiple of the tile): straight from the accumulators
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int rloc = (wm * TM + i) * 32 + l31;
@@ -234,7 +286,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
                         if (rsrow) v += bload(rsRes, rs_off + cstep, 0u);
                     }
                     bstore(rsC, v, c_off + cstep, 0u);
-                } else {                             // ragged N (split-K slabs of the matcher): scalar tail
+                } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int c1 = col + e;
