@@ -114,6 +114,21 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
         if (!p.gather) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) ra[i] = bload(rsA, a_off[i], (unsigned)k0 * 4u);
+        } else if (p.R == 1) {
+            // a slab stays inside one tap for Cc / 32 slabs: the row offsets of the tap are computed when it starts
+            const int tap = k0 / p.Cc;
+            const int cin = k0 - tap * p.Cc;
+            if (cin == 0 || s == s_begin) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    int tf = a_t[i] * p.stride + tap - p.pad;
+                    tf = tf < 0 ? -tf : tf;
+                    tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
+                    a_off[i] = ((unsigned)(a_rb[i] + (tf >> p.tshift) * p.V) * (unsigned)p.lda + lcol) * 4u;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NA; ++i) ra[i] = bload(rsA, a_off[i], (unsigned)cin * 4u);
         } else {
             const int tap = k0 / p.Cc;
             const unsigned c0 = (unsigned)(k0 - tap * p.Cc + lcol) * 4u;
@@ -127,7 +142,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
                     const int row = a_rb[i] + (tf >> p.tshift) * p.V;
                     acc4 += bload(rsA, (unsigned)row * (unsigned)p.lda * 4u + c0, 0u);
                 }
-                ra[i] = p.R > 1 ? acc4 * p.ascale : acc4;
+                ra[i] = acc4 * p.ascale;
             }
         }
         if (p.a_lrelu) {
