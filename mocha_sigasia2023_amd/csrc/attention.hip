@@ -23,8 +23,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int LK = 36;       // LDS row stride for the K/Q chunks (32 + 4 pad)
 static constexpr int DV = 64;       // head dims of V staged per pass
 
+// Occupancy is pinned per instance: left alone, hipcc gives the dh = 256 instance 188 registers (2 waves per SIMD); at 4 waves
+// (128 VGPRs, accumulators in VGPRs, 28 bytes of spill outside the MFMA loops) it runs 0.53 -> 0.44 ms per demo step.
 template <int DH, int NKT, int NQW>
-__global__ __launch_bounds__(NQW * 64) void mocha_attention_f32(AttnParams p) {
+__global__ __launch_bounds__(NQW * 64) __attribute__((amdgpu_waves_per_eu(NKT != 3 ? 1 : (DH == 128 ? 3 : 4)))) void mocha_attention_f32(AttnParams p) {
     constexpr int NTHR = NQW * 64;
     constexpr int KROWS = NKT * 32, QROWS = NQW * 32;
     constexpr int KPT = KROWS * 8 / NTHR;           // float4 of a K chunk per thread
