@@ -37,7 +37,7 @@ __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <int BN, int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void mocha_gemm_f32(GemmParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 64 ? 5 : 3))) void mocha_gemm_f32(GemmParams p) {
     static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
     constexpr int NA = BM / 32;                     // float4 loads of A per thread per slab
     constexpr int NB = BN / 32;                     // float4 loads of W per thread per slab
