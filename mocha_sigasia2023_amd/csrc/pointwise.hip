@@ -367,31 +367,40 @@ hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin,
 // ---------------------------------------------------------------------------------------
 // window_sums: operand of the joint temporal conv fused with AvgPool2d((4,1)) (blocks.py:112-118, model.py:47):
 //   u[(b,t',p)][dt*256 + c] = 1/4 * sum_{j<4} y[(b, refl(4t'+j+dt-2, 60), p)][c],   dt = 0..4
-// The five overlapping 4-frame windows of one output row share 8 input frames; one thread loads the
-// 8 frames of its (row, channel quad) once and emits the five sums.
+// The five overlapping 4-frame windows of one output row share 8 input frames, and consecutive output rows share 4.
+// One thread owns a (window, body part, channel quad) and walks the 15 output frames with a sliding register window of 8
+// input frames (4 new ones per step), so every input frame is fetched once (PMC had shown 2x the input bytes from HBM when
+// each output row fetched its own 8 frames).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mocha_window_sums(const float* __restrict__ y, float* __restrict__ u, int rows /*B*15*6*/) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int row = gid >> 6, q = gid & 63;
-    if (row >= rows) return;
-    const int pp = row % 6, bt = row / 6, t15 = bt % 15, b = bt / 15;
+    const int bp = gid >> 6, q = gid & 63;              // bp = b * 6 + pp
+    if (bp * 15 >= rows) return;
+    const int b = bp / 6, pp = bp - b * 6;
     const f32x4* yb = reinterpret_cast<const f32x4*>(y) + ((size_t)b * 60 * 6 + pp) * 64 + q;
+    f32x4* ub = reinterpret_cast<f32x4*>(u) + ((size_t)b * 15 * 6 + pp) * 5 * 64 + q;
+    auto frame = [&](int t) __attribute__((always_inline)) {
+        t = t < 0 ? -t : t;
+        t = t > 59 ? 118 - t : t;                        // reflect padding (blocks.py:112-118)
+        return yb[(size_t)t * 6 * 64];
+    };
     f32x4 f[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        int t = 4 * t15 - 2 + i;
-        t = t < 0 ? -t : t;
-        t = t > 59 ? 118 - t : t;
-        f[i] = yb[(size_t)t * 6 * 64];
-    }
-    f32x4* ub = reinterpret_cast<f32x4*>(u) + (size_t)row * 5 * 64 + q;
+    for (int i = 0; i < 4; ++i) f[4 + i] = frame(-2 + i);
 #pragma unroll
-    for (int dt = 0; dt < 5; ++dt) ub[dt * 64] = (((f[dt] + f[dt + 1]) + f[dt + 2]) + f[dt + 3]) * 0.25f;
+    for (int t15 = 0; t15 < 15; ++t15) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { f[i] = f[4 + i]; f[4 + i] = frame(4 * t15 + 2 + i); }
+        f32x4* ur = ub + (size_t)t15 * 6 * 5 * 64;
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) ur[dt * 64] = (((f[dt] + f[dt + 1]) + f[dt + 2]) + f[dt + 3]) * 0.25f;
+    }
 }
 
 hipError_t launch_window_sums(const float* y, float* u, int rows, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
-    const long long threads = (long long)rows * 64;
+    if (rows % 90) return hipErrorInvalidValue;          // whole windows: 15 frames x 6 parts
+    const long long threads = (long long)(rows / 15) * 64;
     hipLaunchKernelGGL(mocha_window_sums, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, y, u, rows);
     return hipGetLastError();
 }
