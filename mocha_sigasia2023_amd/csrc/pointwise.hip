@@ -267,13 +267,19 @@ hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, f
 // its <= 24 tokens x 4 channels in registers (one 16-byte load each), so the window is read once;
 // the four token groups combine their partial sums through LDS.
 // ---------------------------------------------------------------------------------------
-static constexpr int IN_MAXT = 24;          // tokens per thread (n <= 96)
+// 8 token groups (512 threads) per window: 12 tokens x 4 channels per thread keeps the kernels under 100 VGPRs (the
+// 4-group version held 24 tokens per thread: 165-224 VGPRs, 2-3 waves per SIMD for a bandwidth-bound kernel).
+static constexpr int IN_NG = 8;             // token groups per window
+static constexpr int IN_MAXT = 12;          // tokens per thread (n <= 96)
 
 __device__ __forceinline__ f32x4 group_sum4(f32x4 v, f32x4* red, int q, int g) {
     __syncthreads();                         // red[] may still be read from the previous reduction
     red[g * 64 + q] = v;
     __syncthreads();
-    return (red[q] + red[64 + q]) + (red[128 + q] + red[192 + q]);
+    f32x4 a = red[q];
+#pragma unroll
+    for (int k = 1; k < IN_NG; ++k) a += red[k * 64 + q];      // fixed order: deterministic
+    return a;
 }
 
 __device__ __forceinline__ void inorm_stats(const f32x4* xv, int cnt, int n, f32x4* red, int q, int g, f32x4& mean, f32x4& den) {
@@ -290,17 +296,17 @@ __device__ __forceinline__ void inorm_stats(const f32x4* xv, int cnt, int n, f32
     den[0] = sqrtf(qq[0]) + 1e-5f; den[1] = sqrtf(qq[1]) + 1e-5f; den[2] = sqrtf(qq[2]) + 1e-5f; den[3] = sqrtf(qq[3]) + 1e-5f;
 }
 
-__global__ __launch_bounds__(256) void mocha_instnorm(const float* __restrict__ x, float* __restrict__ out,
-                                                      float* __restrict__ mean_out, const float* __restrict__ gm,
-                                                      const float* __restrict__ gs, float* __restrict__ zn, int n) {
-    __shared__ f32x4 red[256];
+__global__ __launch_bounds__(64 * IN_NG) void mocha_instnorm(const float* __restrict__ x, float* __restrict__ out,
+                                                             float* __restrict__ mean_out, const float* __restrict__ gm,
+                                                             const float* __restrict__ gs, float* __restrict__ zn, int n) {
+    __shared__ f32x4 red[64 * IN_NG];
     const int b = blockIdx.x, q = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int cnt = (n - g + 3) / 4;                       // tokens g, g+4, ...
+    const int cnt = (n - g + IN_NG - 1) / IN_NG;           // tokens g, g + NG, ...
     const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * n * 256) + q;
     f32x4 xv[IN_MAXT];
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
-        if (i < cnt) xv[i] = xb[(size_t)(g + 4 * i) * 64];
+        if (i < cnt) xv[i] = xb[(size_t)(g + IN_NG * i) * 64];
     f32x4 mean, den;
     inorm_stats(xv, cnt, n, red, q, g, mean, den);
     if (mean_out && g == 0) reinterpret_cast<f32x4*>(mean_out + (size_t)b * 256)[q] = mean;
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(256) void mocha_instnorm(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) {
-            const int t = g + 4 * i;
+            const int t = g + IN_NG * i;
             const f32x4 v = (xv[i] - mean) / den;
             ob[(size_t)t * 64] = v;
             if (zn) {
@@ -321,23 +327,23 @@ __global__ __launch_bounds__(256) void mocha_instnorm(const float* __restrict__ 
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
                            int B, int n, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (n > 4 * IN_MAXT || n < 2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_instnorm, dim3(B), dim3(256), 0, s, x, out, mean_out, gm, gs, zn, n);
+    if (n > IN_NG * IN_MAXT || n < 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_instnorm, dim3(B), dim3(64 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n);
     return hipGetLastError();
 }
 
 // AdaIN followed by the attention's own mapping norm (net/transformer.py:108-113 then :49-56):
 //   xad = (1+gamma) * IN(x) + beta ;  qin = IN(xad)
-__global__ __launch_bounds__(256) void mocha_adain(const float* __restrict__ x, const float* __restrict__ gb,
-                                                   float* __restrict__ xad, float* __restrict__ qin, int n) {
-    __shared__ f32x4 red[256];
+__global__ __launch_bounds__(64 * IN_NG) void mocha_adain(const float* __restrict__ x, const float* __restrict__ gb,
+                                                          float* __restrict__ xad, float* __restrict__ qin, int n) {
+    __shared__ f32x4 red[64 * IN_NG];
     const int b = blockIdx.x, q = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int cnt = (n - g + 3) / 4;
+    const int cnt = (n - g + IN_NG - 1) / IN_NG;
     const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * n * 256) + q;
     f32x4 xv[IN_MAXT];
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
-        if (i < cnt) xv[i] = xb[(size_t)(g + 4 * i) * 64];
+        if (i < cnt) xv[i] = xb[(size_t)(g + IN_NG * i) * 64];
     f32x4 gamma1 = reinterpret_cast<const f32x4*>(gb + (size_t)b * 512)[q];
     const f32x4 beta = reinterpret_cast<const f32x4*>(gb + (size_t)b * 512 + 256)[q];
     gamma1 += 1.f;
@@ -348,19 +354,19 @@ __global__ __launch_bounds__(256) void mocha_adain(const float* __restrict__ x, 
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) {
             xv[i] = gamma1 * ((xv[i] - mean) / den) + beta;
-            ab[(size_t)(g + 4 * i) * 64] = xv[i];
+            ab[(size_t)(g + IN_NG * i) * 64] = xv[i];
         }
     inorm_stats(xv, cnt, n, red, q, g, mean, den);
     f32x4* qb = reinterpret_cast<f32x4*>(qin + (size_t)b * n * 256) + q;
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
-        if (i < cnt) qb[(size_t)(g + 4 * i) * 64] = (xv[i] - mean) / den;
+        if (i < cnt) qb[(size_t)(g + IN_NG * i) * 64] = (xv[i] - mean) / den;
 }
 
 hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin, int B, int n, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (n > 4 * IN_MAXT || n < 2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_adain, dim3(B), dim3(256), 0, s, x, gb, xad, qin, n);
+    if (n > IN_NG * IN_MAXT || n < 2) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_adain, dim3(B), dim3(64 * IN_NG), 0, s, x, gb, xad, qin, n);
     return hipGetLastError();
 }
 
