@@ -118,3 +118,30 @@ def test_misuse_fails_loudly(model):
         Generator(device="cpu")
     with pytest.raises((RuntimeError, ValueError)):
         ContextBank(model, torch.zeros((0, 90, 256), device="cuda"), torch.zeros((0, 90, 256), device="cuda"))
+
+
+def test_contexts_release_their_device_memory():
+    """Create / use / destroy contexts repeatedly: the library must hand every device allocation back (weights, workspaces,
+    bank copies, match scratch, events)."""
+    import gc
+    from mocha_sigasia2023_amd import ContextBank, Generator
+    sd = weights.synthetic_state_dict(2, 1.0)
+    mean, std = _norm()
+    X = torch.from_numpy(synthetic.pose_windows(1, 24)).cuda()
+
+    def cycle():
+        m = Generator(device="cuda:0").load_state_dict(sd).eval()
+        e, c, n = m.encode(X, mean, std)
+        ContextBank(m, n, e, bf16=True).characterize(X, mean, std)
+        ContextBank(m, n, e, copy=True).characterize(X[:3], mean, std)
+        m.characterize_pair(X[:10], X[10:], mean, std)
+        m.set_option("dual_stream", 1); m(X, X); m.set_option("dual_stream", 0)
+        del m
+        gc.collect(); torch.cuda.synchronize()
+
+    cycle(); cycle()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(5):
+        cycle()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 5 context life cycles"
