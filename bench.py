@@ -281,7 +281,7 @@ def main():
             "bank_broadcast_ms": bcast_ms,
             "dual_stream": dual,
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:         # the CPU leg runs at N=1 only (the other ranks would idle through it)
             m_, s_ = synthetic.cnt_norm(7)
             out["cpu_baseline"] = cpu_baseline(sd, V, a.cpu_sample, m_, s_)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
