@@ -123,6 +123,8 @@ struct PostParams {
 hipError_t launch_pose_heads(const float* Y, float* heads, float* speed, int B, int T, int V, hipStream_t s);
 hipError_t launch_post_clip(const PostParams& p, hipStream_t s);
 // per-column mean and population std over N rows (bank build: cnt_norm)
+size_t column_mean_scratch_doubles(int cols);
+hipError_t launch_column_mean(const float* x, int64_t N, int cols, float* mean, double* scratch, hipStream_t s);
 hipError_t launch_column_stats(const float* x, int64_t N, int cols, float* mean, float* sd, hipStream_t s);
 // bank row squared norms
 hipError_t launch_rownorm2(const float* x, const float* sub /*or null*/, float* out, int64_t rows, int cols, hipStream_t s);

@@ -127,6 +127,7 @@ struct mocha_ctx {
     float* bank_cnt_own = nullptr; float* bank_enc_own = nullptr; size_t bank_cap = 0;
     float* bank_norm = nullptr; size_t bank_norm_cap = 0;
     float* bank_center = nullptr;                           // centroid of the matching bank (90*256), see do_match
+    float* center_scratch = nullptr;                        // fp64 partial column sums of launch_column_mean
     DevBuf match_qc[2];                                     // queries minus the centroid
     float* pair_norm = nullptr; size_t pair_norm_cap = 0;
     float* pair_center = nullptr;                           // ... and its centroid      // row norms of the transient bank of mocha_characterize_pair
@@ -952,7 +953,9 @@ int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int6
     if (!c->bank_center && (rc = dev_alloc(c, &c->bank_center, D))) return rc;
     for (int set = 0; set < 2; ++set)                    // centred queries of a <= 8-query step: allocated here (capture-safe later)
         if ((rc = grow(c, c->match_qc[set], (size_t)8 * D))) return rc;
-    LAUNCH(c, s, "mocha_column_stats", "bank.center", 0.0, 4.0 * N * D, launch_column_stats(c->bank_cnt, N, (int)D, c->bank_center, nullptr, s));
+    if (!c->center_scratch && (rc = dev_alloc(c, &c->center_scratch, 2 * column_mean_scratch_doubles((int)D)))) return rc;
+    LAUNCH(c, s, "mocha_column_mean", "bank.center", 0.0, 4.0 * N * D,
+           launch_column_mean(c->bank_cnt, N, (int)D, c->bank_center, reinterpret_cast<double*>(c->center_scratch), s));
     if (c->bank_is_bf16) {
         if (c->bank_bf16_cap < (size_t)N) {
             if (c->bank_bf16) (void)hipFree(c->bank_bf16);

@@ -611,6 +611,39 @@ __global__ __launch_bounds__(256) void mocha_column_stats(const float* __restric
     }
 }
 
+// column mean in two deterministic stages (the bank centroid is on the per-step path of the demo pair): CM_CHUNKS row
+// chunks per 64-column block accumulate in fp64, a second kernel adds the partials in a fixed order
+static constexpr int CM_CHUNKS = 16;
+
+__global__ __launch_bounds__(256) void mocha_column_mean_part(const float* __restrict__ x, long long N, int cols,
+                                                              double* __restrict__ part /*[CM_CHUNKS][4][cols]*/) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane, chunk = blockIdx.y;
+    const long long per = (N + CM_CHUNKS - 1) / CM_CHUNKS;
+    const long long lo = chunk * per, hi = (lo + per) < N ? (lo + per) : N;
+    double a = 0.0;
+    for (long long n = lo + w; n < hi; n += 4) a += (double)x[(size_t)n * cols + col];
+    part[((size_t)chunk * 4 + w) * cols + col] = a;
+}
+
+__global__ __launch_bounds__(256) void mocha_column_mean_fin(const double* __restrict__ part, long long N, int cols,
+                                                             float* __restrict__ mean) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= cols) return;
+    double a = 0.0;
+    for (int k = 0; k < CM_CHUNKS * 4; ++k) a += part[(size_t)k * cols + col];
+    mean[col] = (float)(a / (double)N);
+}
+
+size_t column_mean_scratch_doubles(int cols) { return (size_t)CM_CHUNKS * 4 * cols; }
+
+hipError_t launch_column_mean(const float* x, int64_t N, int cols, float* mean, double* scratch, hipStream_t s) {
+    if (N <= 0 || cols <= 0 || cols % 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_column_mean_part, dim3(cols / 64, CM_CHUNKS), dim3(256), 0, s, x, (long long)N, cols, scratch);
+    hipLaunchKernelGGL(mocha_column_mean_fin, dim3((cols + 255) / 256), dim3(256), 0, s, scratch, (long long)N, cols, mean);
+    return hipGetLastError();
+}
+
 hipError_t launch_column_stats(const float* x, int64_t N, int cols, float* mean, float* sd, hipStream_t s) {
     if (N <= 0 || cols <= 0) return hipErrorInvalidValue;
     if (cols % 64) return hipErrorInvalidValue;
