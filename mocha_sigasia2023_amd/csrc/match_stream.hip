@@ -23,7 +23,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 static constexpr int MS_ROWS_PER_WAVE = 4;      // rows a wave carries through the D loop together
 static constexpr int MS_WAVES = 4;
-static constexpr int MS_CHUNK = 1280;           // floats of every query staged per step (5 x 16 B per lane)
+static constexpr int MS_CHUNK_F32 = 1280;       // elements of every query staged per step: 5 x 16 B per lane of fp32 bank ...
+static constexpr int MS_CHUNK_BF16 = 1536;      // ... 3 x 16 B per lane of bf16 bank (whole 64-lane rounds; both divide 23 040)
 
 __device__ __forceinline__ unsigned long long pack_key(float v, unsigned row) {
     unsigned u = __float_as_uint(v);
@@ -35,6 +36,7 @@ template <int Q, bool BF16>
 __global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict__ bank,
                                                           const float* __restrict__ query, int nq, long long N, int D,
                                                           unsigned long long* __restrict__ partial /*[Q8][gridDim.x]*/) {
+    constexpr int MS_CHUNK = BF16 ? MS_CHUNK_BF16 : MS_CHUNK_F32;
     __shared__ __attribute__((aligned(16))) float qs[Q * MS_CHUNK];
     __shared__ unsigned long long wbest[MS_WAVES][Q];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -194,7 +196,7 @@ size_t match_stream_scratch(int Q, int64_t N) {        // u64 words of partial[]
 hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* query, int Q, int64_t N, int D,
                                unsigned long long* partial, int32_t* idx, float* dist, hipStream_t s) {
     if (Q <= 0) return hipSuccess;
-    if (D % MS_CHUNK != 0) return hipErrorInvalidValue;
+    if (D % (bank_bf16 ? MS_CHUNK_BF16 : MS_CHUNK_F32) != 0) return hipErrorInvalidValue;
     const int rows_per_wg = MS_WAVES * MS_ROWS_PER_WAVE;
     const unsigned grid = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
     for (int q0 = 0; q0 < Q; q0 += 8) {                 // more than 8 queries: one bank pass per 8
