@@ -12,8 +12,10 @@
  *   - every tensor pointer is a DEVICE pointer to contiguous fp32 unless a comment says host;
  *   - layouts are the reference's: poses (B, T, V, C_in) channel-last, tokens (B, 90, 256)
  *     with token = t*6 + body_part (model.py:49), bank entries likewise;
- *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing here
- *     synchronises the device (no hidden syncs; graph-capture safe after mocha_reserve);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.  Steady-state calls do not synchronise
+ *     the device and are graph-capture safe; device allocations (and the device synchronisation that replacing a
+ *     buffer needs) only happen in mocha_finalize_weights, mocha_reserve, mocha_bank_set, mocha_set_option and the
+ *     first call with a batch (or query count) larger than any before;
  *   - functions return 0 on success, a negative mocha_status otherwise;
  *     mocha_last_error(ctx) gives the message.  The caller owns every in/out buffer; the
  *     context owns the device copies of the weights, the bank (unless borrowed) and the
