@@ -1,5 +1,10 @@
+#!/usr/bin/env python3
+"""Diagnostic that exposed the ranking problem of the first matcher: HIP features vs oracle features, the exact arg-min on
+the HIP features vs what the matcher returns, on a synthetic clip pair whose bank rows are near-duplicates (see DESIGN.md,
+Context matching)."""
+import os
 import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, weights
 from oracle import mocha_oracle as O
 sd = weights.synthetic_state_dict(21, 1.2)
