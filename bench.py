@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--dual-stream", action="store_true",
                     help="add a second timing of the same step with the opt-in two-stream overlap (reported beside the headline, "
                          "never as it; off by default so that a rocprofv3 run of the default command sees only the headline kernels)")
-    ap.add_argument("--cpu-sample", type=int, default=48, help="windows per clip for the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="windows per clip for the CPU baseline sample")
     return ap.parse_args()
 
 
