@@ -38,7 +38,8 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 
 template <int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 64 ? 5 : 3))) void mocha_gemm_f32(GemmParams p) {
-    static_assert(WM * WN == 4 && WM * TM * 32 == BM && WN * TN * 32 == BN, "tile shape");
+    constexpr int BM = WM * TM * 32;                // rows of the tile: 128, or 64 for the mid-size instance <64,2,2,1,1>
+    static_assert(WM * WN == 4 && WN * TN * 32 == BN, "tile shape");
     constexpr int NA = BM / 32;                     // float4 loads of A per thread per slab
     constexpr int NB = BN / 32;                     // float4 loads of W per thread per slab
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -229,6 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 64 ? 
         constexpr int LDP = BN + 4;                  // row pitch in floats: 8 consecutive rows cover all banks for b128 accesses
         constexpr int C4 = BN / 4;                   // float4 per row
         static_assert(64 * LDP <= (BM + BN) * LDSK, "epilogue staging fits the operand stages");
+        static_assert(BM % 64 == 0, "staged 64 rows at a time");
         float* stage = smem;
 #pragma unroll
         for (int h = 0; h < BM / 64; ++h) {
@@ -444,8 +446,19 @@ hipError_t gemm_init() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_f32<128, 2, 2, 2, 2>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<128>());
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_f32<64, 4, 1, 1, 2>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<64>());
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_f32<64, 4, 1, 1, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes<64>());
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_f32<64, 2, 2, 1, 1>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)((64 + 64) * LDSK * sizeof(float)));
+}
+
+// Mid-size launches (a few dozen windows: too many rows for the skinny kernel, fewer 128 x 64 tiles than the chip has
+// slots): 64 x 64 tiles, four waves of 32 x 32, so that twice as many workgroups share the CUs.
+bool gemm_is_small(const GemmParams& p) {
+    if (gemm_is_skinny(p) || p.ksplit > 1) return false;
+    const long long t_narrow = (long long)((p.M + BM - 1) / BM) * ((p.N + 63) / 64);
+    return t_narrow < 768;
 }
 
 bool gemm_is_narrow(const GemmParams& p) {
@@ -473,6 +486,12 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     if (gemm_is_skinny(p)) {
         dim3 grid(((p.M + 31) / 32) * ((p.N + 31) / 32));
         hipLaunchKernelGGL(mocha_gemm_skinny, grid, dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
+    if (gemm_is_small(p)) {
+        const int mt = (p.M + 63) / 64;
+        const int mp = mt >= 8 ? (mt + 7) / 8 * 8 : mt;
+        hipLaunchKernelGGL((mocha_gemm_f32<64, 2, 2, 1, 1>), dim3(mp * ((p.N + 63) / 64)), dim3(256), (64 + 64) * LDSK * sizeof(float), s, p);
         return hipGetLastError();
     }
     const int m_tiles = (p.M + BM - 1) / BM;

@@ -39,6 +39,7 @@ struct GemmParams {
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 bool gemm_is_narrow(const GemmParams& p);
+bool gemm_is_small(const GemmParams& p);    // true: mid-size launch -> 64 x 64 tiles
 bool gemm_is_skinny(const GemmParams& p);   // true: a handful of windows -> mocha_gemm_skinny (32x32 tile per workgroup, 4-way in-workgroup split-K)
 // split-precision engine (gemm_split.hip): planes = 33 (fp32-accurate, 6 bf16 MFMAs) or 31 (3 query planes x bf16 bank)
 hipError_t gemm_split_init();
