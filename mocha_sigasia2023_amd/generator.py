@@ -532,24 +532,30 @@ class OursSession:
         self.cm = _dev_f32(cha_encoded_mean, d, (NTOK, DIM), "cha_encoded_mean")
         self.cs = _dev_f32(cha_encoded_std, d, (NTOK, DIM), "cha_encoded_std")
         self.prev = None
-        self.cond = torch.empty((1, 2 * NTOK, DIM), dtype=torch.float32, device=d)
+        self.cond = None
 
     def reset(self, first_cha_encoded):
-        """prev_cha_encoded = curr_cha_encoded.clone() of the first frame (test_fullframework.py:436)."""
-        self.prev = _dev_f32(first_cha_encoded, self.model.device, (NTOK, DIM), "cha_encoded").reshape(1, NTOK, DIM).clone()
+        """prev_cha_encoded = curr_cha_encoded.clone() of the first frame (test_fullframework.py:436).  One (90,256) feature
+        for a single clip, or (B,90,256) for B clips advanced in lock step (clips are the data-parallel axis of this branch)."""
+        f = _dev_f32(first_cha_encoded, self.model.device, (NTOK, DIM), "cha_encoded")
+        self.prev = f.reshape(-1, NTOK, DIM).clone()
+        self.cond = torch.empty((self.prev.shape[0], 2 * NTOK, DIM), dtype=torch.float32, device=self.model.device)
         return self
 
     def step(self, src_encoded, src_cnt, eps=None, deterministic: bool = False):
-        """One frame: returns (trans_Ytil (1,60,V,15), curr_cha_encoded (1,90,256))."""
+        """One frame of every clip: returns (trans_Ytil (B,60,V,15), curr_cha_encoded (B,90,256)); B = 1 for (90,256) inputs."""
         if self.prev is None:
             raise RuntimeError("call reset(first_cha_encoded) first")
         m, d = self.model, self.model.device
-        se = _dev_f32(src_encoded, d, (NTOK, DIM), "src_encoded").reshape(1, NTOK, DIM)
-        sc = _dev_f32(src_cnt, d, (NTOK, DIM), "src_cnt").reshape(1, NTOK, DIM)
+        B = self.prev.shape[0]
+        se = _dev_f32(src_encoded, d, (NTOK, DIM), "src_encoded").reshape(-1, NTOK, DIM)
+        sc = _dev_f32(src_cnt, d, (NTOK, DIM), "src_cnt").reshape(-1, NTOK, DIM)
+        if se.shape[0] != B or sc.shape[0] != B:
+            raise ValueError(f"OursSession.step: expected features of {B} clip(s), got {se.shape[0]} / {sc.shape[0]}")
         self.cvae._ctx.call("mocha_cvae_condition", _ptr(sc), _ptr(self.sm), _ptr(self.ss), _ptr(self.prev), _ptr(self.cm),
-                            _ptr(self.cs), 1, _ptr(self.cond), _stream())
+                            _ptr(self.cs), B, _ptr(self.cond), _stream())
         vae = self.cvae.sample(self.cond, deterministic=deterministic, eps=eps)
         cur = torch.empty_like(vae)
-        self.cvae._ctx.call("mocha_scale_shift", _ptr(vae), _ptr(self.cm), _ptr(self.cs), 1, _ptr(cur), _stream())
+        self.cvae._ctx.call("mocha_scale_shift", _ptr(vae), _ptr(self.cm), _ptr(self.cs), B, _ptr(cur), _stream())
         self.prev = cur
         return m.to_mot(m.decoder(se, cur)), cur

@@ -84,3 +84,31 @@ def test_ours_branch_frames_match_oracle():
         Y, gcur = sess.step(enc_s[i].cuda(), cnt_s[i].cuda(), eps=eps.cuda())
         assert float((gcur.cpu() - cur).abs().max()) < 1e-4 * max(1.0, float(cur.abs().max())) * i
         assert float((Y.cpu() - Yo).abs().max()) < 1e-4 * max(1.0, float(Yo.abs().max())) * i
+
+
+def test_ours_session_advances_several_clips_in_lock_step():
+    """B clips through one OursSession (clips are the data-parallel axis of the autoregressive CVAE branch) give the same
+    frames as B single-clip sessions (the same kernels at another batch size: fp32 summation order may differ)."""
+    from mocha_sigasia2023_amd import Generator, OursSession
+    gsd = weights.synthetic_state_dict(12, 1.2)
+    model = Generator(device="cuda:0").load_state_dict(gsd).eval()
+    net = _model()
+    rng = np.random.Generator(np.random.PCG64(4))
+    stats = [(0.1 * rng.standard_normal((90, 256))).astype(np.float32), rng.uniform(0.5, 1.5, (90, 256)).astype(np.float32),
+             (0.1 * rng.standard_normal((90, 256))).astype(np.float32), rng.uniform(0.5, 1.5, (90, 256)).astype(np.float32)]
+    B, F = 3, 3
+    X = torch.from_numpy(synthetic.pose_windows(50, B * (F + 1))).cuda()
+    enc, cnt = model.encode(X)
+    enc, cnt = enc.reshape(B, F + 1, 90, 256), cnt.reshape(B, F + 1, 90, 256)
+    eps = torch.from_numpy(synthetic.token_features(77, F)[:, :B].copy()).cuda()          # (F, B, 256)
+    multi = OursSession(model, net, *stats).reset(enc[:, 0].contiguous())
+    singles = [OursSession(model, net, *stats).reset(enc[b, 0]) for b in range(B)]
+    for f in range(1, F + 1):
+        Ym, cm_ = multi.step(enc[:, f].contiguous(), cnt[:, f].contiguous(), eps=eps[f - 1].contiguous())
+        assert Ym.shape == (B, 60, 24, 15)
+        for b in range(B):
+            Ys, cs_ = singles[b].step(enc[b, f], cnt[b, f], eps=eps[f - 1, b:b + 1].contiguous())
+            assert float((Ym[b] - Ys[0]).abs().max()) < 2e-5 * max(1.0, float(Ys.abs().max()))
+            assert float((cm_[b] - cs_[0]).abs().max()) < 2e-5 * max(1.0, float(cs_.abs().max()))
+    with pytest.raises(ValueError):
+        multi.step(enc[0, 1], cnt[0, 1])
