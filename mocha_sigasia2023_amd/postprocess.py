@@ -95,6 +95,26 @@ def retarget_clip(bank, src_X, cnt_mean, cnt_std, src_rvel, src_rang, src_speed,
     return (post or PostProcessor(bank.model)).run(heads, speed, src_rvel, src_rang, src_speed, contact, bvh=bvh)
 
 
+def retarget_clip_ours(session, src_encoded, src_cnt, src_rvel, src_rang, src_speed, contact, eps=None, deterministic: bool = False,
+                       post: Optional[PostProcessor] = None, bvh: bool = True, denorm=None):
+    """The demo's CVAE ("Ours") branch for a whole clip (test_fullframework.py:446-457 per frame, then :474-632): the
+    autoregressive frame loop through ``OursSession`` (already ``reset`` with the first matched character feature), then the
+    pose heads and the post-processing of all frames at once.  src_encoded / src_cnt (N,90,256); ``eps`` (N,256) fixes the
+    sampler's noise; ``denorm`` = (Y_mean, Y_std) broadcastable to (60,V,15) de-normalises the decoded windows as :457 does."""
+    m = session.model
+    N = src_encoded.shape[0]
+    Ys = []
+    for i in range(N):
+        y, _ = session.step(src_encoded[i], src_cnt[i], eps=None if eps is None else eps[i:i + 1], deterministic=deterministic)
+        Ys.append(y)
+    Y = torch.cat(Ys)
+    if denorm is not None:
+        mean, std = (torch.as_tensor(a, dtype=torch.float32, device=m.device) for a in denorm)
+        Y = Y * std + mean
+    heads, speed = pose_heads(m, Y)
+    return (post or PostProcessor(m)).run(heads, speed, src_rvel, src_rang, src_speed, contact, bvh=bvh)
+
+
 _CHANNEL = {"x": "Xrotation", "y": "Yrotation", "z": "Zrotation"}
 _AXIS = {"x": 0, "y": 1, "z": 2}
 
