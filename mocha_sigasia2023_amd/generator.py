@@ -519,10 +519,12 @@ class CVAE:
 class OursSession:
     """The demo's CVAE ("Ours") branch, frame by frame and entirely on the device
     (test_fullframework.py:446-457): condition = cat[z-scored src cnt, z-scored previous character feature]
-    -> CVAE.sample -> de-normalise -> decoder -> to_mot, feeding the sampled feature back.  The CVAE and the
-    Generator live in one context; each frame enqueues ~50 small kernels (skinny GEMMs)."""
+    -> CVAE.sample -> de-normalise -> decoder -> to_mot, feeding the sampled feature back.  One clip, or B clips
+    advanced in lock step (the branch is autoregressive in time; clips are its data-parallel axis).  The ~65 small
+    kernels of a frame are captured into a HIP graph per sampling mode and replayed (``use_graph``)."""
 
-    def __init__(self, model: Generator, cvae: "CVAE", src_cnt_mean, src_cnt_std, cha_encoded_mean, cha_encoded_std):
+    def __init__(self, model: Generator, cvae: "CVAE", src_cnt_mean, src_cnt_std, cha_encoded_mean, cha_encoded_std,
+                 use_graph: bool = True):
         if cvae.device != model.device:
             raise ValueError("CVAE and Generator must be on the same device")
         self.model, self.cvae = model, cvae
@@ -531,31 +533,67 @@ class OursSession:
         self.ss = _dev_f32(src_cnt_std, d, (NTOK, DIM), "src_cnt_std")
         self.cm = _dev_f32(cha_encoded_mean, d, (NTOK, DIM), "cha_encoded_mean")
         self.cs = _dev_f32(cha_encoded_std, d, (NTOK, DIM), "cha_encoded_std")
+        self.use_graph = use_graph
         self.prev = None
-        self.cond = None
 
     def reset(self, first_cha_encoded):
         """prev_cha_encoded = curr_cha_encoded.clone() of the first frame (test_fullframework.py:436).  One (90,256) feature
-        for a single clip, or (B,90,256) for B clips advanced in lock step (clips are the data-parallel axis of this branch)."""
-        f = _dev_f32(first_cha_encoded, self.model.device, (NTOK, DIM), "cha_encoded")
-        self.prev = f.reshape(-1, NTOK, DIM).clone()
-        self.cond = torch.empty((self.prev.shape[0], 2 * NTOK, DIM), dtype=torch.float32, device=self.model.device)
+        for a single clip, or (B,90,256) for B clips."""
+        m, d = self.model, self.model.device
+        f = _dev_f32(first_cha_encoded, d, (NTOK, DIM), "cha_encoded").reshape(-1, NTOK, DIM)
+        B = f.shape[0]
+        if self.prev is None or self.prev.shape[0] != B:
+            new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=d)
+            self.prev, self.se, self.sc = new(B, NTOK, DIM), new(B, NTOK, DIM), new(B, NTOK, DIM)
+            self.cond, self.vae, self.cur, self.dec = new(B, 2 * NTOK, DIM), new(B, NTOK, DIM), new(B, NTOK, DIM), new(B, NTOK, DIM)
+            self.eps, self.mu, self.logvar = new(B, DIM), new(B, DIM), new(B, DIM)
+            self.Y = new(B, m.cfg["nframes"], m.V, m.cfg["mot_in_dim"])
+            self._graphs = {}
+        self.prev.copy_(f)
         return self
 
+    def _enqueue(self, with_eps: bool):
+        m, c, B, st = self.model._ctx, self.cvae._ctx, self.prev.shape[0], _stream()
+        c.call("mocha_cvae_condition", _ptr(self.sc), _ptr(self.sm), _ptr(self.ss), _ptr(self.prev), _ptr(self.cm), _ptr(self.cs),
+               B, _ptr(self.cond), st)
+        c.call("mocha_cvae_sample", _ptr(self.cond), B, _ptr(self.vae), _ptr(self.mu), _ptr(self.logvar),
+               _ptr(self.eps) if with_eps else None, st)
+        c.call("mocha_scale_shift", _ptr(self.vae), _ptr(self.cm), _ptr(self.cs), B, _ptr(self.cur), st)
+        self.prev.copy_(self.cur)
+        m.call("mocha_decoder", _ptr(self.se), _ptr(self.cur), B, _ptr(self.dec), st)
+        m.call("mocha_to_mot", _ptr(self.dec), B, _ptr(self.Y), st)
+
     def step(self, src_encoded, src_cnt, eps=None, deterministic: bool = False):
-        """One frame of every clip: returns (trans_Ytil (B,60,V,15), curr_cha_encoded (B,90,256)); B = 1 for (90,256) inputs."""
+        """One frame of every clip: returns (trans_Ytil (B,60,V,15), curr_cha_encoded (B,90,256)), B = 1 for (90,256) inputs.
+        Both are views of session buffers that the next step overwrites.  ``eps`` (B,256) is the sampler's noise
+        (drawn with torch.randn when omitted and not deterministic)."""
         if self.prev is None:
             raise RuntimeError("call reset(first_cha_encoded) first")
-        m, d = self.model, self.model.device
-        B = self.prev.shape[0]
+        d, B = self.model.device, self.prev.shape[0]
         se = _dev_f32(src_encoded, d, (NTOK, DIM), "src_encoded").reshape(-1, NTOK, DIM)
         sc = _dev_f32(src_cnt, d, (NTOK, DIM), "src_cnt").reshape(-1, NTOK, DIM)
         if se.shape[0] != B or sc.shape[0] != B:
             raise ValueError(f"OursSession.step: expected features of {B} clip(s), got {se.shape[0]} / {sc.shape[0]}")
-        self.cvae._ctx.call("mocha_cvae_condition", _ptr(sc), _ptr(self.sm), _ptr(self.ss), _ptr(self.prev), _ptr(self.cm),
-                            _ptr(self.cs), B, _ptr(self.cond), _stream())
-        vae = self.cvae.sample(self.cond, deterministic=deterministic, eps=eps)
-        cur = torch.empty_like(vae)
-        self.cvae._ctx.call("mocha_scale_shift", _ptr(vae), _ptr(self.cm), _ptr(self.cs), B, _ptr(cur), _stream())
-        self.prev = cur
-        return m.to_mot(m.decoder(se, cur)), cur
+        self.se.copy_(se, non_blocking=True); self.sc.copy_(sc, non_blocking=True)
+        with_eps = not deterministic
+        if with_eps:
+            if eps is None:
+                self.eps.normal_()
+            else:
+                self.eps.copy_(_dev_f32(eps, d, (DIM,), "eps").reshape(B, DIM), non_blocking=True)
+        if not self.use_graph:
+            self._enqueue(with_eps)
+        else:
+            g = self._graphs.get(with_eps)
+            if g is None:
+                keep = self.prev.clone()
+                self._enqueue(with_eps)                       # warm-up outside capture (lazy allocations), then undo its state update
+                torch.cuda.synchronize(d)
+                self.prev.copy_(keep)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._enqueue(with_eps)
+                self._graphs[with_eps] = g
+                self.prev.copy_(keep)
+            g.replay()
+        return self.Y, self.cur

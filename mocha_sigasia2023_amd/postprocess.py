@@ -106,7 +106,7 @@ def retarget_clip_ours(session, src_encoded, src_cnt, src_rvel, src_rang, src_sp
     Ys = []
     for i in range(N):
         y, _ = session.step(src_encoded[i], src_cnt[i], eps=None if eps is None else eps[i:i + 1], deterministic=deterministic)
-        Ys.append(y)
+        Ys.append(y.clone())                    # the session returns views of buffers that the next step overwrites
     Y = torch.cat(Ys)
     if denorm is not None:
         mean, std = (torch.as_tensor(a, dtype=torch.float32, device=m.device) for a in denorm)
