@@ -368,6 +368,22 @@ __global__ __launch_bounds__(256) void mocha_gemm_skinny(GemmParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    // The kernel is a latency chain (load round, 64 dependent MFMAs, reduction, epilogue): the epilogue's operands are
+    // fetched by the wave that will use them before the K loop, so their round trip is hidden under it.
+    const int row = m0 + l31;
+    f32x4 ebias[4], eres[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ebias[g] = z; eres[g] = z;
+        const int col = n0 + 8 * g + 4 * hh;
+        if (wave == 0 && row < p.M && col < p.N) {
+            if (p.bias) ebias[g] = *reinterpret_cast<const f32x4*>(p.bias + col);
+            if (p.rowbias) ebias[g] += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(row % p.rb_mod) * p.N + col);
+            if (p.residual) eres[g] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * p.ldr + col);
+        }
+    }
+
     for (int g0 = g_begin; g0 < g_end; g0 += 8) {
         f32x4 a4[8], b4[8];
 #pragma unroll
@@ -412,22 +428,18 @@ __global__ __launch_bounds__(256) void mocha_gemm_skinny(GemmParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
 
-    const int row = m0 + l31;
     if (row >= p.M) return;
-    const float* rbrow = p.rowbias ? p.rowbias + (size_t)(row % p.rb_mod) * p.N : nullptr;
-    const float* rsrow = p.residual ? p.residual + (size_t)row * p.ldr : nullptr;
     float* crow = p.C + (size_t)row * p.ldc;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int col = n0 + 8 * g + 4 * hh;
         if (col >= p.N) continue;                   // N % 4 == 0 is checked on the host for this kernel
         f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + col);
-        if (rbrow) v += *reinterpret_cast<const f32x4*>(rbrow + col);
+        v += ebias[g];
         if (p.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
         else if (p.act == 2) { v[0] = lrelu02(v[0]); v[1] = lrelu02(v[1]); v[2] = lrelu02(v[2]); v[3] = lrelu02(v[3]); }
-                        else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        if (rsrow) v += *reinterpret_cast<const f32x4*>(rsrow + col);
+        else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+        v += eres[g];
         *reinterpret_cast<f32x4*>(crow + col) = v;
     }
 }
