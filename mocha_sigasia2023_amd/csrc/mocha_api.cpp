@@ -652,7 +652,6 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-    if (getenv("MOCHA_DUAL_STREAM")) c->dual_stream = atoi(getenv("MOCHA_DUAL_STREAM")) != 0;
     if (e != hipSuccess) { delete c; return fail(nullptr, MOCHA_ERR_HIP, "device %d init failed: %s", device, hipGetErrorString(e)); }
     *out = c;
     return 0;
