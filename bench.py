@@ -19,8 +19,11 @@ output); --three-calls runs it as encode(cha) + ContextBank + characterize(src).
 
 Multi-GPU (weak scaling, one process per GPU): every rank runs the same step on its own source
 clip; the character clip and the cnt norm are owned by rank 0 and broadcast once over RCCL
-before the timed region (a set-up step, reported as bank_broadcast_ms); there is no
-collective inside the timed region because windows are independent units.
+before the timed region, and the character bank rank 0 builds from it is broadcast through the C ABI
+(mocha_bank_broadcast: scatter + all-gather over xGMI; reported as bank_broadcast_ms); there is no
+collective inside the timed region because windows are independent units.  `python bench.py --gpus N`
+with N > 1 and no RANK in the environment spawns the N ranks itself (fresh child processes, started before
+this process touches a GPU); under torch.distributed.run it reads RANK / LOCAL_RANK / WORLD_SIZE as usual.
 
 Prints ONE JSON line on rank 0 (see the keys below).
 """
@@ -60,7 +63,30 @@ def parse():
                     help="add a second timing of the same step with the opt-in two-stream overlap (reported beside the headline, "
                          "never as it; off by default so that a rocprofv3 run of the default command sees only the headline kernels)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="windows per clip for the CPU baseline sample")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra records of the default N=1 line (matcher roofline, bank4k, streaming)")
     return ap.parse_args()
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set, rendezvous over 127.0.0.1) and wait for them.  This process has not touched a GPU and never will:
+    counting devices does not initialise HIP, and the children are new processes, not re-execs of this one."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if a.gpus > n_dev:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: this node exposes {n_dev} GPU(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    raise SystemExit(max(abs(rc) for rc in rcs))
 
 
 def pmc_traffic_for(kernel_name):
@@ -117,18 +143,20 @@ def bank4k(a):
     m_, s_ = synthetic.cnt_norm(7)
     mean, std = torch.from_numpy(m_).to(dev), torch.from_numpy(s_).to(dev)
     g = torch.Generator(device=dev); g.manual_seed(2)
+    bank_nm = bank_enc = None
     if rank == 0:
         bank_nm = torch.randn((NB, 90 * 256), device=dev, generator=g)
         bank_enc = torch.randn((NB, 90, 256), device=dev, generator=g)
-    else:
-        bank_nm = torch.empty((NB, 90 * 256), device=dev)
-        bank_enc = torch.empty((NB, 90, 256), device=dev)
-    torch.cuda.synchronize(); D.barrier()
-    t0 = time.perf_counter()
-    D.broadcast_([bank_nm, bank_enc], src=0)
-    torch.cuda.synchronize()
-    bcast_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else None
-    bank = ContextBank(model, bank_nm, bank_enc, bf16=True)
+    bank = ContextBank(model, bank_nm, bank_enc, bf16=True) if rank == 0 else None
+    bcast_ms = None
+    if torch.distributed.is_initialized():
+        # the bank travels through the C ABI: mocha_bank_broadcast (scatter + all-gather over RCCL / xGMI)
+        D.init_comm(model)
+        torch.cuda.synchronize(); D.barrier()
+        t0 = time.perf_counter()
+        bank = D.bank_broadcast(model, bank, NB, root=0, bf16=True)
+        torch.cuda.synchronize()
+        bcast_ms = D.max_over_ranks((time.perf_counter() - t0) * 1e3, dev)
     with torch.no_grad():
         for _ in range(a.warmup):
             bank.characterize(src, mean, std)
@@ -146,13 +174,76 @@ def bank4k(a):
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]/[3]: 1024 windows x 4096-entry bank (bf16 cnt), V={V}, {W // world} windows per GPU",
                        "parallelism": f"dp{world}, bank broadcast from rank 0"},
-            "bank_broadcast_ms": bcast_ms, "bank_bytes": bank_nm.numel() * 4 + bank_enc.numel() * 4}), flush=True)
+            "bank_broadcast_ms": bcast_ms, "bank_bytes": 2 * NB * 90 * 256 * 4}), flush=True)
     if torch.distributed.is_initialized():
         D.barrier(); torch.distributed.destroy_process_group()
 
 
+def match_records(model, dev):
+    """Roofline of the context-matching kernels on the shapes SURVEY.md §8(d) names for the HBM target: one streamed query
+    against a 16 384-entry bank (configs[4]) and 128 queries against a 4 096-entry bf16 bank (configs[3], per-GPU share).
+    Algorithmic bytes = (N + Q) * 23040 * element size + 4 Q; time = sum of every kernel of one mocha_match call, HIP events."""
+    from mocha_sigasia2023_amd import ContextBank
+    D = 90 * 256
+    out = {}
+    g = torch.Generator(device=dev); g.manual_seed(16384)
+    big = torch.randn((16384, D), device=dev, generator=g)
+    for name, N, Q, bf16 in (("q1_x_16k_f32", 16384, 1, False), ("q1_x_16k_bf16", 16384, 1, True), ("q128_x_4k_bf16", 4096, 128, True),
+                             ("q128_x_4k_f32", 4096, 128, False)):
+        nm = big[:N]
+        bank = ContextBank(model, nm, nm.view(N, 90, 256), bf16=bf16)
+        q = torch.randn((Q, D), device=dev, generator=g)
+        for _ in range(3):
+            bank.query(q)
+        torch.cuda.synchronize()
+        reps = 10
+        model.profile_start()
+        for _ in range(reps):
+            bank.query(q)
+        prof = model.profile_stop()
+        us = sum(v["ms"] for v in prof["kernels"].values()) / reps * 1e3
+        elt = 2 if bf16 else 4
+        by = (N * elt + Q * 4) * D + 4 * Q
+        fl = 2.0 * Q * N * D
+        out[name] = {"us": us, "algorithmic_bytes": by, "GB/s": by / us / 1e3, "frac_of_hbm_peak": by / us / 1e3 / PEAK_HBM_GBS,
+                     "TFLOP/s": fl / us / 1e6, "kernels": {k: v["ms"] / reps * 1e3 for k, v in prof["kernels"].items()}}
+    del big
+    return out
+
+
+def stream_record(model, dev, V):
+    """BASELINE configs[4]: a 300-frame clip streamed window by window (285 windows) against a 16 384-entry bank through the
+    captured per-window step (mocha_step_graph)."""
+    from mocha_sigasia2023_amd import ContextBank, StreamingCharacterizer, synthetic
+    D = 90 * 256
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    nm = torch.randn((16384, D), device=dev, generator=g)
+    m_, s_ = synthetic.cnt_norm(7)
+    src = torch.from_numpy(synthetic.pose_windows(5, 285, V)).to(dev)
+    out = {}
+    for bf16 in (False, True):
+        bank = ContextBank(model, nm, nm.view(-1, 90, 256), bf16=bf16)
+        sc = StreamingCharacterizer(bank, m_, s_, use_graph=True)
+        for i in range(5):
+            sc.step(src[i])
+        torch.cuda.synchronize()
+        lat = []
+        t_all = time.perf_counter()
+        for i in range(285):
+            t0 = time.perf_counter()
+            sc.step(src[i])
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        total = time.perf_counter() - t_all
+        lat = np.sort(np.asarray(lat)) * 1e3
+        out["bf16_bank" if bf16 else "f32_bank"] = {"windows_per_s": 285 / total, "p50_ms": float(lat[142]), "p99_ms": float(lat[282])}
+    return out
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(a)
     if a.workload == "bank4k":
         return bank4k(a)
     from mocha_sigasia2023_amd import distributed as D
@@ -183,13 +274,27 @@ def main():
         cha = torch.empty((W, 60, V, 15), dtype=torch.float32, device=dev)
         mean = torch.empty((90, 256), dtype=torch.float32, device=dev)
         std = torch.empty_like(mean)
-    bcast_ms = None
+    bcast_ms = clip_bcast_ms = None
     if dist_on:
         torch.cuda.synchronize(); D.barrier()
         t0 = time.perf_counter()
         D.broadcast_([cha, mean, std], src=0)     # RCCL over xGMI, set-up only: rank 0 owns the character clip
         torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
+        clip_bcast_ms = (time.perf_counter() - t0) * 1e3
+        # north star: "RCCL broadcast of the character feature bank over xGMI".  Rank 0 builds the bank of the character clip and
+        # hands it to every rank through the C ABI (mocha_bank_broadcast: scatter + all-gather); every rank checks what it got.
+        D.init_comm(model)
+        with torch.no_grad():
+            enc_c, _, nm_c = model.encode(cha, mean, std)
+            bank0 = ContextBank(model, nm_c, enc_c) if rank == 0 else None
+            torch.cuda.synchronize(); D.barrier()
+            t0 = time.perf_counter()
+            got = D.bank_broadcast(model, bank0, W, root=0)
+            torch.cuda.synchronize()
+            bcast_ms = D.max_over_ranks((time.perf_counter() - t0) * 1e3, dev)
+            probe = got.query(nm_c[: min(W, 16)], return_distance=False)[:, 0].cpu().tolist()
+        if probe != list(range(min(W, 16))):
+            raise SystemExit(f"rank {rank}: the broadcast bank does not reproduce the owner's bank (probe {probe})")
 
     def step_three_calls():
         enc_c, cnt_c, nm_c = model.encode(cha, mean, std)               # bank build
@@ -216,9 +321,16 @@ def main():
             Y, idx = step()
         sync_all()
         elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
     elapsed = D.max_over_ranks(elapsed, dev)
     ms_per_step = elapsed / a.steps * 1e3
     value = world * W * a.steps / elapsed
+    per_rank = [W * a.steps / my_elapsed]
+    if dist_on:
+        t = torch.tensor([per_rank[0]], dtype=torch.float64, device=dev)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        torch.distributed.all_gather(parts, t)
+        per_rank = [float(p.item()) for p in parts]
 
     # extra (not the headline): the same step with the library's two-stream overlap enabled
     dual = None
@@ -254,7 +366,9 @@ def main():
         traffic, traffic_src = pmc_traffic_for(dom)
         roofline = {
             "kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "traffic_source": (f"from profile: {traffic_src} (rocprofv3 --pmc passes of this command, committed; PMC counters cannot "
+                               "be read inside this process)") if traffic_src else None,
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
             "launches_per_step": d["launches"] // 3, "avg_launch_us": d["ms"] / d["launches"] * 1e3,
             "algorithmic_flops_per_launch": d["flops"] / d["launches"],
@@ -278,13 +392,21 @@ def main():
             "roofline": roofline,
             "kernel_breakdown": breakdown,
             "match_sites": {k: {"ms_per_step": v["ms"] / 3} for k, v in mk.items()},
-            "bank_broadcast_ms": bcast_ms,
+            "bank_broadcast_ms": bcast_ms, "clip_broadcast_ms": clip_bcast_ms,
+            "per_rank_frames_per_s": per_rank,
             "dual_stream": dual,
         }
+        if world == 1 and not a.no_extras:
+            # extra records measured in the same process (not the headline): the matcher's own roofline on the shapes the
+            # north star's ">= 50 % HBM in the context-matching kernel" is evaluated on, and the streamed configs[4] step
+            with torch.no_grad():
+                out["match"] = match_records(model, dev)
+                out["stream_16k"] = stream_record(model, dev, V)
         if not a.no_cpu_baseline and world == 1:         # the CPU leg runs at N=1 only (the other ranks would idle through it)
             m_, s_ = synthetic.cnt_norm(7)
             out["cpu_baseline"] = cpu_baseline(sd, V, a.cpu_sample, m_, s_)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
+            out["config"]["cpu_baseline_sample"] = f"{a.cpu_sample} + {a.cpu_sample} windows (the GPU workload is {W} + {W})"
         print(json.dumps(out), flush=True)
     if dist_on:
         D.barrier()

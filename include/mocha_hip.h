@@ -14,8 +14,10 @@
  *     with token = t*6 + body_part (model.py:49), bank entries likewise;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it.  Steady-state calls do not synchronise
  *     the device and are graph-capture safe; device allocations (and the device synchronisation that replacing a
- *     buffer needs) only happen in mocha_finalize_weights, mocha_reserve, mocha_bank_set, mocha_set_option and the
- *     first call with a batch (or query count) larger than any before;
+ *     buffer needs) only happen in mocha_finalize_weights, mocha_reserve, mocha_bank_set (both also size the match
+ *     scratch for every query count the workspace admits), mocha_bank_broadcast, mocha_set_option and the first call
+ *     with a batch larger than any before.  Each such replacement bumps mocha_generation(ctx): a caller that captured
+ *     calls into its own HIP graph compares the generation before replaying (mocha_step_graph does so itself);
  *   - functions return 0 on success, a negative mocha_status otherwise;
  *     mocha_last_error(ctx) gives the message.  The caller owns every in/out buffer; the
  *     context owns the device copies of the weights, the bank (unless borrowed) and the
@@ -116,6 +118,32 @@ int mocha_bank_gather(mocha_ctx* ctx, const int32_t* idx, int Q, float* out, voi
 int mocha_characterize(mocha_ctx* ctx, const float* src_X, int B, const float* cnt_mean, const float* cnt_std,
                        float* Y, int32_t* idx, void* stream);
 
+/* One streamed window per call (BASELINE configs[4]; the demo's per-frame loop test_fullframework.py:438-443, 465-467):
+ * mocha_characterize with B = 1, captured into a HIP graph on first use and replayed afterwards (one graph launch
+ * instead of ~45 kernel launches).  The graph is keyed on the five buffer pointers, `raw` and mocha_generation(ctx);
+ * it is re-captured transparently when any of them changes (new bank, grown workspace, other buffers).  X1 (1,T,V,C_in)
+ * [raw != 0: (1,T,V+1,C_in) un-normalised, after mocha_set_pose_norm], Y1 (1,T,V,C_in), idx (1,); all device memory
+ * that stays valid between calls.  `stream` may be the null stream (capture runs on an internal stream). */
+int mocha_step_graph(mocha_ctx* ctx, const float* X1, const float* cnt_mean, const float* cnt_std, float* Y1, int32_t* idx,
+                     int raw, void* stream);
+
+/* Multi-GPU set-up: one process per GPU, windows sharded across ranks, the character bank replicated.
+ * The reference has no counterpart (trainer.py:45-47 is nn.DataParallel); the only exchange on the path is this one-time
+ * bank broadcast over RCCL / xGMI.  RCCL is loaded lazily (dlopen "librccl.so.1"); single-GPU callers never touch it.
+ *   mocha_comm_unique_id : rank 0 obtains the 128-byte ncclUniqueId (HOST buffer) and ships it to the other ranks by any
+ *                          means (torch.distributed, MPI, a file);
+ *   mocha_comm_init      : every rank joins (ncclCommInitRank) — collective;
+ *   mocha_bank_broadcast : the root's current bank (mocha_bank_set, N entries) becomes every rank's current bank.
+ *                          cnt_nm and encoded travel as scatter (grouped ncclSend/ncclRecv of 1/world each) + in-place
+ *                          ncclAllGather, so that every xGMI link of the root carries a share instead of one ring
+ *                          neighbour carrying all of it; centroid, row norms and the optional bf16 copy (flags &
+ *                          MOCHA_BANK_BF16) are recomputed locally.  `comm` = an ncclComm_t created by the same librccl,
+ *                          or NULL for the context's own.  Collective; enqueued on `stream`. */
+int mocha_comm_unique_id(mocha_ctx* ctx, void* id128);
+int mocha_comm_init(mocha_ctx* ctx, const void* id128, int nranks, int rank);
+int mocha_comm_destroy(mocha_ctx* ctx);
+int mocha_bank_broadcast(mocha_ctx* ctx, void* comm, int root, int64_t N, int flags, void* stream);
+
 /* Pose normalisation of the demo fused into the path: the four norm.npz
  * arrays of the reference (test_fullframework.py:64-71), HOST fp32, (V+1)*C_in each with the root bone
  * first.  Afterwards the *_raw entry points take un-normalised poses WITH the root bone,
@@ -201,6 +229,9 @@ int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
 
 /* Introspection for tests and tooling. */
 int mocha_abi_version(void);
+/* Monotonic counter, bumped whenever the context replaces a device buffer a captured graph may hold (workspaces, match
+ * scratch, CVAE workspace) or its current bank changes.  Host-side; no synchronisation. */
+int64_t mocha_generation(const mocha_ctx* ctx);
 int mocha_graph_constants(mocha_ctx* ctx, float* A_j /*3*V*V host*/, float* A_b /*2*6*6 host*/,
                           float* pool /*V*6 host*/, float* unpool /*6*V host*/);
 

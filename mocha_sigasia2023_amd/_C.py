@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmocha_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class mocha_cfg(C.Structure):
@@ -62,6 +62,12 @@ SIGNATURES = {
     "mocha_column_stats": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "mocha_set_option": (_i, [_vp, C.c_char_p, _i]),
     "mocha_graph_constants": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "mocha_generation": (_i64, [_vp]),
+    "mocha_step_graph": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mocha_comm_unique_id": (_i, [_vp, _vp]),
+    "mocha_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "mocha_comm_destroy": (_i, [_vp]),
+    "mocha_bank_broadcast": (_i, [_vp, _vp, _i, _i64, _i, _vp]),
     "mocha_profile_start": (_i, [_vp]),
     "mocha_profile_stop": (_i, [_vp, C.c_char_p, _i64]),
 }

@@ -142,6 +142,6 @@ hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* que
 hipError_t launch_to_bf16(const float* x, const float* sub /*per-column, or null*/, int cols, void* y, int64_t n, hipStream_t s);
 hipError_t launch_rownorm2_bf16(const void* x, float* out, int64_t rows, int cols, hipStream_t s);
 // out[q] = src[idx[q]] rows of `cols` floats
-hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, int Q, int cols, hipStream_t s);
+hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, int Q, int cols, int64_t nrows, hipStream_t s);
 
 }  // namespace mocha

@@ -4,6 +4,9 @@
 #include "../../include/mocha_hip.h"
 #include "kernels.h"
 
+#include <rccl/rccl.h>      // types only: the RCCL entry points are resolved at run time (see Rccl below)
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -106,6 +109,10 @@ struct mocha_ctx {
 
     std::vector<float*> owned;                 // every hipMalloc'ed pointer
     std::map<std::string, float*> w;           // repacked device weights by short name
+    std::map<std::string, size_t> wsize, cwsize;   // element counts of w / cw entries (re-loading reuses the allocation)
+    // Bumped whenever a device buffer that a captured graph may have baked in is replaced (workspaces, match scratch,
+    // CVAE workspace) or the current bank changes: graph holders compare mocha_generation() before replaying.
+    int64_t generation = 1;
     int ntok = 90, nT15 = 15, dim = 256, d4 = 64;
 
     // workspaces: sized for `chunk` windows; larger batches are processed chunk by chunk
@@ -145,6 +152,15 @@ struct mocha_ctx {
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
     unsigned long long* best_ws[2] = {nullptr, nullptr}; size_t best_ws_n[2] = {0, 0};
 
+    // captured per-window step (mocha_step_graph): one executable graph, re-captured when its key changes
+    struct StepGraph {
+        hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr;
+        const void *x = nullptr, *mean = nullptr, *sd = nullptr; void *y = nullptr, *idx = nullptr;
+        int64_t generation = -1; bool raw = false;
+    } step;
+    hipStream_t cap_stream = nullptr;                 // capture happens on this internal stream (the caller's may be the null stream)
+    ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 1;      // mocha_comm_init
+
     // per-launch HIP-event profiling (mocha_profile_start/stop); off in normal operation
     struct ProfRec { std::string kernel, site; hipEvent_t e0, e1; double flops, bytes; };
     bool prof_on = false;
@@ -175,14 +191,29 @@ int dev_alloc(mocha_ctx* c, float** out, size_t nfloats) {
     return 0;
 }
 
-int upload(mocha_ctx* c, const std::string& name, const std::vector<float>& v) {
+void dev_free(mocha_ctx* c, float* p) {
+    if (!p) return;
+    (void)hipFree(p);
+    c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), p), c->owned.end());
+}
+
+// host -> device copy of one named tensor; a re-load (second load_state_dict on the same context) reuses the
+// existing allocation when the size is unchanged and frees it otherwise, so repeated loads do not leak
+int upload_to(mocha_ctx* c, std::map<std::string, float*>& tab, std::map<std::string, size_t>& sizes, const std::string& name,
+              const std::vector<float>& v) {
     float* d = nullptr;
-    int rc = dev_alloc(c, &d, v.size());
-    if (rc) return rc;
+    auto it = tab.find(name);
+    if (it != tab.end() && sizes[name] == v.size()) d = it->second;
+    else {
+        if (it != tab.end()) { HIPCHK(c, hipDeviceSynchronize()); dev_free(c, it->second); tab.erase(it); }
+        int rc = dev_alloc(c, &d, v.size());
+        if (rc) return rc;
+    }
     HIPCHK(c, hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
-    c->w[name] = d;
+    tab[name] = d; sizes[name] = v.size();
     return 0;
 }
+int upload(mocha_ctx* c, const std::string& name, const std::vector<float>& v) { return upload_to(c, c->w, c->wsize, name, v); }
 
 void build_expectations(mocha_ctx* c) {
     const mocha_cfg& g = c->cfg;
@@ -294,10 +325,7 @@ int ensure_ws(mocha_ctx* c, int B) {
     // free old workspaces
     for (int set = 0; set < 2; ++set) {
         for (auto& kv : c->wss[set]) {
-            if (kv.second.p) {
-                (void)hipFree(kv.second.p);
-                c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), kv.second.p), c->owned.end());
-            }
+            dev_free(c, kv.second.p);
         }
         c->wss[set].clear();
         if (c->idx_ws[set]) { (void)hipFree(c->idx_ws[set]); c->idx_ws[set] = nullptr; }
@@ -316,6 +344,7 @@ int ensure_ws(mocha_ctx* c, int B) {
     }
     c->idx_ws_n = want;
     c->chunk = want;
+    c->generation++;
     return 0;
 }
 
@@ -538,9 +567,12 @@ int for_chunks(mocha_ctx* c, int B, hipStream_t s, F&& fn) {
     c->cur = 1;
     for (int b0 = h; b0 < B && !rc; b0 += c->chunk) rc = fn(b0, std::min(c->chunk, B - b0), c->aux);
     c->cur = 0;
-    HIPCHK(c, hipEventRecord(c->ev_join, c->aux));
-    HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0));
-    return rc;
+    // join even when a half failed: the caller's stream must not be left forked (an open capture would be invalidated)
+    const hipError_t ej = hipEventRecord(c->ev_join, c->aux);
+    const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(s, c->ev_join, 0) : ej;
+    if (rc) return rc;
+    HIPCHK(c, ew);
+    return 0;
 }
 
 int ready(mocha_ctx* c, int B) {
@@ -561,11 +593,43 @@ int ready(mocha_ctx* c, int B) {
 int grow(mocha_ctx* c, DevBuf& b, size_t need) {
     if (b.n >= need) return 0;
     HIPCHK(c, hipDeviceSynchronize());
-    if (b.p) { (void)hipFree(b.p); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), b.p), c->owned.end()); }
+    dev_free(c, b.p);
     b = DevBuf{};
     int rc = dev_alloc(c, &b.p, need);
     if (rc) return rc;
     b.n = need;
+    c->generation++;
+    return 0;
+}
+
+// split of the many-query GEMM's K loop over gridDim.z so that a launch has about three tiles per CU
+int match_ksplit(int Q, int64_t N) {
+    const long long tiles = (long long)((Q + 127) / 128) * ((N + 127) / 128);
+    return (int)std::min<long long>(16, std::max<long long>(1, (768 + tiles - 1) / tiles));
+}
+
+// Scratch of do_match for up to Q queries against N bank rows, in workspace set `set`: centred queries, the streaming
+// scan's partial minima, the GEMM's score slabs.  mocha_reserve and mocha_bank_set call it for the workspace chunk, so
+// that a steady-state match never allocates (graph-capture safe); do_match itself calls it for exactly its Q.
+int ensure_match_scratch(mocha_ctx* c, int set, int Q, int64_t N, bool every_q_up_to) {
+    const size_t D = 90 * 256;
+    int rc;
+    if ((rc = grow(c, c->match_qc[set], (size_t)std::max(Q, 8) * D))) return rc;
+    const size_t need_ws = match_stream_scratch(8, N);
+    if (c->best_ws_n[set] < need_ws) {
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->best_ws[set]) (void)hipFree(c->best_ws[set]);
+        c->best_ws[set] = nullptr; c->best_ws_n[set] = 0;
+        void* bp = nullptr;
+        HIPCHK(c, hipMalloc(&bp, sizeof(unsigned long long) * need_ws));
+        c->best_ws[set] = (unsigned long long*)bp; c->best_ws_n[set] = need_ws;
+        c->generation++;
+    }
+    if (Q > 8) {
+        size_t need = 0;
+        for (int q = every_q_up_to ? 9 : Q; q <= Q; ++q) need = std::max(need, (size_t)match_ksplit(q, N) * q * (size_t)N);
+        if ((rc = grow(c, c->match_S[set], need))) return rc;
+    }
     return 0;
 }
 
@@ -575,20 +639,12 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     const int64_t N = c->bank_N;
     const int set = c->cur;
     int rc;
+    if ((rc = ensure_match_scratch(c, set, Q, N, false))) return rc;
     const bool need_qc = c->bank_is_bf16 || Q > 8;       // the bf16 bank holds bf16(b - c); the GEMM works on centred operands
-    if (need_qc) {
-        if ((rc = grow(c, c->match_qc[set], (size_t)Q * D))) return rc;
+    if (need_qc)
         LAUNCH(c, s, "mocha_sub_rows", "match.center", 0.0, 8.0 * Q * D, launch_sub_rows(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
-    }
     const float* qc = need_qc ? c->match_qc[set].p : nullptr;
     if (Q <= 8) {
-        const size_t need_ws = match_stream_scratch(Q, N);
-        if (c->best_ws_n[set] < need_ws) {
-            if (c->best_ws[set]) (void)hipFree(c->best_ws[set]);
-            void* bp = nullptr;
-            HIPCHK(c, hipMalloc(&bp, sizeof(unsigned long long) * need_ws));
-            c->best_ws[set] = (unsigned long long*)bp; c->best_ws_n[set] = need_ws;
-        }
         const void* bank = c->bank_is_bf16 ? (const void*)c->bank_bf16 : (const void*)c->bank_cnt;
         const double passes = (Q + 7) / 8;
         LAUNCH(c, s, c->bank_is_bf16 ? "mocha_match_stream<bf16>" : "mocha_match_stream<f32>", "match.stream", 3.0 * Q * N * D,
@@ -596,10 +652,8 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
                launch_match_stream(bank, c->bank_is_bf16 ? 1 : 0, c->bank_is_bf16 ? qc : qnm, Q, N, D, c->best_ws[set], idx, dist, s));
         return 0;
     }
-    const long long tiles = (long long)((Q + 127) / 128) * ((N + 127) / 128);
-    int ksplit = (int)std::min<long long>(16, std::max<long long>(1, (768 + tiles - 1) / tiles));
+    const int ksplit = match_ksplit(Q, N);
     DevBuf& mS = c->match_S[set];
-    if ((rc = grow(c, mS, (size_t)ksplit * Q * N))) return rc;
     GemmParams g = plain(qc, D, c->bank_cnt, mS.p, (int)N, Q, (int)N, D);
     g.ksplit = ksplit; g.slab_stride = (long long)Q * N;
     if (c->bank_is_bf16) {
@@ -622,7 +676,9 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
 // =========================================================================================== C ABI
 extern "C" {
 
-int mocha_abi_version(void) { return 1; }
+int mocha_abi_version(void) { return 2; }
+
+int64_t mocha_generation(const mocha_ctx* c) { return c ? c->generation : 0; }
 
 const char* mocha_last_error(const mocha_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -667,6 +723,10 @@ void mocha_destroy(mocha_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->bone_parents) (void)hipFree(c->bone_parents);
+    if (c->step.exec) (void)hipGraphExecDestroy(c->step.exec);
+    if (c->step.graph) (void)hipGraphDestroy(c->step.graph);
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
+    (void)mocha_comm_destroy(c);
     delete c;
 }
 
@@ -811,7 +871,12 @@ int mocha_reserve(mocha_ctx* c, int max_batch) {
         HIPCHK(c, hipDeviceSynchronize());
         c->chunk = 0;
     }
-    return ensure_ws(c, max_batch);
+    int rc = ensure_ws(c, max_batch);
+    if (rc) return rc;
+    if (c->bank_N > 0)                                    // ... and the match scratch of the current bank for that many queries
+        for (int set = 0; set < ((c->dual_stream && !c->wss[1].empty()) ? 2 : 1); ++set)
+            if ((rc = ensure_match_scratch(c, set, std::max(c->chunk, 8), c->bank_N, true))) return rc;
+    return 0;
 }
 
 int mocha_pos_emb(mocha_ctx* c, const float** dev_ptr) {
@@ -913,7 +978,9 @@ int mocha_forward_features(mocha_ctx* c, const float* src_X, const float* cha_X,
     return mocha_encode(c, cha_X, B, cha_enc, cha_cnt, nullptr, nullptr, nullptr, stream);
 }
 
-int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int64_t N, int flags, void* stream) {
+// `current`: the bank becomes the context's current bank (mocha_bank_set); false for the transient bank of
+// mocha_characterize_pair, which is swapped out again before the call returns and must not invalidate captured graphs
+static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded, int64_t N, int flags, void* stream, bool current) {
     int rc = ready(c, 0); if (rc) return rc;
     if (!cnt_nm || !encoded || N < 1 || N > (int64_t)1 << 30) return fail(c, MOCHA_ERR_ARG, "bad bank arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -923,7 +990,7 @@ int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int6
     } else {
         if (c->bank_cap < (size_t)N) {
             for (float** p : {&c->bank_cnt_own, &c->bank_enc_own})
-                if (*p) { (void)hipFree(*p); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), *p), c->owned.end()); *p = nullptr; }
+                if (*p) { dev_free(c, *p); *p = nullptr; }
             if ((rc = dev_alloc(c, &c->bank_cnt_own, (size_t)N * D))) return rc;
             if ((rc = dev_alloc(c, &c->bank_enc_own, (size_t)N * D))) return rc;
             c->bank_cap = (size_t)N;
@@ -933,26 +1000,18 @@ int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int6
         c->bank_cnt = c->bank_cnt_own; c->bank_enc = c->bank_enc_own;
     }
     if (c->bank_norm_cap < (size_t)N) {
-        if (c->bank_norm) { (void)hipFree(c->bank_norm); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), c->bank_norm), c->owned.end()); c->bank_norm = nullptr; }
+        if (c->bank_norm) { dev_free(c, c->bank_norm); c->bank_norm = nullptr; }
         if ((rc = dev_alloc(c, &c->bank_norm, (size_t)N))) return rc;
         c->bank_norm_cap = (size_t)N;
     }
     c->bank_N = N;
-    {                                                     // scratch of the streaming matcher for up to 8 queries
-        const size_t need_ws = match_stream_scratch(8, N);  // (allocated here so a later single-query step is capture-safe)
-        for (int set = 0; set < 2; ++set)
-            if (c->best_ws_n[set] < need_ws) {
-                if (c->best_ws[set]) (void)hipFree(c->best_ws[set]);
-                void* bp = nullptr;
-                HIPCHK(c, hipMalloc(&bp, sizeof(unsigned long long) * need_ws));
-                c->best_ws[set] = (unsigned long long*)bp; c->best_ws_n[set] = need_ws;
-            }
-    }
+    if (current) c->generation++;                         // a captured step has the previous bank's pointers and row count baked in
+    // match scratch for every query count the workspace admits: a later match never allocates (capture-safe)
+    for (int set = 0; set < ((c->dual_stream && !c->wss[1].empty()) ? 2 : 1); ++set)
+        if ((rc = ensure_match_scratch(c, set, std::max(c->chunk, 8), N, true))) return rc;
     c->bank_is_bf16 = (flags & MOCHA_BANK_BF16) != 0;
     // centroid of the bank: the many-query GEMM and the bf16 copy work on b - centroid (see do_match)
     if (!c->bank_center && (rc = dev_alloc(c, &c->bank_center, D))) return rc;
-    for (int set = 0; set < 2; ++set)                    // centred queries of a <= 8-query step: allocated here (capture-safe later)
-        if ((rc = grow(c, c->match_qc[set], (size_t)8 * D))) return rc;
     if (!c->center_scratch && (rc = dev_alloc(c, &c->center_scratch, 2 * column_mean_scratch_doubles((int)D)))) return rc;
     LAUNCH(c, s, "mocha_column_mean", "bank.center", 0.0, 4.0 * N * D,
            launch_column_mean(c->bank_cnt, N, (int)D, c->bank_center, reinterpret_cast<double*>(c->center_scratch), s));
@@ -971,6 +1030,10 @@ int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int6
     return 0;
 }
 
+int mocha_bank_set(mocha_ctx* c, const float* cnt_nm, const float* encoded, int64_t N, int flags, void* stream) {
+    return bank_set_impl(c, cnt_nm, encoded, N, flags, stream, true);
+}
+
 int mocha_match(mocha_ctx* c, const float* query_nm, int Q, int32_t* idx, float* dist, void* stream) {
     int rc = ready(c, 0); if (rc) return rc;
     if (Q == 0) return 0;
@@ -985,7 +1048,7 @@ int mocha_bank_gather(mocha_ctx* c, const int32_t* idx, int Q, float* out, void*
     if (Q == 0) return 0;
     if (!idx || !out || Q < 0) return fail(c, MOCHA_ERR_ARG, "bad gather arguments");
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, Q * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, idx, out, Q, 90 * 256, s));
+    LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, Q * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, idx, out, Q, 90 * 256, c->bank_N, s));
     return 0;
 }
 
@@ -1004,7 +1067,7 @@ static int characterize_impl(mocha_ctx* c, const float* src_X, int B, const floa
         if ((r = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return r;
         LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * 3, launch_instnorm(WS(c, "enc_s"), WS(c, "cnt"), nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s));
         if ((r = do_match(c, WS(c, "qnm"), b, ix, nullptr, s))) return r;
-        LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, b * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), b, 90 * 256, s));
+        LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, b * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), b, 90 * 256, c->bank_N, s));
         if ((r = run_decoder(c, WS(c, "enc_s"), WS(c, "sel"), b, WS(c, "dec"), s))) return r;
         return run_to_mot(c, WS(c, "dec"), b, Y + b0 * ys, s, raw);
     });
@@ -1051,11 +1114,11 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     struct Saved { const float *cnt, *enc; int64_t N; bool bf16; float* norm; size_t norm_cap; float* center; } sv{
         c->bank_cnt, c->bank_enc, c->bank_N, c->bank_is_bf16, c->bank_norm, c->bank_norm_cap, c->bank_center};
     c->bank_norm = c->pair_norm; c->bank_norm_cap = c->pair_norm_cap; c->bank_center = c->pair_center;
-    rc = mocha_bank_set(c, WS(c, "qnm"), WS(c, "enc_s"), B_cha, MOCHA_BANK_BORROW, stream);
+    rc = bank_set_impl(c, WS(c, "qnm"), WS(c, "enc_s"), B_cha, MOCHA_BANK_BORROW, stream, false);
     int32_t* ix = idx ? idx : c->idx_ws[0];
     if (!rc) rc = do_match(c, WS(c, "qnm") + (size_t)B_cha * T, B_src, ix, nullptr, s);
     if (!rc) rc = [&]() -> int {
-        LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, B_src * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), B_src, 90 * 256, s));
+        LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, B_src * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), B_src, 90 * 256, c->bank_N, s));
         return 0;
     }();
     c->pair_norm = c->bank_norm; c->pair_norm_cap = c->bank_norm_cap; c->pair_center = c->bank_center;
@@ -1074,6 +1137,179 @@ int mocha_characterize_pair(mocha_ctx* c, const float* src_X, int B_src, const f
 int mocha_characterize_pair_raw(mocha_ctx* c, const float* src_X_raw, int B_src, const float* cha_X_raw, int B_cha, const float* cnt_mean,
                                 const float* cnt_std, float* Y, int32_t* idx, float* cha_encoded, float* cha_cnt_nm, void* stream) {
     return characterize_pair_impl(c, src_X_raw, B_src, cha_X_raw, B_cha, cnt_mean, cnt_std, Y, idx, cha_encoded, cha_cnt_nm, stream, true);
+}
+
+// ------------------------------------------------------------------------------------------- captured per-window step
+// BASELINE configs[4]: a clip streamed one 60-frame window per step.  The whole step (mot_embedding, +pos_emb, encoder, cnt,
+// z-score, bank scan, gather, decoder, to_mot: test_fullframework.py:438-443, 465-467) is captured once into a HIP graph and
+// replayed; the graph is keyed on the buffer pointers and on the context generation, and re-captured when either changes.
+int mocha_step_graph(mocha_ctx* c, const float* X1, const float* cnt_mean, const float* cnt_std, float* Y1, int32_t* idx,
+                     int raw, void* stream) {
+    int rc = ready(c, 1); if (rc) return rc;
+    if (!X1 || !cnt_mean || !cnt_std || !Y1 || !idx) return fail(c, MOCHA_ERR_ARG, "null argument");
+    if (!c->bank_cnt) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
+    hipStream_t s = (hipStream_t)stream;
+    auto& g = c->step;
+    const bool hit = g.exec && g.x == X1 && g.mean == cnt_mean && g.sd == cnt_std && g.y == Y1 && g.idx == idx &&
+                     g.generation == c->generation && g.raw == (raw != 0);
+    if (!hit) {
+        if (c->prof_on) return fail(c, MOCHA_ERR_STATE, "mocha_step_graph: stop profiling before capturing");
+        // make sure nothing inside the captured region allocates (scratch for one query against the current bank)
+        if ((rc = ensure_match_scratch(c, 0, 8, c->bank_N, true))) return rc;
+        if (!c->cap_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+        const int64_t gen0 = c->generation;
+        HIPCHK(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeRelaxed));
+        rc = characterize_impl(c, X1, 1, cnt_mean, cnt_std, Y1, idx, c->cap_stream, raw != 0);
+        hipGraph_t graph = nullptr;
+        const hipError_t ee = hipStreamEndCapture(c->cap_stream, &graph);
+        if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (ee != hipSuccess) return fail(c, MOCHA_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ee));
+        if (c->generation != gen0) { (void)hipGraphDestroy(graph); return fail(c, MOCHA_ERR_STATE, "a buffer was replaced during capture"); }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ei != hipSuccess) { (void)hipGraphDestroy(graph); return fail(c, MOCHA_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ei)); }
+        g.exec = exec; g.graph = graph; g.x = X1; g.mean = cnt_mean; g.sd = cnt_std; g.y = Y1; g.idx = idx;
+        g.generation = c->generation; g.raw = raw != 0;
+    }
+    HIPCHK(c, hipGraphLaunch(g.exec, s));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------- RCCL (multi-GPU set-up)
+// One process per GPU; the only exchange on the path is the one-time broadcast of the character bank.
+// RCCL is resolved at run time (dlopen of librccl.so.1) so that single-GPU users never load it.
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load(mocha_ctx* c) {
+    if (g_rccl.h) return 0;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(c, MOCHA_ERR_STATE, "cannot load RCCL (librccl.so.1): %s", dlerror());
+    Rccl r; r.h = h;
+    bool ok = true;
+    auto sym = [&](const char* n) { void* p = dlsym(h, n); if (!p) ok = false; return p; };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))sym("ncclCommUserRank");
+    r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+    r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+    r.Send = (decltype(r.Send))sym("ncclSend");
+    r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(h); return fail(c, MOCHA_ERR_STATE, "librccl lacks an expected entry point"); }
+    g_rccl = r;
+    return 0;
+}
+#define NCCLCHK(c, expr)                                                                                                  \
+    do {                                                                                                                  \
+        ncclResult_t r__ = (expr);                                                                                        \
+        if (r__ != ncclSuccess) return fail((c), MOCHA_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(r__));    \
+    } while (0)
+
+// Broadcast `count` floats from `root` so that every xGMI link of the root carries traffic: the root sends chunk r to
+// rank r (grouped point-to-point = scatter), then an in-place all-gather completes every rank's copy.  A flat
+// ncclBroadcast is a ring through the root's neighbours and bound by one link (~153 GB/s); scatter + all-gather moves
+// 1/world of the data per link and step.  The count % world tail (a few floats) goes through one small ncclBroadcast.
+int bcast_chunked(mocha_ctx* c, ncclComm_t comm, int world, int rank, int root, float* buf, size_t count, hipStream_t s) {
+    if (world == 1 || count == 0) return 0;
+    const size_t chunk = count / (size_t)world, tail = count - chunk * (size_t)world;
+    if (chunk > 0) {
+        NCCLCHK(c, g_rccl.GroupStart());
+        if (rank == root) {
+            for (int r = 0; r < world; ++r)
+                if (r != root) NCCLCHK(c, g_rccl.Send(buf + chunk * (size_t)r, chunk, ncclFloat32, r, comm, s));
+        } else {
+            NCCLCHK(c, g_rccl.Recv(buf + chunk * (size_t)rank, chunk, ncclFloat32, root, comm, s));
+        }
+        NCCLCHK(c, g_rccl.GroupEnd());
+        NCCLCHK(c, g_rccl.AllGather(buf + chunk * (size_t)rank, buf, chunk, ncclFloat32, comm, s));
+    }
+    if (tail > 0) NCCLCHK(c, g_rccl.Broadcast(buf + chunk * (size_t)world, buf + chunk * (size_t)world, tail, ncclFloat32, root, comm, s));
+    return 0;
+}
+}  // namespace
+
+int mocha_comm_unique_id(mocha_ctx* c, void* id128) {
+    if (!c || !id128) return fail(c, MOCHA_ERR_ARG, "null argument");
+    int rc = rccl_load(c); if (rc) return rc;
+    ncclUniqueId id;
+    NCCLCHK(c, g_rccl.GetUniqueId(&id));
+    memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+int mocha_comm_init(mocha_ctx* c, const void* id128, int nranks, int rank) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, MOCHA_ERR_ARG, "bad communicator arguments");
+    int rc = rccl_load(c); if (rc) return rc;
+    if (c->comm) return fail(c, MOCHA_ERR_STATE, "communicator already initialised");
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    NCCLCHK(c, g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+    c->comm_rank = rank; c->comm_size = nranks;
+    return 0;
+}
+
+int mocha_comm_destroy(mocha_ctx* c) {
+    if (!c) return MOCHA_ERR_ARG;
+    if (c->comm && g_rccl.h) { (void)g_rccl.CommDestroy(c->comm); }
+    c->comm = nullptr; c->comm_rank = 0; c->comm_size = 1;
+    return 0;
+}
+
+int mocha_bank_broadcast(mocha_ctx* c, void* comm_, int root, int64_t N, int flags, void* stream) {
+    int rc = ready(c, 0); if (rc) return rc;
+    if ((rc = rccl_load(c))) return rc;
+    ncclComm_t comm = comm_ ? (ncclComm_t)comm_ : c->comm;
+    if (!comm) return fail(c, MOCHA_ERR_STATE, "no communicator: call mocha_comm_init first or pass one");
+    int world = 1, rank = 0;
+    NCCLCHK(c, g_rccl.CommCount(comm, &world));
+    NCCLCHK(c, g_rccl.CommUserRank(comm, &rank));
+    if (root < 0 || root >= world || N < 1 || N > (int64_t)1 << 30) return fail(c, MOCHA_ERR_ARG, "bad bank_broadcast arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t D = 90 * 256;
+    if (rank == root) {
+        if (!c->bank_cnt || c->bank_N != N) return fail(c, MOCHA_ERR_STATE, "root has no current bank of %lld entries", (long long)N);
+    } else {
+        if (c->bank_cap < (size_t)N) {
+            HIPCHK(c, hipDeviceSynchronize());
+            for (float** p : {&c->bank_cnt_own, &c->bank_enc_own})
+                if (*p) { dev_free(c, *p); *p = nullptr; }
+            if ((rc = dev_alloc(c, &c->bank_cnt_own, (size_t)N * D))) return rc;
+            if ((rc = dev_alloc(c, &c->bank_enc_own, (size_t)N * D))) return rc;
+            c->bank_cap = (size_t)N;
+        }
+    }
+    // the root's own chunks are rewritten in place with identical values by the all-gather (a borrowed bank stays unchanged)
+    float* cnt = rank == root ? const_cast<float*>(c->bank_cnt) : c->bank_cnt_own;
+    float* enc = rank == root ? const_cast<float*>(c->bank_enc) : c->bank_enc_own;
+    if ((rc = bcast_chunked(c, comm, world, rank, root, cnt, (size_t)N * D, s))) return rc;
+    if ((rc = bcast_chunked(c, comm, world, rank, root, enc, (size_t)N * D, s))) return rc;
+    if (rank == root) return 0;
+    // derived data (centroid, norms, bf16 copy) is recomputed locally: deterministic kernels, same result on every rank
+    return bank_set_impl(c, c->bank_cnt_own, c->bank_enc_own, N, (flags & MOCHA_BANK_BF16) | MOCHA_BANK_BORROW, stream, true);
 }
 
 int mocha_set_pose_norm(mocha_ctx* c, const float* x_mean, const float* x_std, const float* y_mean, const float* y_std) {
@@ -1165,10 +1401,7 @@ int mocha_cvae_finalize(mocha_ctx* c) {
         if (!c->cvae_host.count(kv.first)) return fail(c, MOCHA_ERR_STATE, "missing CVAE weight '%s'", kv.first.c_str());
     HIPCHK(c, hipSetDevice(c->device));
     for (auto& kv : c->cvae_host) {
-        float* d = nullptr;
-        int rc = dev_alloc(c, &d, kv.second.data.size()); if (rc) return rc;
-        HIPCHK(c, hipMemcpy(d, kv.second.data.data(), kv.second.data.size() * sizeof(float), hipMemcpyHostToDevice));
-        c->cw[kv.first] = d;
+        int rc = upload_to(c, c->cw, c->cwsize, kv.first, kv.second.data); if (rc) return rc;
     }
     if (c->cw.count("pe")) { c->cvae_ready = true; return 0; }     // table came with the state_dict (pos_encoder.pe)
     // sin/cos positional encoding rows 0..191 (model_CVAE.py:168-178), float32 arithmetic like torch
@@ -1181,10 +1414,7 @@ int mocha_cvae_finalize(mocha_ctx* c) {
             pe[t * 256 + 2 * i + 1] = cosf(a);
         }
     }
-    float* dpe = nullptr;
-    int rc = dev_alloc(c, &dpe, pe.size()); if (rc) return rc;
-    HIPCHK(c, hipMemcpy(dpe, pe.data(), pe.size() * sizeof(float), hipMemcpyHostToDevice));
-    c->cw["pe"] = dpe;
+    int rc = upload_to(c, c->cw, c->cwsize, "pe", pe); if (rc) return rc;
     c->cvae_ready = true;
     return 0;
 }
@@ -1192,8 +1422,9 @@ int mocha_cvae_finalize(mocha_ctx* c) {
 static int cvae_ws(mocha_ctx* c, int B) {
     if (c->cvae_B >= B) return 0;
     if (c->cvae_B > 0) HIPCHK(c, hipDeviceSynchronize());
-    for (auto& kv : c->cws) if (kv.second.p) { (void)hipFree(kv.second.p); c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), kv.second.p), c->owned.end()); }
+    for (auto& kv : c->cws) dev_free(c, kv.second.p);
     c->cws.clear();
+    c->generation++;
     const std::pair<const char*, size_t> plan[] = {{"t0", 182 * 256}, {"t1", 182 * 256}, {"t2", 182 * 256}, {"qkv", 182 * 768},
                                                    {"hff", 182 * 512}, {"mem", 181 * 256}, {"kv", 181 * 512}};
     for (auto& pl : plan) { DevBuf b; b.n = pl.second * (size_t)B; int rc = dev_alloc(c, &b.p, b.n); if (rc) return rc; c->cws[pl.first] = b; }
@@ -1398,20 +1629,6 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "dual_min") { c->dual_min = value < 2 ? 2 : value; return 0; }
     if (n == "fold_decoder") { c->fold_decoder = value != 0; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);
-}
-
-// debugging aid (not in the public header): copy a workspace buffer to the host after a device sync
-int mocha_debug_read(mocha_ctx* c, const char* name, float* host, int64_t count) {
-    if (!c || !name || !host) return MOCHA_ERR_ARG;
-    HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipDeviceSynchronize());
-    const std::string n(name);
-    const DevBuf* b = nullptr;
-    if (n.rfind("cvae.", 0) == 0 && c->cws.count(n.substr(5))) b = &c->cws.at(n.substr(5));
-    else if (c->wss[0].count(n)) b = &c->wss[0].at(n);
-    if (!b || (size_t)count > b->n) return fail(c, MOCHA_ERR_ARG, "no such buffer or too many elements");
-    HIPCHK(c, hipMemcpy(host, b->p, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
-    return 0;
 }
 
 int mocha_profile_start(mocha_ctx* c) {

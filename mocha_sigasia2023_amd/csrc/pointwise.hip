@@ -512,8 +512,11 @@ __global__ __launch_bounds__(256) void mocha_argmin(const float* __restrict__ S,
     }
     // ---- 2. exact squared distances of all candidates in one pass over the query row
     int ci[RERANK];
+    // pad with the best (harmless duplicate); when no score was finite (NaN / inf queries or bank rows) there is no best
+    // either: fall back to row 0 so that no address below is out of range -- the distance then comes out NaN / inf
+    const int first = cand[0] == 0x7fffffff ? 0 : cand[0];
 #pragma unroll
-    for (int c = 0; c < RERANK; ++c) ci[c] = cand[c] == 0x7fffffff ? cand[0] : cand[c];     // pad with the best (harmless duplicate)
+    for (int c = 0; c < RERANK; ++c) ci[c] = cand[c] == 0x7fffffff ? first : cand[c];
     float a[RERANK];
 #pragma unroll
     for (int c = 0; c < RERANK; ++c) a[c] = 0.f;
@@ -551,6 +554,10 @@ __global__ __launch_bounds__(256) void mocha_argmin(const float* __restrict__ S,
             const float d2 = (dsum[c][0] + dsum[c][1]) + (dsum[c][2] + dsum[c][3]);
             if (d2 < best_d || (d2 == best_d && cand[c] < best_i)) { best_d = d2; best_i = cand[c]; }
         }
+        if (best_i == 0x7fffffff) {                          // nothing comparable: a valid row index, distance of that row (NaN / inf)
+            best_i = 0;
+            best_d = (dsum[0][0] + dsum[0][1]) + (dsum[0][2] + dsum[0][3]);
+        }
         idx[q] = best_i;
         if (dist) dist[q] = sqrtf(best_d);
     }
@@ -566,17 +573,19 @@ hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int 
 }
 
 __global__ __launch_bounds__(256) void mocha_gather_rows(const float* __restrict__ src, const int32_t* __restrict__ idx,
-                                                         float* __restrict__ out, int cols4) {
+                                                         float* __restrict__ out, int cols4, long long nrows) {
     const size_t q = blockIdx.x;
-    const f32x4* s = reinterpret_cast<const f32x4*>(src) + (size_t)idx[q] * cols4;
+    long long r = idx[q];                              // caller-supplied indices are clamped into the bank: never out of bounds
+    r = r < 0 ? 0 : (r >= nrows ? nrows - 1 : r);
+    const f32x4* s = reinterpret_cast<const f32x4*>(src) + (size_t)r * cols4;
     f32x4* o = reinterpret_cast<f32x4*>(out) + q * cols4;
     for (int i = threadIdx.x; i < cols4; i += 256) o[i] = s[i];
 }
 
-hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, int Q, int cols, hipStream_t s) {
+hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, int Q, int cols, int64_t nrows, hipStream_t s) {
     if (Q <= 0) return hipSuccess;
-    if (cols % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_gather_rows, dim3(Q), dim3(256), 0, s, src, idx, out, cols / 4);
+    if (cols % 4 || nrows < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_gather_rows, dim3(Q), dim3(256), 0, s, src, idx, out, cols / 4, (long long)nrows);
     return hipGetLastError();
 }
 

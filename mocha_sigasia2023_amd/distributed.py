@@ -26,7 +26,11 @@ def init(backend: str, device: torch.device | None = None) -> Tuple[int, int]:
     """Initialise the default process group (rendezvous over 127.0.0.1 unless MASTER_ADDR is set)."""
     rank, _, world = env_rank()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    if "MASTER_PORT" not in os.environ:
+        if world > 1:
+            raise RuntimeError("MASTER_PORT is not set: launch the ranks with torch.distributed.run (or bench.py --gpus N), "
+                               "which choose a port per job")
+        os.environ["MASTER_PORT"] = str(20000 + os.getpid() % 20000)      # single rank: any free-ish port, per process
     if not dist.is_initialized():
         kw = {}
         if backend == "nccl" and device is not None:
@@ -47,6 +51,37 @@ def broadcast_(tensors: Iterable[torch.Tensor], src: int = 0) -> None:
     if dist.is_initialized():
         for t in tensors:
             dist.broadcast(t, src=src)
+
+
+def init_comm(model) -> None:
+    """Give the model's context its RCCL communicator (``mocha_comm_init``): rank 0 draws the 128-byte unique id through
+    the C ABI and the default process group (any backend) ships it to the other ranks."""
+    import ctypes as C
+    rank, _, world = env_rank()
+    if getattr(model, "_comm_ready", False):
+        return
+    buf = (C.c_char * 128)()
+    if rank == 0:
+        model._ctx.call("mocha_comm_unique_id", C.cast(buf, C.c_void_p))
+    if world > 1:
+        obj = [bytes(buf.raw)]
+        dist.broadcast_object_list(obj, src=0)
+        buf = (C.c_char * 128).from_buffer_copy(obj[0])
+    model._ctx.call("mocha_comm_init", C.cast(buf, C.c_void_p), world, rank)
+    model._comm_ready = True
+
+
+def bank_broadcast(model, bank, n_entries: int, root: int = 0, bf16: bool = False):
+    """``mocha_bank_broadcast``: the root's ContextBank becomes every rank's current bank over RCCL / xGMI (scatter +
+    all-gather of cnt_nm and encoded; derived data recomputed locally).  Returns the rank's bank handle."""
+    import ctypes as C
+    from .generator import ContextBank, _stream
+    rank, _, _ = env_rank()
+    init_comm(model)
+    if rank == root:
+        bank.activate()
+    model._ctx.call("mocha_bank_broadcast", C.c_void_p(0), root, C.c_int64(n_entries), 2 if bf16 else 0, _stream())
+    return bank if rank == root else ContextBank.received(model, n_entries, bf16)
 
 
 def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:

@@ -26,8 +26,16 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+class _CurrentStream:
+    """Placeholder argument: ``_Context.call`` replaces it by the current stream of the CONTEXT's device (a caller whose
+    current device differs from the model's would otherwise hand over a stream of the wrong device)."""
+
+
+_STREAM = _CurrentStream()
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _STREAM
 
 
 def _dev_f32(t, device, shape_tail=None, name="tensor") -> torch.Tensor:
@@ -71,8 +79,15 @@ class _Context:
 
     def call(self, fn: str, *args):
         with torch.cuda.device(self.device):
+            if any(a is _STREAM for a in args):
+                st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                args = tuple(st if a is _STREAM else a for a in args)
             rc = getattr(self.lib, fn)(self.h, *args)
         _C.check(self.lib, self.h, rc, fn)
+
+    def generation(self) -> int:
+        """Bumped by the library whenever it replaces a device buffer a captured graph may hold, or the bank changes."""
+        return int(self.lib.mocha_generation(self.h))
 
     def __del__(self):
         try:
@@ -355,8 +370,22 @@ class ContextBank:
         self._bf16 = bf16          # match against a bf16 copy of cnt_nm (half the bytes per bank scan)
         self.activate()
 
+    @classmethod
+    def received(cls, model: "Generator", n_entries: int, bf16: bool = False) -> "ContextBank":
+        """Handle for a bank that ``mocha_bank_broadcast`` delivered into the context's own buffers on a non-root rank
+        (distributed.bank_broadcast): it has no tensors of its own and is the context's current bank."""
+        self = cls.__new__(cls)
+        self.model, self.N, self._copy, self._bf16 = model, int(n_entries), True, bf16
+        self.cnt_nm = self.encoded = None
+        model._bank = self
+        return self
+
     def activate(self):
         """Make this bank the context's current bank (borrowed buffers unless copy=True)."""
+        if self.cnt_nm is None:
+            if getattr(self.model, "_bank", None) is not self:
+                raise RuntimeError("a received bank lives in the context and was replaced by another bank: broadcast it again")
+            return self
         flags = (0 if self._copy else 1) | (2 if self._bf16 else 0)
         self.model._ctx.call("mocha_bank_set", _ptr(self.cnt_nm), _ptr(self.encoded), self.N, flags, _stream())
         self.model._bank = self
@@ -406,39 +435,36 @@ class StreamingCharacterizer:
     """Window-by-window characterization (BASELINE configs[4]: a clip streamed one 60-frame window
     per step against a large bank).  The whole per-window step — encode, z-score, 1-NN bank scan,
     gather, decoder, to_mot (test_fullframework.py:438-443,465-467) — is captured once into a HIP
-    graph and replayed per window, so the ~45 kernel launches cost one graph launch."""
+    graph by the library (``mocha_step_graph``) and replayed per window, so the ~45 kernel launches cost one
+    graph launch.  The library re-captures by itself when the bank or a workspace it baked in has changed; this class
+    re-activates its bank when another bank was made current in between."""
 
     def __init__(self, bank: ContextBank, cnt_mean, cnt_std, use_graph: bool = True):
         self.bank, self.model = bank, bank.model
         m = self.model
-        m.reserve(max(m._reserved if hasattr(m, "_reserved") else 1, 1))
         self.mean = _dev_f32(cnt_mean, m.device, (NTOK, DIM), "cnt_mean")
         self.std = _dev_f32(cnt_std, m.device, (NTOK, DIM), "cnt_std")
         self.x = torch.zeros((1, m.cfg["nframes"], m.V, m.cfg["mot_in_dim"]), dtype=torch.float32, device=m.device)
         self.y = torch.empty_like(self.x)
         self.idx = torch.zeros((1,), dtype=torch.int32, device=m.device)
+        self.use_graph = use_graph
         bank.activate()
-        self._enqueue()                                   # warm-up outside capture (lazy allocations, module load)
-        torch.cuda.synchronize(m.device)
-        self.graph = None
-        if use_graph:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._enqueue()
-            self.graph = g
 
     def _enqueue(self):
-        self.model._ctx.call("mocha_characterize", _ptr(self.x), 1, _ptr(self.mean), _ptr(self.std), _ptr(self.y),
-                             _ptr(self.idx), _stream())
+        if getattr(self.model, "_bank", None) is not self.bank:
+            self.bank.activate()                           # another bank was made current: ours again (bumps the generation)
+        if self.use_graph:
+            self.model._ctx.call("mocha_step_graph", _ptr(self.x), _ptr(self.mean), _ptr(self.std), _ptr(self.y),
+                                 _ptr(self.idx), 0, _stream())
+        else:
+            self.model._ctx.call("mocha_characterize", _ptr(self.x), 1, _ptr(self.mean), _ptr(self.std), _ptr(self.y),
+                                 _ptr(self.idx), _stream())
 
     def step(self, window: torch.Tensor):
         """window (60, V, 15) or (1, 60, V, 15) on the GPU -> (Y (60, V, 15) view, idx tensor view); both
         are overwritten by the next step."""
         self.x.copy_(window.reshape(self.x.shape), non_blocking=True)
-        if self.graph is not None:
-            self.graph.replay()
-        else:
-            self._enqueue()
+        self._enqueue()
         return self.y[0], self.idx
 
 
@@ -584,6 +610,9 @@ class OursSession:
         if not self.use_graph:
             self._enqueue(with_eps)
         else:
+            gen = (self.model._ctx.generation(), self.cvae._ctx.generation())
+            if getattr(self, "_graph_gen", None) != gen:          # a workspace a graph baked in was replaced: capture again
+                self._graphs = {}
             g = self._graphs.get(with_eps)
             if g is None:
                 keep = self.prev.clone()
@@ -594,6 +623,7 @@ class OursSession:
                 with torch.cuda.graph(g):
                     self._enqueue(with_eps)
                 self._graphs[with_eps] = g
+                self._graph_gen = (self.model._ctx.generation(), self.cvae._ctx.generation())
                 self.prev.copy_(keep)
             g.replay()
         return self.Y, self.cur

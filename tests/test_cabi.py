@@ -59,3 +59,14 @@ def test_weight_schema_matches_reference_count():
     assert n == 6116559
     sd = weights.synthetic_state_dict(1, 1.0)
     assert set(weights.param_shapes()) | set(weights.buffer_arrays()) == set(sd)
+
+
+def test_bench_launcher_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` spawns its own ranks; on a node with fewer GPUs (here: none) it must refuse before any
+    rank starts, without touching a GPU."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "exposes" in (r.stderr + r.stdout)

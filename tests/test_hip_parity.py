@@ -93,14 +93,14 @@ def test_to_mot(golden_dir, name):
     z, meta, model, _ = load(golden_dir, name)
     Y = model.to_mot(T(z["decoded"]))
     assert Y.shape == z["Y"].shape
-    assert absmax(Y, z["Y"]) < TOL * max(1.0, np.abs(z["Y"]).max())
+    assert absmax(Y, z["Y"]) < TOL                      # absolute (north star: 1e-4 per joint and channel)
 
 
 @pytest.mark.parametrize("name", VARIANTS)
 def test_generator_forward(golden_dir, name):
     z, meta, model, _ = load(golden_dir, name)
     Y = model(T(z["src_X"]), T(z["cha_X"]))
-    assert absmax(Y, z["Y_forward"]) < TOL * max(1.0, np.abs(z["Y"]).max())
+    assert absmax(Y, z["Y_forward"]) < TOL
     se, ce, sc, cc = model(T(z["src_X"]), T(z["cha_X"]), extract_feature=True)
     assert rel(se, z["src_encoded"]) < RTOL and rel(ce, z["cha_encoded"]) < RTOL
     assert rel(sc, z["src_cnt"]) < RTOL and rel(cc, z["cha_cnt"]) < RTOL
@@ -137,7 +137,7 @@ def test_characterize_vs_oracle(B, chunk):
     with torch.no_grad():
         Yo, idxo = O.characterize(O.to_torch_state(sd), torch.from_numpy(src), torch.from_numpy(cha), mean, std)
     assert np.array_equal(idx.cpu().numpy(), idxo)
-    assert absmax(Y, Yo.numpy()) < TOL * max(1.0, float(Yo.abs().max()))
+    assert absmax(Y, Yo.numpy()) < TOL
 
 
 def test_batch_independence_and_determinism():
@@ -258,7 +258,7 @@ def test_streaming_graph_replay_matches_batched():
         for i in range(src.shape[0]):
             y, idx = sc.step(src[i])
             assert int(idx.item()) == int(io[i])
-            assert absmax(y, Yo[i].numpy()) < TOL * max(1.0, float(Yo.abs().max()))
+            assert absmax(y, Yo[i].numpy()) < TOL
 
 
 def test_fused_pose_normalisation():
@@ -360,6 +360,6 @@ def test_characterize_pair_matches_the_three_call_path():
     assert np.all(d_ours <= d_best * (1 + 1e-9))
     same = ours == io
     assert same.all()
-    assert absmax(Y2[torch.from_numpy(same).to(Y2.device)], Yo.numpy()[same]) < TOL * max(1.0, float(Yo.abs().max()))
+    assert absmax(Y2[torch.from_numpy(same).to(Y2.device)], Yo.numpy()[same]) < TOL
     with pytest.raises(RuntimeError, match="workspace limit"):
         model.characterize_pair(T(synthetic.pose_windows(7, 700)), T(synthetic.pose_windows(8, 700)), mean, std)

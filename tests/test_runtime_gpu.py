@@ -1,0 +1,169 @@
+"""Runtime behaviour of the context through the C ABI (run with -m gpu): introspection entry points, the generation
+counter that guards captured graphs, the captured per-window step, the RCCL communicator with one rank, bank-sharded
+matching with one rank, repeated weight loads, non-finite inputs, and bench.py's own N-rank launcher."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from mocha_sigasia2023_amd import ContextBank, Generator, StreamingCharacterizer, synthetic, weights
+from mocha_sigasia2023_amd.skeleton import skeleton_constants
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def model():
+    return Generator(device="cuda:0").load_state_dict(weights.synthetic_state_dict(11, 1.0)).eval()
+
+
+def _norm():
+    return synthetic.cnt_norm(3)
+
+
+@pytest.mark.parametrize("layout", ["mocha", "mixamo"])
+def test_graph_constants_and_pos_emb_entry_points(layout):
+    """mocha_graph_constants regenerates a14's buffers (net/graph.py) in C++; mocha_pos_emb exposes model.pos_emb (model.py:40)."""
+    sd = weights.synthetic_state_dict(3, 1.0, layout)
+    m = Generator(layout=layout, device="cuda:0").load_state_dict(sd).eval()
+    sk = skeleton_constants(layout)
+    V = sk.V
+    A_j = np.empty((3, V, V), np.float32); A_b = np.empty((2, 6, 6), np.float32)
+    pool = np.empty((V, 6), np.float32); unpool = np.empty((6, V), np.float32)
+    m._ctx.call("mocha_graph_constants", *[a.ctypes.data_as(C.c_void_p) for a in (A_j, A_b, pool, unpool)])
+    assert np.array_equal(A_j, sd["mot_embedding.2.A_j"]) and np.array_equal(A_b, sd["mot_embedding.5.A_b"])
+    assert np.array_equal(pool, sd["mot_embedding.3.weight"]) and np.array_equal(unpool, sd["to_mot.3.weight"])
+    p = C.c_void_p()
+    m._ctx.call("mocha_pos_emb", C.byref(p))
+    host = np.empty((90, 256), np.float32)
+    torch.cuda.synchronize()
+    hip = C.CDLL("libamdhip64.so.7")                                                          # already loaded by torch: same runtime
+    assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), p, host.nbytes, 2) == 0          # hipMemcpyDeviceToHost
+    assert np.array_equal(host, sd["pos_emb"][0])
+    assert torch.equal(m.pos_emb.cpu(), torch.from_numpy(sd["pos_emb"]))
+
+
+def test_generation_counts_buffer_replacements(model):
+    mean, std = _norm()
+    ctx = model._ctx
+    e, c, n = model.encode(torch.from_numpy(synthetic.pose_windows(1, 6)), mean, std)
+    g0 = ctx.generation()
+    model.encode(torch.from_numpy(synthetic.pose_windows(2, 6)), mean, std)                  # same size: nothing replaced
+    assert ctx.generation() == g0
+    bank = ContextBank(model, n, e)                                                          # new current bank
+    g1 = ctx.generation()
+    assert g1 > g0
+    bank.query(n)                                                                            # scratch was sized by bank_set
+    bank.characterize(torch.from_numpy(synthetic.pose_windows(3, 6)), mean, std)
+    assert ctx.generation() == g1
+    model.characterize_pair(torch.from_numpy(synthetic.pose_windows(3, 4)), torch.from_numpy(synthetic.pose_windows(4, 2)), mean, std)
+    assert ctx.generation() == g1                                                            # the transient bank does not count
+    model.encode(torch.from_numpy(synthetic.pose_windows(2, 40)), mean, std)                 # grows the workspaces
+    assert ctx.generation() > g1
+
+
+def test_streamer_does_not_shrink_the_workspace_and_follows_its_bank(model):
+    """the streamer must not lower the workspace limit, and must notice another bank / replaced buffers."""
+    mean, std = _norm()
+    cha = torch.from_numpy(synthetic.pose_windows(21, 30)).cuda()
+    src = torch.from_numpy(synthetic.pose_windows(22, 12)).cuda()
+    e, c, n = model.encode(cha, mean, std)
+    bank = ContextBank(model, n, e)
+    Yb, ib = bank.characterize(src, mean, std, return_index=True)
+    sc = StreamingCharacterizer(bank, mean, std)
+    y0, i0 = sc.step(src[0]); y0 = y0.clone(); i0 = int(i0.item())
+    assert i0 == int(ib[0])
+    # a large batch afterwards still runs as one chunk (the limit was not lowered to 1) ...
+    Y2 = model.characterize_pair(src, cha, mean, std)
+    assert float((Y2 - Yb).abs().max()) < 2e-5
+    # ... another bank becomes current, a bigger batch replaces the workspaces: the next step is still this bank's answer
+    other = ContextBank(model, n[:3].contiguous(), e[:3].contiguous())
+    other.query(n[:2].contiguous())
+    model.encode(torch.from_numpy(synthetic.pose_windows(23, 64)), mean, std)
+    for i in (0, 5, 11):
+        y, idx = sc.step(src[i])
+        assert int(idx.item()) == int(ib[i])
+        assert float((y - Yb[i]).abs().max()) < 2e-5
+    y, _ = sc.step(src[0])
+    assert torch.equal(y, y0)                                                                 # same kernels, same window: bit-identical
+
+
+def test_repeated_load_state_dict_reuses_device_memory():
+    sd = weights.synthetic_state_dict(5, 1.0)
+    m = Generator(device="cuda:0").load_state_dict(sd).eval()
+    X = torch.from_numpy(synthetic.pose_windows(9, 2)).cuda()
+    Y0 = m(X, X)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(5):
+        m.load_state_dict(sd)
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < (4 << 20)                                   # a weight set is ~60 MB with the folded copies
+    assert torch.equal(m(X, X), Y0)
+    sd2 = weights.synthetic_state_dict(6, 1.0)
+    assert not torch.equal(m.load_state_dict(sd2)(X, X), Y0)                                  # and a new set really replaces the old one
+
+
+def test_non_finite_queries_do_not_fault(model):
+    mean, std = _norm()
+    e, c, n = model.encode(torch.from_numpy(synthetic.pose_windows(31, 20)), mean, std)
+    bank = ContextBank(model, n, e)
+    q = n[:12].clone()
+    q[3] = float("nan"); q[7] = float("inf")
+    d, i = bank.query(q)                                                                      # many-query path (GEMM + arg-min)
+    i = i[:, 0].cpu().numpy()
+    assert ((i >= 0) & (i < 20)).all()
+    ok = [k for k in range(12) if k not in (3, 7)]
+    assert i[ok].tolist() == ok
+    assert not np.isfinite(d[3, 0].item()) and not np.isfinite(d[7, 0].item())
+    g = bank.gather(torch.tensor([-5, 3, 10 ** 6], dtype=torch.int32))                        # out-of-range indices are clamped
+    assert torch.equal(g[0], e[0]) and torch.equal(g[1], e[3]) and torch.equal(g[2], e[19])
+
+
+def test_rccl_bank_broadcast_one_rank(model):
+    """mocha_comm_* + mocha_bank_broadcast with a one-rank communicator: RCCL loads, the collective sequence runs, the
+    bank is unchanged.  (N > 1 ranks need N GPUs: the driver's scaling run exercises them through bench.py.)"""
+    from mocha_sigasia2023_amd import distributed as D
+    mean, std = _norm()
+    e, c, n = model.encode(torch.from_numpy(synthetic.pose_windows(41, 9)), mean, std)
+    bank = ContextBank(model, n, e)
+    ref = bank.query(n, return_distance=False)[:, 0].tolist()
+    os.environ.pop("RANK", None); os.environ.pop("WORLD_SIZE", None)
+    D.init_comm(model)
+    got = D.bank_broadcast(model, bank, 9, root=0)
+    torch.cuda.synchronize()
+    assert got is bank
+    assert bank.query(n, return_distance=False)[:, 0].tolist() == ref == list(range(9))
+
+
+def test_sharded_context_bank_one_rank(model):
+    from mocha_sigasia2023_amd.bank import ShardedContextBank
+    mean, std = _norm()
+    e, c, n = model.encode(torch.from_numpy(synthetic.pose_windows(51, 17)), mean, std)
+    sb = ShardedContextBank(model, n.reshape(17, -1), e, 17)
+    d, i = sb.query(n[:5].reshape(5, -1))
+    assert i.tolist() == [0, 1, 2, 3, 4]
+    assert torch.equal(sb.gather(i), e[:5])
+
+
+@pytest.mark.timeout(900)
+def test_bench_one_rank_over_rccl_and_launcher_refuses_missing_gpus():
+    """bench.py with the RCCL plumbing forced on (one rank): process group, clip broadcast, C-ABI bank broadcast, max-over-ranks
+    timing all run; `--gpus N` beyond the node's GPUs is refused by the launcher before any rank starts."""
+    env = dict(os.environ, MOCHA_FORCE_DIST="1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-extras", "--windows", "64"], env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["bank_broadcast_ms"] is not None and line["value"] > 0
+    assert len(line["per_rank_frames_per_s"]) == 1
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n + 1)], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "exposes" in (r.stderr + r.stdout)
