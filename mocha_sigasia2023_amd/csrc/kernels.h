@@ -130,10 +130,17 @@ hipError_t launch_column_stats(const float* x, int64_t N, int cols, float* mean,
 // bank row squared norms
 hipError_t launch_rownorm2(const float* x, const float* sub /*or null*/, float* out, int64_t rows, int cols, hipStream_t s);
 hipError_t launch_sub_rows(const float* x, const float* sub, float* out, int64_t rows, int cols, hipStream_t s);
-// per query: argmin_n (bnorm[n] - 2*sum_z S[z][q][n]); then exact distance to the winner
-hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm,
-                         const float* query, const float* bank, const void* bank16 /*bf16 bank or null*/, int Q, int64_t N, int D,
-                         int32_t* idx, float* dist, hipStream_t s);
+// many-query matcher (match_mfma.hip): centred bf16 queries, one-plane bf16 coarse scores S[z][q][n] (K split z), and the
+// select kernel: top-8 coarse scores ||b-c||^2 - 2 S per query, exact re-rank in the direct form.  margin_rel < 0:
+// re-evaluate all 8 (bf16 coarse pass); >= 0: only candidates within margin_rel * (2||q-c||^2 + ||b-c||^2 + ||b0-c||^2) of the best.
+// bank = raw fp32 rows (exact distance sum (q - b)^2) or bank16 = centred bf16 rows (sum ((q - c) - b16)^2).
+hipError_t match_mfma_init();
+int match_bf16_ksplit(int Q, int64_t N);
+hipError_t launch_center_bf16(const float* x, const float* centre, void* out, int64_t rows, int cols, hipStream_t s);
+hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s);
+hipError_t launch_match_select(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm, const float* query,
+                               const float* centre, const float* bank, const void* bank16, float margin_rel, int Q, int64_t N, int D,
+                               int32_t* idx, float* dist, hipStream_t s);
 // streaming matcher for few queries against a large bank (HBM-bound): bank fp32 or bf16;
 // partial = match_stream_scratch(Q, N) u64 words of scratch
 size_t match_stream_scratch(int Q, int64_t N);

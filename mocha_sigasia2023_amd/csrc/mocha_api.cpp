@@ -640,9 +640,15 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     const int set = c->cur;
     int rc;
     if ((rc = ensure_match_scratch(c, set, Q, N, false))) return rc;
-    const bool need_qc = c->bank_is_bf16 || Q > 8;       // the bf16 bank holds bf16(b - c); the GEMM works on centred operands
-    if (need_qc)
-        LAUNCH(c, s, "mocha_sub_rows", "match.center", 0.0, 8.0 * Q * D, launch_sub_rows(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
+    // centred queries: the bf16 bank holds bf16(b - c) and the GEMMs work on centred operands.  The many-query bf16 pass takes
+    // them as bf16 (match_qc holds Q x D bf16 then), everything else as fp32.
+    const bool need_qc = c->bank_is_bf16 || Q > 8;
+    if (need_qc) {
+        if (c->bank_is_bf16 && Q > 8)
+            LAUNCH(c, s, "mocha_center_bf16", "match.center", 0.0, 6.0 * Q * D, launch_center_bf16(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
+        else
+            LAUNCH(c, s, "mocha_sub_rows", "match.center", 0.0, 8.0 * Q * D, launch_sub_rows(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
+    }
     const float* qc = need_qc ? c->match_qc[set].p : nullptr;
     if (Q <= 8) {
         const void* bank = c->bank_is_bf16 ? (const void*)c->bank_bf16 : (const void*)c->bank_cnt;
@@ -652,22 +658,30 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
                launch_match_stream(bank, c->bank_is_bf16 ? 1 : 0, c->bank_is_bf16 ? qc : qnm, Q, N, D, c->best_ws[set], idx, dist, s));
         return 0;
     }
-    const int ksplit = match_ksplit(Q, N);
     DevBuf& mS = c->match_S[set];
+    if (c->bank_is_bf16) {
+        // bf16 bank: one bf16 plane of the centred queries against the centred bf16 bank; the select kernel re-evaluates every
+        // row whose coarse score is within the query rounding's error bound (2^-9 (2||q||^2 + ||b||^2 + ||b0||^2), plus slack for the
+        // fp32 accumulation: 0.002) of the best exactly - fp32 centred query against the bf16 rows - so the result is the exact
+        // search over the rounded bank
+        const int ksplit = match_bf16_ksplit(Q, N);
+        LAUNCH(c, s, "mocha_match_gemm_bf16", "match.qk_bf16", 2.0 * Q * (double)N * D, 2.0 * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
+               launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s));
+        LAUNCH(c, s, "mocha_match_select", "match.select", 0.0, 4.0 * ksplit * Q * N + Q * (8.0 * D + 8 * 2.0 * D),
+               launch_match_select(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, nullptr, c->bank_bf16, 0.002f,
+                                   Q, N, D, idx, dist, s));
+        return 0;
+    }
+    const int ksplit = match_ksplit(Q, N);
     GemmParams g = plain(qc, D, c->bank_cnt, mS.p, (int)N, Q, (int)N, D);
     g.ksplit = ksplit; g.slab_stride = (long long)Q * N;
-    if (c->bank_is_bf16) {
-        // bf16 bank: exact fp32 (centred) queries as three bf16 planes against the rounded centred bank on the bf16 matrix pipe
-        g.Wsplit = (const unsigned short*)c->bank_bf16;
-        LAUNCH(c, s, "mocha_gemm_split<128,2,2,2,2,3,1,2>", "match.qk_bf16", 2.0 * Q * (double)N * D,
-               4.0 * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit, launch_gemm_split(g, 31, s));
-    } else {
-        g.wsub = c->bank_center;
-        GEMM(c, s, "match.qk", g);
-    }
-    LAUNCH(c, s, "mocha_argmin", "match.argmin", 0.0, (double)ksplit * Q * N * 4 * 4,
-           launch_argmin(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, c->bank_is_bf16 ? qc : qnm, c->bank_cnt,
-                         c->bank_is_bf16 ? c->bank_bf16 : nullptr, Q, N, D, idx, dist, s));
+    g.wsub = c->bank_center;
+    GEMM(c, s, "match.qk", g);
+    // exact-f32 MFMA on centred operands: a coarse score is accurate to ~4e-7 (||q-c||^2 + ||b-c||^2); candidates within ten
+    // times that of the best are re-evaluated in the direct form
+    LAUNCH(c, s, "mocha_match_select", "match.select", 0.0, 4.0 * ksplit * Q * N + Q * 16.0 * D,
+           launch_match_select(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, c->bank_cnt, nullptr, 4e-6f,
+                               Q, N, D, idx, dist, s));
     return 0;
 }
 
@@ -704,6 +718,7 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = gemm_init();
     if (e == hipSuccess) e = gemm_split_init();
+    if (e == hipSuccess) e = match_mfma_init();
     if (e == hipSuccess) e = featurize_init();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);

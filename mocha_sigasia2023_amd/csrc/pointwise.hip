@@ -439,136 +439,19 @@ hipError_t launch_rownorm2(const float* x, const float* sub, float* out, int64_t
     return hipGetLastError();
 }
 
-// out[row] = x[row] - sub   (queries centred on the bank centroid)
+// out[row] = x[row] - sub   (queries centred on the bank centroid); flat grid, one thread per float4
 __global__ __launch_bounds__(256) void mocha_sub_rows(const float* __restrict__ x, const float* __restrict__ sub, float* __restrict__ out,
-                                                      int cols4) {
-    const size_t row = blockIdx.x;
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x) + row * cols4;
-    f32x4* o = reinterpret_cast<f32x4*>(out) + row * cols4;
-    for (int i = threadIdx.x; i < cols4; i += 256) o[i] = xr[i] - reinterpret_cast<const f32x4*>(sub)[i];
+                                                      int cols4, long long total4) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(x)[i] - reinterpret_cast<const f32x4*>(sub)[i % cols4];
 }
 
 hipError_t launch_sub_rows(const float* x, const float* sub, float* out, int64_t rows, int cols, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
     if (cols % 4) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_sub_rows, dim3((unsigned)rows), dim3(256), 0, s, x, sub, out, cols / 4);
-    return hipGetLastError();
-}
-
-// 1-NN from the score matrix S = (q - c)·(b - c)^T of the GEMM path (c = bank centroid, bnorm = ||b - c||^2):
-//   1. the RERANK smallest approximate scores ||b-c||^2 - 2 (q-c)·(b-c) in (value, index) order — fp32 GEMM sums over 23 040
-//      terms carry an error of ~1e-5 of the centred norms, which can exceed the gap between near-duplicate bank rows
-//      (consecutive windows of one clip);
-//   2. their exact squared distances in the direct (q-b)^2 form; the smallest wins, ties to the lowest index
-// (semantics of BallTree.query(k=1), test_fullframework.py:296,443).  qexact / bank (or bank16) are the operands of the
-// direct form: the original fp32 rows, or the centred queries and the centred bf16 bank.
-static constexpr int RERANK = 4;
-
-__global__ __launch_bounds__(256) void mocha_argmin(const float* __restrict__ S, int ksplit, long long slab_stride,
-                                                    int lds, const float* __restrict__ bnorm,
-                                                    const float* __restrict__ qexact, const float* __restrict__ bank,
-                                                    const unsigned short* __restrict__ bank16,
-                                                    long long N, int D, int32_t* __restrict__ idx,
-                                                    float* __restrict__ dist) {
-    __shared__ float rv[4];
-    __shared__ int ri[4];
-    __shared__ int cand[RERANK];
-    __shared__ float dsum[RERANK][4];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    // ---- 1. the RERANK smallest approximate scores, in (value, index) order
-    float prev_v = -INFINITY;
-    int prev_i = -1;
-    const int rounds = N < RERANK ? (int)N : RERANK;
-    for (int round = 0; round < RERANK; ++round) {
-        float best = INFINITY;
-        int bi = 0x7fffffff;
-        if (round < rounds) {
-            for (long long nn = tid; nn < N; nn += 256) {
-                float dot = 0.f;
-                for (int z = 0; z < ksplit; ++z) dot += S[(size_t)z * slab_stride + (size_t)q * lds + nn];
-                const float v = bnorm[nn] - 2.f * dot;
-                const bool after = v > prev_v || (v == prev_v && (int)nn > prev_i);
-                if (after && (v < best || (v == best && (int)nn < bi))) { best = v; bi = (int)nn; }
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(best, o);
-                const int oi = __shfl_xor(bi, o);
-                if (ov < best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-            }
-        }
-        if ((tid & 63) == 0) { rv[tid >> 6] = best; ri[tid >> 6] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            float b = rv[0]; int i = ri[0];
-            for (int w = 1; w < 4; ++w)
-                if (rv[w] < b || (rv[w] == b && ri[w] < i)) { b = rv[w]; i = ri[w]; }
-            cand[round] = i;                             // 0x7fffffff when there is no further candidate
-            rv[0] = b;
-        }
-        __syncthreads();
-        prev_v = rv[0]; prev_i = cand[round];
-        __syncthreads();
-    }
-    // ---- 2. exact squared distances of all candidates in one pass over the query row
-    int ci[RERANK];
-    // pad with the best (harmless duplicate); when no score was finite (NaN / inf queries or bank rows) there is no best
-    // either: fall back to row 0 so that no address below is out of range -- the distance then comes out NaN / inf
-    const int first = cand[0] == 0x7fffffff ? 0 : cand[0];
-#pragma unroll
-    for (int c = 0; c < RERANK; ++c) ci[c] = cand[c] == 0x7fffffff ? first : cand[c];
-    float a[RERANK];
-#pragma unroll
-    for (int c = 0; c < RERANK; ++c) a[c] = 0.f;
-    if (bank16) {
-        for (int i = tid; i < D; i += 256) {
-            const float qv = qexact[(size_t)q * D + i];
-#pragma unroll
-            for (int c = 0; c < RERANK; ++c) {
-                const float d = qv - __uint_as_float((unsigned)bank16[(size_t)ci[c] * D + i] << 16);
-                a[c] = fmaf(d, d, a[c]);
-            }
-        }
-    } else {
-        const f32x4* qr = reinterpret_cast<const f32x4*>(qexact + (size_t)q * D);
-        for (int i = tid; i < D / 4; i += 256) {
-            const f32x4 qv = qr[i];
-#pragma unroll
-            for (int c = 0; c < RERANK; ++c) {
-                const f32x4 d = qv - reinterpret_cast<const f32x4*>(bank + (size_t)ci[c] * D)[i];
-                a[c] = fmaf(d[0], d[0], a[c]); a[c] = fmaf(d[1], d[1], a[c]); a[c] = fmaf(d[2], d[2], a[c]); a[c] = fmaf(d[3], d[3], a[c]);
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < RERANK; ++c) {
-        a[c] = wave_sum(a[c]);
-        if ((tid & 63) == 0) dsum[c][tid >> 6] = a[c];
-    }
-    __syncthreads();
-    if (tid == 0) {
-        float best_d = INFINITY;
-        int best_i = 0x7fffffff;
-        for (int c = 0; c < RERANK; ++c) {
-            if (cand[c] == 0x7fffffff) continue;
-            const float d2 = (dsum[c][0] + dsum[c][1]) + (dsum[c][2] + dsum[c][3]);
-            if (d2 < best_d || (d2 == best_d && cand[c] < best_i)) { best_d = d2; best_i = cand[c]; }
-        }
-        if (best_i == 0x7fffffff) {                          // nothing comparable: a valid row index, distance of that row (NaN / inf)
-            best_i = 0;
-            best_d = (dsum[0][0] + dsum[0][1]) + (dsum[0][2] + dsum[0][3]);
-        }
-        idx[q] = best_i;
-        if (dist) dist[q] = sqrtf(best_d);
-    }
-}
-
-hipError_t launch_argmin(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm,
-                         const float* qexact, const float* bank, const void* bank16, int Q, int64_t N, int D, int32_t* idx,
-                         float* dist, hipStream_t s) {
-    if (Q <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mocha_argmin, dim3(Q), dim3(256), 0, s, S, ksplit, slab_stride, lds, bnorm, qexact, bank,
-                       (const unsigned short*)bank16, (long long)N, D, idx, dist);
+    const long long total4 = (long long)rows * (cols / 4);
+    hipLaunchKernelGGL(mocha_sub_rows, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, x, sub, out, cols / 4, total4);
     return hipGetLastError();
 }
 
