@@ -48,6 +48,19 @@ void split_weights_host(const float* w, size_t count, unsigned short* out /*3*co
 hipError_t gemm_init();           // one-time function attributes (dynamic LDS size)
 
 // ---------------------------------------------------------------------------------------
+// Fused transformer-layer tail (xf_tail.hip; net/transformer.py:91-94):
+//   x1 = ao[M,Kin] · Wo[256,Kin]^T + bo + resid[M,256];   out[M,256] = GELU(x1 · W1[512,256]^T + b1) · W2[256,512]^T + b2 + x1
+// ---------------------------------------------------------------------------------------
+struct XfTailParams {
+    const float* ao; int Kin;
+    const float* Wo; const float* bo; const float* resid;
+    const float* W1; const float* b1; const float* W2; const float* b2;
+    float* out; int M;
+};
+hipError_t xf_tail_init();
+hipError_t launch_xf_tail(const XfTailParams& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------
 // Multi-head attention, nq queries x nk keys (<= 192), one workgroup per (window, head)
 // (net/transformer.py:65-76; nn.MultiheadAttention in model_CVAE.py):
 //   out[b, i, h*DH + d] = softmax_j(q_i·k_j * scale) v_j ;  batch b starts at row b*nq (q, out) / b*nk (k, v)
