@@ -138,7 +138,11 @@ int mocha_step_graph(mocha_ctx* ctx, const float* X1, const float* cnt_mean, con
  *                          ncclAllGather, so that every xGMI link of the root carries a share instead of one ring
  *                          neighbour carrying all of it; centroid, row norms and the optional bf16 copy (flags &
  *                          MOCHA_BANK_BF16) are recomputed locally.  `comm` = an ncclComm_t created by the same librccl,
- *                          or NULL for the context's own.  Collective; enqueued on `stream`. */
+ *                          or NULL for the context's own.  Collective; enqueued on `stream`.
+ *   mocha_set_rccl_library: which librccl to resolve (before the first mocha_comm_* call; process-wide).  A process that
+ *                          already holds an RCCL - PyTorch wheels bundle their own copy - should name that file, so that one
+ *                          RCCL instance serves the process; NULL / never called: "librccl.so.1" from the loader path. */
+int mocha_set_rccl_library(const char* path);
 int mocha_comm_unique_id(mocha_ctx* ctx, void* id128);
 int mocha_comm_init(mocha_ctx* ctx, const void* id128, int nranks, int rank);
 int mocha_comm_destroy(mocha_ctx* ctx);

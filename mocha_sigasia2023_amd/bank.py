@@ -6,6 +6,10 @@
 * ``save_bank`` / ``load_bank`` — the reference's ``np.savez_compressed(encoded=, cnt=, range_starts=, range_stops=,
   action_label=)`` feature file (collect_CVAE_feature_action.py:185-189) and ``cnt_norm.npz`` (mean, std;
   compute_cnt_norm.py:178-179).
+* ``load_database`` / ``write_database`` — the reference's ``database.bin`` (etc/utils.py:144-190, written by
+  preprocess/generate_database_bin.py:228-246); ``collect_windows`` — the bank scripts' step-1 windowing over the
+  clips of one character (collect_CVAE_feature_action.py:104-133); ``build_bank_from_database`` chains them with the
+  device featurisation and ``build_bank``: database.bin -> windows -> X -> encoded / cnt -> the reference's ``.npz`` files.
 * ``ShardedContextBank`` — each rank scans its own block of bank rows and the per-query (distance, index) pairs are
   all-gathered (8 bytes per query and rank); every rank then holds the global winner.  Cuts the HBM-bound scan of a
   streamed query by the number of GPUs; the ``encoded`` features are replicated so the gather stays local.
@@ -36,8 +40,117 @@ def build_bank(model: Generator, X, batch: int = 1024, raw: bool = False):
     return {"encoded": encoded, "cnt": cntf, "cnt_mean": mean, "cnt_std": std}
 
 
+def load_database(filename: str) -> dict:
+    """The reference's motion database file (etc/utils.py:144-190): little-endian blocks, each with a uint32 header —
+    bone positions, velocities (nframes, nbones, 3) f32, rotations (nframes, nbones, 4) f32 (w, x, y, z), angular
+    velocities (nframes, nbones, 3) f32, bone parents (nbones) i32, range starts / stops (nranges) i32, style labels,
+    action ("content") labels (nranges) i32, contact states (nframes, ncontacts) int8.  The reference returns the action
+    labels under ``content_labels`` (:172-173) while its bank script reads ``action_labels``
+    (collect_CVAE_feature_action.py:81); both keys are provided."""
+    import struct
+    with open(filename, "rb") as f:
+        buf = f.read()
+    off = 0
+
+    def u32(n):
+        nonlocal off
+        v = struct.unpack_from("<" + "I" * n, buf, off)
+        off += 4 * n
+        return v
+
+    def arr(dtype, shape):
+        nonlocal off
+        count = int(np.prod(shape))
+        a = np.frombuffer(buf, dtype=dtype, count=count, offset=off).reshape(shape)
+        off += count * np.dtype(dtype).itemsize
+        return a
+
+    out = {}
+    for key, width in (("bone_positions", 3), ("bone_velocities", 3), ("bone_rotations", 4), ("bone_angular_velocities", 3)):
+        nframes, nbones = u32(2)
+        out[key] = arr("<f4", (nframes, nbones, width))
+    out["bone_parents"] = arr("<i4", (u32(1)[0],))
+    for key in ("range_starts", "range_stops", "style_labels", "content_labels"):
+        out[key] = arr("<i4", (u32(1)[0],))
+    out["action_labels"] = out["content_labels"]
+    nframes, ncontacts = u32(2)
+    out["contact_states"] = arr("i1", (nframes, ncontacts))
+    if off != len(buf):
+        raise ValueError(f"{filename}: {len(buf) - off} trailing bytes (not a database.bin of this layout)")
+    return out
+
+
+def write_database(filename: str, db: dict) -> None:
+    """Inverse of ``load_database``: the block sequence of preprocess/generate_database_bin.py:228-246."""
+    import struct
+    f32 = lambda k: np.ascontiguousarray(db[k], dtype="<f4")
+    i32 = lambda k: np.ascontiguousarray(db[k], dtype="<i4")
+    pos = f32("bone_positions")
+    nframes, nbones = pos.shape[:2]
+    labels = "action_labels" if "action_labels" in db else "content_labels"
+    contacts = np.ascontiguousarray(db["contact_states"]).astype(np.uint8)
+    with open(filename, "wb") as f:
+        for k in ("bone_positions", "bone_velocities", "bone_rotations", "bone_angular_velocities"):
+            f.write(struct.pack("<II", nframes, nbones) + f32(k).tobytes())
+        f.write(struct.pack("<I", nbones) + i32("bone_parents").tobytes())
+        for k in ("range_starts", "range_stops", "style_labels", labels):
+            f.write(struct.pack("<I", len(db["range_starts"])) + i32(k).tobytes())
+        f.write(struct.pack("<II", nframes, contacts.shape[1]) + contacts.tobytes())
+
+
+def collect_windows(db: dict, style_labels, action_labels, window: int = 60) -> dict:
+    """Step-1 windows of every clip whose style and action are wanted (collect_CVAE_feature_action.py:104-133): a clip
+    [start, stop) yields the windows [start + j - window, start + j) for j = window .. stop - start - 1, i.e.
+    stop - start - window of them (the last possible window is not taken, as in the reference's ``range(window,
+    total_frames)``).  Returns the windows' first frames (``starts``, global frame indices), the per-window action label
+    and the per-clip [range_starts, range_stops) over the window list (the reference's cha_range_starts / _stops)."""
+    styles, actions = set(int(s) for s in style_labels), set(int(a) for a in action_labels)
+    starts, labels, rs, re_ = [], [], [], []
+    for i in range(len(db["range_starts"])):
+        if int(db["style_labels"][i]) not in styles or int(db["action_labels"][i]) not in actions:
+            continue
+        start, stop = int(db["range_starts"][i]), int(db["range_stops"][i])
+        n = max(stop - start - window, 0)
+        starts.extend(start + j - window for j in range(window, stop - start))
+        labels.extend([int(db["action_labels"][i])] * n)
+        off = re_[-1] if re_ else 0
+        rs.append(off); re_.append(off + (stop - start - window))
+    return {"starts": np.asarray(starts, dtype=np.int64), "action_label": np.asarray(labels, dtype=np.int32),
+            "range_starts": np.asarray(rs, dtype=np.int32), "range_stops": np.asarray(re_, dtype=np.int32)}
+
+
+def build_bank_from_database(model: Generator, database, style_labels, action_labels, window: int = 60, batch: int = 1024) -> dict:
+    """database.bin (path or ``load_database`` dict) -> the character bank of collect_CVAE_feature_action.py:83-189 and
+    compute_cnt_norm.py:157-179: windows of the wanted clips, featurised (FK, re-rooting, z-score with the pose norm of
+    ``model.set_pose_norm``) and encoded on the device.  Returns ``build_bank``'s dict plus ``range_starts``,
+    ``range_stops``, ``action_label`` and ``starts``; ``save_bank`` writes the reference's ``.npz`` files from it."""
+    db = load_database(database) if isinstance(database, str) else database
+    w = collect_windows(db, style_labels, action_labels, window)
+    if not getattr(model, "_has_pose_norm", False):
+        raise RuntimeError("build_bank_from_database needs the pose norm: call model.set_pose_norm(X_mean, X_std, Y_mean, Y_std) first")
+    idx = w["starts"][:, None] + np.arange(window)[None]                       # (N, window) frame indices
+    enc, cnt = [], []
+    for s in range(0, len(idx), batch):
+        ii = idx[s:s + batch]
+        rot, pos, vel, ang = (torch.from_numpy(np.ascontiguousarray(db[k][ii], dtype=np.float32)) for k in
+                              ("bone_rotations", "bone_positions", "bone_velocities", "bone_angular_velocities"))
+        X_raw = model.featurize(rot, pos, vel, ang)
+        e, c = model.encode(X_raw, raw=True)
+        enc.append(e); cnt.append(c)
+    if not enc:
+        raise ValueError("no clip of the database matches the wanted style / action labels")
+    encoded, cntf = torch.cat(enc), torch.cat(cnt)
+    mean = torch.empty((NTOK, DIM), dtype=torch.float32, device=model.device)
+    std = torch.empty_like(mean)
+    model._ctx.call("mocha_column_stats", _ptr(cntf), C.c_int64(cntf.shape[0]), _ptr(mean), _ptr(std), _stream())
+    return {"encoded": encoded, "cnt": cntf, "cnt_mean": mean, "cnt_std": std, **w}
+
+
 def save_bank(path: str, bank: dict, range_starts=None, range_stops=None, action_label=None, norm_path: Optional[str] = None):
     n = bank["encoded"].shape[0]
+    range_starts = bank.get("range_starts") if range_starts is None else range_starts
+    range_stops = bank.get("range_stops") if range_stops is None else range_stops
+    action_label = bank.get("action_label") if action_label is None else action_label
     np.savez_compressed(path, encoded=bank["encoded"].cpu().numpy(), cnt=bank["cnt"].cpu().numpy(),
                         range_starts=np.asarray([0] if range_starts is None else range_starts),
                         range_stops=np.asarray([n] if range_stops is None else range_stops),

@@ -1230,10 +1230,16 @@ struct Rccl {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
+std::string g_rccl_path;          // mocha_set_rccl_library: a process that already holds an RCCL (PyTorch ships its own) should use that one
 
 int rccl_load(mocha_ctx* c) {
     if (g_rccl.h) return 0;
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    void* h = nullptr;
+    if (!g_rccl_path.empty()) {
+        h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(c, MOCHA_ERR_STATE, "cannot load RCCL from '%s': %s", g_rccl_path.c_str(), dlerror());
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) return fail(c, MOCHA_ERR_STATE, "cannot load RCCL (librccl.so.1): %s", dlerror());
     Rccl r; r.h = h;
@@ -1283,6 +1289,12 @@ int bcast_chunked(mocha_ctx* c, ncclComm_t comm, int world, int rank, int root, 
     return 0;
 }
 }  // namespace
+
+int mocha_set_rccl_library(const char* path) {
+    if (g_rccl.h) return MOCHA_ERR_STATE;              // already resolved: too late to switch
+    g_rccl_path = path ? path : "";
+    return 0;
+}
 
 int mocha_comm_unique_id(mocha_ctx* c, void* id128) {
     if (!c || !id128) return fail(c, MOCHA_ERR_ARG, "null argument");

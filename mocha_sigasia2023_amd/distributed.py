@@ -60,6 +60,10 @@ def init_comm(model) -> None:
     rank, _, world = env_rank()
     if getattr(model, "_comm_ready", False):
         return
+    # one RCCL per process: PyTorch bundles its own copy (the one torch.distributed's "nccl" backend drives); use it if present
+    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if os.path.exists(bundled):
+        model._ctx.lib.mocha_set_rccl_library(bundled.encode())        # status -3 = already resolved: keep what is loaded
     buf = (C.c_char * 128)()
     if rank == 0:
         model._ctx.call("mocha_comm_unique_id", C.cast(buf, C.c_void_p))

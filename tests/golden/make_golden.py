@@ -189,6 +189,74 @@ def run_featurize():
     print("featurize", X.shape, X.dtype, float(np.abs(X).max()))
 
 
+def run_database():
+    """Row N4's tail: a small synthetic ``database.bin`` in the byte layout preprocess/generate_database_bin.py:228-246 writes,
+    read back with THE REFERENCE's ``load_database`` (etc/utils.py:144-190); the step-1 windowing, FK / re-rooting and z-score
+    by EXECUTING lines 93-165 of the reference's collect_CVAE_feature_action.py (its ``main`` is not importable piecewise) in a
+    namespace prepared with that file's own variable names.  Stored: the file bytes, what the reference reader returns, the
+    reference's window ranges / labels / first frames, and its normalised features X for a few windows."""
+    import io
+    import struct
+    import textwrap
+    sys.path.insert(0, os.path.join(REF, "motion")); sys.path.insert(0, os.path.join(REF, "etc"))
+    import quat
+    from utils import load_database as ref_load_database
+    from mocha_sigasia2023_amd.skeleton import LAYOUTS
+    r = np.random.Generator(np.random.PCG64(2024))
+    lengths, styles, actions = [75, 64, 90, 61, 70], [2, 2, 5, 2, 2], [1, 3, 1, 4, 2]
+    nframes, nbones = sum(lengths), 25
+    rot = r.standard_normal((nframes, nbones, 4)).astype(np.float32)
+    rot /= np.sqrt((rot * rot).sum(-1, keepdims=True)); rot = np.where(rot[..., :1] > 0, rot, -rot).astype(np.float32)
+    db = {"bone_positions": (0.3 * r.standard_normal((nframes, nbones, 3))).astype(np.float32),
+          "bone_velocities": r.standard_normal((nframes, nbones, 3)).astype(np.float32), "bone_rotations": rot,
+          "bone_angular_velocities": r.standard_normal((nframes, nbones, 3)).astype(np.float32),
+          "bone_parents": np.concatenate([[-1], np.asarray(LAYOUTS["mocha"]["parents"]) + 1]).astype(np.int32),
+          "range_starts": np.cumsum([0] + lengths[:-1]).astype(np.int32), "range_stops": np.cumsum(lengths).astype(np.int32),
+          "style_labels": np.asarray(styles, np.int32), "action_labels": np.asarray(actions, np.int32),
+          "contact_states": (r.uniform(size=(nframes, 2)) > 0.5).astype(np.uint8)}
+    buf = io.BytesIO()                                    # preprocess/generate_database_bin.py:235-246, same order and headers
+    for k in ("bone_positions", "bone_velocities", "bone_rotations", "bone_angular_velocities"):
+        buf.write(struct.pack("II", nframes, nbones) + db[k].ravel().tobytes())
+    buf.write(struct.pack("I", nbones) + db["bone_parents"].ravel().tobytes())
+    for k in ("range_starts", "range_stops", "style_labels", "action_labels"):
+        buf.write(struct.pack("I", len(lengths)) + db[k].ravel().tobytes())
+    buf.write(struct.pack("II", nframes, 2) + db["contact_states"].ravel().tobytes())
+    raw = buf.getvalue()
+    tmp = os.path.join("/tmp", "mocha_golden_database.bin")
+    open(tmp, "wb").write(raw)
+    database = ref_load_database(tmp)                     # the reference reader
+    out = {"bin": np.frombuffer(raw, dtype=np.uint8)}
+    import hashlib
+    for k, v in database.items():                         # what the reference reader returned: small arrays verbatim, the frame arrays
+        v = np.asarray(v)                                 # (already in `bin`) as shape + dtype + SHA-256 of their bytes
+        if v.size <= 64:
+            out["db_" + k] = v
+        else:
+            out["dbsha_" + k] = np.array([str(v.shape), str(v.dtype), hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest()])
+    # ---- the reference's windowing + featurisation, executed from its own source text
+    src = open(os.path.join(REF, "collect_CVAE_feature_action.py")).read().splitlines()
+    code = textwrap.dedent("\n".join(src[92:165]))        # lines 93-165
+    Xm = r.standard_normal((1, 1, 25, 15)).astype(np.float32); Xs = r.uniform(0.5, 2.0, (1, 1, 25, 15)).astype(np.float32)
+    ns = {"np": np, "quat": quat, "parents": database["bone_parents"], "contacts": database["contact_states"],
+          "range_starts": database["range_starts"], "range_stops": database["range_stops"], "style_labels": database["style_labels"],
+          "action_labels": database["content_labels"],    # the reader's name for them (etc/utils.py:172-173)
+          "Ypos": database["bone_positions"].astype(np.float32), "Yrot": database["bone_rotations"].astype(np.float32),
+          "Yvel": database["bone_velocities"].astype(np.float32), "Yang": database["bone_angular_velocities"].astype(np.float32),
+          "target_style_label": [2], "target_action_label": [1, 3, 4], "style_names": ["s%d" % i for i in range(8)],
+          "action_names": ["a%d" % i for i in range(8)], "X_mean": Xm, "X_std": Xs, "print": lambda *a, **k: None}
+    exec(compile(code, "collect_CVAE_feature_action.py[93:165]", "exec"), ns)
+    N = len(ns["action_label"])
+    # first frame of every window: located by matching the reference's slices in the frame arrays
+    pos = database["bone_positions"]
+    starts = np.array([next(g for g in range(nframes - 59) if np.array_equal(pos[g:g + 60], ns["Ypos"][k])) for k in range(N)], np.int64)
+    sel = np.array([0, 7, N // 2, N - 1])
+    out.update(range_starts=ns["cha_range_starts"], range_stops=ns["cha_range_stops"], action_label=ns["action_label"], starts=starts,
+               X_sel=ns["X"][sel].astype(np.float32), sel=sel, X_mean=Xm, X_std=Xs, style_keep=np.array([2]), action_keep=np.array([1, 3, 4]))
+    np.savez_compressed(os.path.join(HERE, "database_bank.npz"), **out)
+    os.remove(tmp)
+    print("database", {k: getattr(v, "shape", v) for k, v in out.items() if not k.startswith("db_")})
+
+
 def run_postprocess():
     """The demo's per-frame post-processing (test_fullframework.py:303-437 for the first frame, :457-632 after it)
     driven through the reference's own motion/quat.py and motion/Inertialization.py on synthetic decoded windows."""
@@ -286,5 +354,6 @@ if __name__ == "__main__":
     run_match()
     run_cvae()
     run_featurize()
+    run_database()
     run_postprocess()
     run_bvh()
