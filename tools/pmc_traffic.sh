@@ -8,7 +8,7 @@ cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/pmc_traffic_$tag; rm -rf $out; mkdir -p $out
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/$ctr.stdout 2> $out/$ctr.stderr
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/$ctr.stdout 2> $out/$ctr.stderr
 done
 python3 - $out <<'PY'
 import csv, sys, glob, collections
