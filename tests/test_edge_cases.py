@@ -145,3 +145,57 @@ def test_contexts_release_their_device_memory():
         cycle()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, f"device memory shrank by {(free0 - free1) >> 20} MiB over 5 context life cycles"
+
+
+def _torch_bruteforce(q, bank):
+    """float64 1-NN on the device, ties to the lowest index (reference semantics of the matcher)."""
+    q64 = q.double()
+    best_d = torch.full((q.shape[0],), float("inf"), dtype=torch.float64, device=q.device)
+    best_i = torch.zeros((q.shape[0],), dtype=torch.int64, device=q.device)
+    for s in range(0, bank.shape[0], 2048):
+        d = torch.cdist(q64, bank[s:s + 2048].double()) ** 2
+        dm, im = d.min(dim=1)
+        upd = dm < best_d
+        best_d = torch.where(upd, dm, best_d); best_i = torch.where(upd, im + s, best_i)
+    return best_i, best_d.sqrt()
+
+
+def test_many_query_matcher_with_more_candidates_than_its_list_holds(model):
+    """Every row of the bank ties with every other one (300 copies of one entry, and a second group 1e-3 further away): all of
+    them are inside the coarse pass's error bound, more than the select kernel's 128-entry list holds, so it walks the index
+    windows; ties must go to the lowest index, exactly like the few-query scan and the float64 search."""
+    from mocha_sigasia2023_amd import ContextBank
+    r = np.random.Generator(np.random.PCG64(3))
+    base = r.standard_normal((1, 90 * 256)).astype(np.float32)
+    bank = np.repeat(base, 300, axis=0)
+    bank[150:] += 1e-3                                              # second group: farther from the queries below
+    q = (base + 1e-4 * r.standard_normal((11, 90 * 256))).astype(np.float32)
+    tb, tq = torch.from_numpy(bank).cuda(), torch.from_numpy(q).cuda()
+    for bf16 in (False, True):
+        b = ContextBank(model, tb, tb.view(300, 90, 256), bf16=bf16)
+        d, i = b.query(tq)                                          # 11 queries: coarse pass + select
+        assert i[:, 0].cpu().tolist() == [0] * 11
+        d8, i8 = b.query(tq[:3])                                    # 3 queries: the streaming scan agrees
+        assert i8[:, 0].cpu().tolist() == [0] * 3
+        assert torch.allclose(d[:3, 0], d8[:, 0], rtol=1e-5)
+
+
+@pytest.mark.timeout(900)
+def test_many_query_matcher_beyond_the_register_resident_score_chunks(model):
+    """A bank of more than 16 384 rows (the select kernel keeps four 4 096-row score chunks in registers and recomputes the
+    rest), ragged row count, both bank precisions, against a float64 search on the device."""
+    from mocha_sigasia2023_amd import ContextBank
+    N = 16384 + 517
+    g = torch.Generator(device="cuda"); g.manual_seed(99)
+    bank = torch.randn((N, 90 * 256), device="cuda", generator=g)
+    q = torch.randn((12, 90 * 256), device="cuda", generator=g)
+    q[0] = bank[N - 1] + 0.01 * q[0]; q[1] = bank[16384 + 3] + 0.01 * q[1]; q[2] = bank[5] + 0.01 * q[2]
+    ri, rd = _torch_bruteforce(q, bank)
+    d, i = ContextBank(model, bank, bank.view(N, 90, 256)).query(q)
+    assert torch.equal(i[:, 0].long(), ri) and i[0, 0].item() == N - 1 and i[1, 0].item() == 16387
+    assert torch.allclose(d[:, 0].double(), rd, rtol=1e-5)
+    c = bank.double().mean(0).float()
+    b16 = (bank - c).to(torch.bfloat16).float()                      # what the bf16 bank holds: bf16(b - centroid)
+    ri16, _ = _torch_bruteforce(q - c, b16)
+    i16 = ContextBank(model, bank, bank.view(N, 90, 256), bf16=True).query(q, return_distance=False)
+    assert torch.equal(i16[:, 0].long(), ri16)

@@ -162,7 +162,7 @@ def test_bench_one_rank_over_rccl_and_launcher_refuses_missing_gpus():
                         "--no-extras", "--windows", "64"], env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])      # RCCL prints its banner to stdout
-    assert line["n_gpus"] == 1 and line["bank_broadcast_ms"] is not None and line["value"] > 0
+    assert line["n_gpus"] == 1 and line["bank_broadcast_ms"] is not None and line["bank_broadcast_error"] is None and line["value"] > 0
     assert len(line["per_rank_frames_per_s"]) == 1
     n = torch.cuda.device_count()
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n + 1)], capture_output=True, text=True, timeout=300)
