@@ -31,7 +31,7 @@ static constexpr int SBK = 32;                  // fp32 elements of K per slab =
 static constexpr int SROW = 40;                 // bf16 per LDS row (32 + 8 pad) = 80 bytes
 
 __device__ __forceinline__ float lrelu02s(float x) { return x > 0.f ? x : 0.2f * x; }
-__device__ __forceinline__ float gelu_erfs(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erfs(float x) { return 0.5f * x * (1.0f + mocha_erf(x * 0.70710678118654752440f)); }
 
 // round-to-nearest-even bf16 of a finite float, as the high half-word
 __device__ __forceinline__ unsigned bf16_rn(float x) {

@@ -30,33 +30,10 @@ namespace mocha {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// erf to < 1 ulp (5.8e-8 absolute), branch-free: both ranges are evaluated and selected, so that the GELU of one hidden chunk
-// is straight-line VALU code the scheduler can place between the MFMAs of the next chunk (the library erff branches per
-// lane).  Coefficients: N. Juffa's single-precision erff (two minimax polynomials, split at 0.9277); checked against a float64
-// erf over [-6, 6] (tests/test_xf_tail_erf.py).
-__device__ __forceinline__ float xt_erf(float a) {
-    const float t = fabsf(a), s = a * a;
-    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
-    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
-    r = fmaf(r, s, u);
-    r = fmaf(r, t, -1.06777877e-1f);
-    r = fmaf(r, t, -6.34846687e-1f);
-    r = fmaf(r, t, -1.28717512e-1f);
-    r = fmaf(r, t, -t);
-    const float big = copysignf(1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896340736f), a);
-    float q = -5.96761703e-4f;
-    q = fmaf(q, s, 4.99119423e-3f);
-    q = fmaf(q, s, -2.67681349e-2f);
-    q = fmaf(q, s, 1.12819925e-1f);
-    q = fmaf(q, s, -3.76125336e-1f);
-    q = fmaf(q, s, 1.28379166e-1f);
-    const float small = fmaf(q, a, a);
-    return t > 0.927734375f ? big : small;
-}
 #ifdef XT_EXP_NOGELU
 __device__ __forceinline__ float xt_gelu(float x) { return x; }
 #else
-__device__ __forceinline__ float xt_gelu(float x) { return 0.5f * x * (1.0f + xt_erf(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float xt_gelu(float x) { return 0.5f * x * (1.0f + mocha_erf(x * 0.70710678118654752440f)); }
 #endif
 
 // Scheduling directive for one slab's compute block: 16 groups of 8 MFMAs; the two weight fragments of group g + 1 are read
