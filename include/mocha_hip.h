@@ -109,6 +109,15 @@ int mocha_bank_set(mocha_ctx* ctx, const float* cnt_nm, const float* encoded, in
  * query row (Q, 90*256) in the bank.  idx (Q,) int32; dist (Q,) fp32 Euclidean distance to the
  * winner (may be NULL). */
 int mocha_match(mocha_ctx* ctx, const float* query_nm, int Q, int32_t* idx, float* dist, void* stream);
+/* tree.query(q, k) for k > 1 (scikit-learn BallTree semantics; the reference only ever asks for k = 1, SURVEY.md §8f N4 lists
+ * k > 1 as optional): the k nearest rows of every query, exact, distances ascending, ties to the lower row index.
+ * idx (Q,k) int32 (-1 where the bank has fewer than k rows), dist (Q,k) fp32 or NULL.  One bank scan per 8 queries - a
+ * convenience, not a fast path; allocates its scratch on first use.
+ * mocha_bank_gather_blend: soft matching over those neighbours, out (Q,90,256) = sum_j softmax_j(-dist[q][j] / temperature) *
+ * bank.encoded[idx[q][j]] (entries with idx < 0 left out; k <= 64, temperature > 0). */
+int mocha_match_topk(mocha_ctx* ctx, const float* query_nm, int Q, int k, int32_t* idx, float* dist, void* stream);
+int mocha_bank_gather_blend(mocha_ctx* ctx, const int32_t* idx, const float* dist, float temperature, int Q, int k, float* out,
+                            void* stream);
 /* cha_encoded[frame_index], test_fullframework.py:298,465: out (Q,90,256) = bank.encoded[idx[q]]. */
 int mocha_bank_gather(mocha_ctx* ctx, const int32_t* idx, int Q, float* out, void* stream);
 

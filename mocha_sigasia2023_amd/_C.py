@@ -44,6 +44,8 @@ SIGNATURES = {
     "mocha_bank_set": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "mocha_match": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "mocha_bank_gather": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mocha_match_topk": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "mocha_bank_gather_blend": (_i, [_vp, _vp, _vp, C.c_float, _i, _i, _vp, _vp]),
     "mocha_characterize": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mocha_set_pose_norm": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mocha_encode_raw": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -159,6 +159,12 @@ hipError_t launch_match_select(const float* S, int ksplit, long long slab_stride
 size_t match_stream_scratch(int Q, int64_t N);
 hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* query, int Q, int64_t N, int D,
                                unsigned long long* partial, int32_t* idx, float* dist, hipStream_t s);
+// k nearest rows per query, exact (every row's direct-form distance, then a k-pass selection); keys = 8 * N u64 words of scratch
+hipError_t launch_match_topk(const void* bank, int bank_bf16, const float* query, int Q, int64_t N, int D, int k,
+                             unsigned long long* keys, int32_t* idx, float* dist, hipStream_t s);
+// out[q] = sum_j softmax_j(-dist[q][j] / temperature) * src[idx[q][j]] over the k neighbours of query q
+hipError_t launch_gather_blend(const float* src, const int32_t* idx, const float* dist, float temperature, float* out, int Q, int k,
+                               int cols, int64_t nrows, hipStream_t s);
 hipError_t launch_to_bf16(const float* x, const float* sub /*per-column, or null*/, int cols, void* y, int64_t n, hipStream_t s);
 hipError_t launch_rownorm2_bf16(const void* x, float* out, int64_t rows, int cols, hipStream_t s);
 // out[q] = src[idx[q]] rows of `cols` floats

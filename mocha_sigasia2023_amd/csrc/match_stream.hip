@@ -32,10 +32,12 @@ __device__ __forceinline__ unsigned long long pack_key(float v, unsigned row) {
     return ((unsigned long long)u << 32) | row;
 }
 
+// all_keys != 0 (top-k queries): every row's key goes to partial[q][row] instead of one minimum per workgroup
 template <int Q, bool BF16>
 __global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict__ bank,
                                                           const float* __restrict__ query, int nq, long long N, int D,
-                                                          unsigned long long* __restrict__ partial /*[Q8][gridDim.x]*/) {
+                                                          unsigned long long* __restrict__ partial /*[Q8][gridDim.x] or [Q8][N]*/,
+                                                          int all_keys) {
     constexpr int MS_CHUNK = BF16 ? MS_CHUNK_BF16 : MS_CHUNK_F32;
     __shared__ __attribute__((aligned(16))) float qs[Q * MS_CHUNK];
     __shared__ unsigned long long wbest[MS_WAVES][Q];
@@ -139,11 +141,13 @@ __global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict
             if (row < N) {
                 const unsigned long long k = pack_key(v, (unsigned)row);      // v = squared distance
                 kmin = k < kmin ? k : kmin;
+                if (all_keys && lane == 0 && q < nq) partial[(size_t)q * N + row] = k;
             }
         }
         if (lane == 0) wbest[wave][q] = kmin;
     }
     __syncthreads();
+    if (all_keys) return;
     if (tid < Q) {
         unsigned long long k = wbest[0][tid];
 #pragma unroll
@@ -205,8 +209,8 @@ hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* que
         unsigned long long* pp = partial + (size_t)q0 * grid;      // partial[q][wg], q global
 #define MS_LAUNCH(QQ)                                                                                          \
         do {                                                                                                   \
-            if (bank_bf16) hipLaunchKernelGGL((mocha_match_stream<QQ, true>), dim3(grid), dim3(256), 0, s, bank, qp, nq, (long long)N, D, pp); \
-            else hipLaunchKernelGGL((mocha_match_stream<QQ, false>), dim3(grid), dim3(256), 0, s, bank, qp, nq, (long long)N, D, pp);          \
+            if (bank_bf16) hipLaunchKernelGGL((mocha_match_stream<QQ, true>), dim3(grid), dim3(256), 0, s, bank, qp, nq, (long long)N, D, pp, 0); \
+            else hipLaunchKernelGGL((mocha_match_stream<QQ, false>), dim3(grid), dim3(256), 0, s, bank, qp, nq, (long long)N, D, pp, 0);          \
         } while (0)
         if (nq == 1) MS_LAUNCH(1);
         else if (nq == 2) MS_LAUNCH(2);
@@ -216,6 +220,61 @@ hipError_t launch_match_stream(const void* bank, int bank_bf16, const float* que
     }
     if (bank_bf16) hipLaunchKernelGGL((mocha_match_finish<true>), dim3(Q), dim3(256), 0, s, partial, (int)grid, bank, query, D, idx, dist);
     else hipLaunchKernelGGL((mocha_match_finish<false>), dim3(Q), dim3(256), 0, s, partial, (int)grid, bank, query, D, idx, dist);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k nearest rows (the tree.query(k > 1) of scikit-learn's BallTree; the reference itself only uses k = 1): the scan above
+// writes the exact squared distance of EVERY row as a (value, row) key; one workgroup per query then takes the k smallest
+// keys in k passes - keys are unique, so pass r selects the smallest key greater than pass r - 1's, no marking needed.
+// Distances ascending, ties to the lowest row.  One bank scan per 8 queries: a convenience, not a fast path.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_match_topk_finish(const unsigned long long* __restrict__ keys /*[Q][N]*/, long long N, int k,
+                                                               int32_t* __restrict__ idx /*[Q][k]*/, float* __restrict__ dist /*[Q][k] or null*/) {
+    __shared__ unsigned long long kred[256];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long* kq = keys + (size_t)q * N;
+    unsigned long long prev = 0;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = ~0ull;
+        for (long long i = tid; i < N; i += 256) {
+            const unsigned long long v = kq[i];
+            if ((r == 0 || v > prev) && v < best) best = v;
+        }
+        kred[tid] = best;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) kred[tid] = kred[tid + o] < kred[tid] ? kred[tid + o] : kred[tid];
+            __syncthreads();
+        }
+        prev = kred[0];
+        __syncthreads();
+        if (tid == 0) {
+            if (prev == ~0ull) { idx[(size_t)q * k + r] = -1; if (dist) dist[(size_t)q * k + r] = INFINITY; }      // fewer than k rows
+            else {
+                idx[(size_t)q * k + r] = (int32_t)(prev & 0xffffffffull);
+                unsigned u = (unsigned)(prev >> 32);
+                u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+                if (dist) dist[(size_t)q * k + r] = sqrtf(__uint_as_float(u));
+            }
+        }
+    }
+}
+
+hipError_t launch_match_topk(const void* bank, int bank_bf16, const float* query, int Q, int64_t N, int D, int k,
+                             unsigned long long* keys /*8 * N words*/, int32_t* idx, float* dist, hipStream_t s) {
+    if (Q <= 0) return hipSuccess;
+    if (k < 1 || D % (bank_bf16 ? MS_CHUNK_BF16 : MS_CHUNK_F32) != 0) return hipErrorInvalidValue;
+    const int rows_per_wg = MS_WAVES * MS_ROWS_PER_WAVE;
+    const unsigned grid = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
+    for (int q0 = 0; q0 < Q; q0 += 8) {                 // one bank pass per 8 queries; the key buffer is reused (same stream)
+        const int nq = (Q - q0) < 8 ? (Q - q0) : 8;
+        const float* qp = query + (size_t)q0 * D;
+        if (bank_bf16) hipLaunchKernelGGL((mocha_match_stream<8, true>), dim3(grid), dim3(256), 0, s, bank, qp, nq, (long long)N, D, keys, 1);
+        else hipLaunchKernelGGL((mocha_match_stream<8, false>), dim3(grid), dim3(256), 0, s, bank, qp, nq, (long long)N, D, keys, 1);
+        hipLaunchKernelGGL(mocha_match_topk_finish, dim3(nq), dim3(256), 0, s, keys, (long long)N, k, idx + (size_t)q0 * k,
+                           dist ? dist + (size_t)q0 * k : nullptr);
+    }
     return hipGetLastError();
 }
 

@@ -153,6 +153,7 @@ struct mocha_ctx {
     float* pose_norm = nullptr;        // [x_mean | x_std | y_mean | y_std], (V+1)*C_in each (norm.npz of the reference)
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
     unsigned long long* best_ws[2] = {nullptr, nullptr}; size_t best_ws_n[2] = {0, 0};
+    unsigned long long* topk_keys = nullptr; size_t topk_keys_n = 0;       // every row's key of up to 8 queries (mocha_match_topk)
 
     // captured per-window step (mocha_step_graph): one executable graph, re-captured when its key changes
     struct StepGraph {
@@ -752,6 +753,7 @@ void mocha_destroy(mocha_ctx* c) {
     for (float* p : c->owned) (void)hipFree(p);
     for (int set = 0; set < 2; ++set) { if (c->idx_ws[set]) (void)hipFree(c->idx_ws[set]); if (c->best_ws[set]) (void)hipFree(c->best_ws[set]); }
     if (c->bank_bf16) (void)hipFree(c->bank_bf16);
+    if (c->topk_keys) (void)hipFree(c->topk_keys);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -1073,6 +1075,47 @@ int mocha_match(mocha_ctx* c, const float* query_nm, int Q, int32_t* idx, float*
     if (!query_nm || !idx || Q < 0) return fail(c, MOCHA_ERR_ARG, "bad match arguments");
     if (Q == 0) return 0;
     return do_match(c, query_nm, Q, idx, dist, (hipStream_t)stream);
+}
+
+int mocha_match_topk(mocha_ctx* c, const float* query_nm, int Q, int k, int32_t* idx, float* dist, void* stream) {
+    int rc = ready(c, 0); if (rc) return rc;
+    if (Q == 0) return 0;
+    if (!query_nm || !idx || Q < 0 || k < 1 || k > 64) return fail(c, MOCHA_ERR_ARG, "bad top-k arguments (1 <= k <= 64)");
+    if (!c->bank_cnt || c->bank_N <= 0) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
+    hipStream_t s = (hipStream_t)stream;
+    const int D = 90 * 256;
+    const int64_t N = c->bank_N;
+    const size_t need = (size_t)8 * N;
+    if (c->topk_keys_n < need) {                            // not on the per-frame path: allocated on first use
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->topk_keys) (void)hipFree(c->topk_keys);
+        c->topk_keys = nullptr; c->topk_keys_n = 0;
+        void* kp = nullptr;
+        HIPCHK(c, hipMalloc(&kp, need * sizeof(unsigned long long)));
+        c->topk_keys = (unsigned long long*)kp; c->topk_keys_n = need;
+        c->generation++;
+    }
+    const float* q = query_nm;
+    if (c->bank_is_bf16) {                                  // the bf16 bank holds bf16(b - centroid): centred queries
+        if ((rc = grow(c, c->match_qc[0], (size_t)std::max(Q, 8) * D))) return rc;
+        LAUNCH(c, s, "mocha_sub_rows", "match.center", 0.0, 8.0 * Q * D, launch_sub_rows(query_nm, c->bank_center, c->match_qc[0].p, Q, D, s));
+        q = c->match_qc[0].p;
+    }
+    const void* bank = c->bank_is_bf16 ? (const void*)c->bank_bf16 : (const void*)c->bank_cnt;
+    LAUNCH(c, s, "mocha_match_topk", "match.topk", 3.0 * Q * N * D, ((Q + 7) / 8) * (double)N * D * (c->bank_is_bf16 ? 2.0 : 4.0),
+           launch_match_topk(bank, c->bank_is_bf16 ? 1 : 0, q, Q, N, D, k, c->topk_keys, idx, dist, s));
+    return 0;
+}
+
+int mocha_bank_gather_blend(mocha_ctx* c, const int32_t* idx, const float* dist, float temperature, int Q, int k, float* out, void* stream) {
+    int rc = ready(c, 0); if (rc) return rc;
+    if (!c->bank_enc) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
+    if (Q == 0) return 0;
+    if (!idx || !dist || !out || Q < 0 || k < 1 || k > 64 || !(temperature > 0.f)) return fail(c, MOCHA_ERR_ARG, "bad gather_blend arguments");
+    hipStream_t s = (hipStream_t)stream;
+    LAUNCH(c, s, "mocha_gather_blend", "bank.gather_blend", 2.0 * Q * k * 90 * 256, Q * (k + 1.0) * 90 * 256 * 4,
+           launch_gather_blend(c->bank_enc, idx, dist, temperature, out, Q, k, 90 * 256, c->bank_N, s));
+    return 0;
 }
 
 int mocha_bank_gather(mocha_ctx* c, const int32_t* idx, int Q, float* out, void* stream) {

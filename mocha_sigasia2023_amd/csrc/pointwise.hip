@@ -465,6 +465,43 @@ __global__ __launch_bounds__(256) void mocha_gather_rows(const float* __restrict
     for (int i = threadIdx.x; i < cols4; i += 256) o[i] = s[i];
 }
 
+// Soft context matching over the k neighbours of a top-k query: out[q] = sum_j softmax_j(-dist[q][j] / temperature) src[idx[q][j]]
+// (neighbours with idx < 0 - a bank with fewer than k rows - are left out).  k <= 64.
+__global__ __launch_bounds__(256) void mocha_gather_blend(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          const float* __restrict__ dist, float inv_temp, float* __restrict__ out, int k,
+                                                          int cols4, long long nrows) {
+    __shared__ float w[64];
+    __shared__ long long rows[64];
+    const size_t q = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float mx = -INFINITY;
+        for (int j = 0; j < k; ++j) {
+            const long long r = idx[q * k + j];
+            rows[j] = (r >= 0 && r < nrows) ? r : -1;
+            if (rows[j] >= 0) mx = fmaxf(mx, -dist[q * k + j] * inv_temp);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < k; ++j) { w[j] = rows[j] >= 0 ? __expf(-dist[q * k + j] * inv_temp - mx) : 0.f; sum += w[j]; }
+        for (int j = 0; j < k; ++j) w[j] = sum > 0.f ? w[j] / sum : 0.f;
+    }
+    __syncthreads();
+    f32x4* o = reinterpret_cast<f32x4*>(out) + q * cols4;
+    for (int i = threadIdx.x; i < cols4; i += 256) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < k; ++j)
+            if (rows[j] >= 0) acc += w[j] * (reinterpret_cast<const f32x4*>(src) + (size_t)rows[j] * cols4)[i];
+        o[i] = acc;
+    }
+}
+
+hipError_t launch_gather_blend(const float* src, const int32_t* idx, const float* dist, float temperature, float* out, int Q, int k,
+                               int cols, int64_t nrows, hipStream_t s) {
+    if (Q <= 0) return hipSuccess;
+    if (cols % 4 || nrows < 1 || k < 1 || k > 64 || !(temperature > 0.f)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_gather_blend, dim3(Q), dim3(256), 0, s, src, idx, dist, 1.0f / temperature, out, k, cols / 4, (long long)nrows);
+    return hipGetLastError();
+}
+
 hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, int Q, int cols, int64_t nrows, hipStream_t s) {
     if (Q <= 0) return hipSuccess;
     if (cols % 4 || nrows < 1) return hipErrorInvalidValue;

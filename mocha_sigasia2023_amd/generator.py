@@ -392,18 +392,37 @@ class ContextBank:
         return self
 
     def query(self, query_nm, k: int = 1, return_distance: bool = True):
-        if k != 1:
-            raise ValueError("only k=1 is on the path (test_fullframework.py:296,443)")
+        """``BallTree.query``: (dist (Q,k), idx (Q,k)), distances ascending.  k = 1 is the path (test_fullframework.py:296,443)
+        and takes the fast matchers; k > 1 is an exact k-pass selection over every row's distance (``mocha_match_topk``)."""
         if getattr(self.model, "_bank", None) is not self:
             self.activate()
         q = _dev_f32(query_nm, self.model.device, None, "query").reshape(-1, NTOK * DIM)
         Q = q.shape[0]
+        if k != 1:
+            if not 1 < k <= 64:
+                raise ValueError("k must be in 1 .. 64")
+            idx = torch.empty((Q, k), dtype=torch.int32, device=q.device)
+            dist = torch.empty((Q, k), dtype=torch.float32, device=q.device) if return_distance else None
+            self.model._ctx.call("mocha_match_topk", _ptr(q), Q, int(k), _ptr(idx), _ptr(dist), _stream())
+            return (dist, idx) if return_distance else idx
         idx = torch.empty((Q,), dtype=torch.int32, device=q.device)
         dist = torch.empty((Q,), dtype=torch.float32, device=q.device) if return_distance else None
         self.model._ctx.call("mocha_match", _ptr(q), Q, _ptr(idx), _ptr(dist), _stream())
         if return_distance:
             return dist[:, None], idx[:, None]
         return idx[:, None]
+
+    def gather_blend(self, idx, dist, temperature: float = 1.0):
+        """Soft context matching over the k neighbours of ``query(q, k)``: softmax(-dist / temperature)-weighted sum of their
+        ``encoded`` entries, (Q,90,256).  An extension (SURVEY.md §8f N4 "optional"): the reference gathers the single nearest."""
+        if getattr(self.model, "_bank", None) is not self:
+            self.activate()
+        idx = idx.to(device=self.model.device, dtype=torch.int32).contiguous()
+        d = dist.to(self.model.device, torch.float32).contiguous()
+        Q, k = idx.shape
+        out = torch.empty((Q, NTOK, DIM), dtype=torch.float32, device=self.model.device)
+        self.model._ctx.call("mocha_bank_gather_blend", _ptr(idx), _ptr(d), C.c_float(temperature), Q, k, _ptr(out), _stream())
+        return out
 
     def gather(self, idx):
         if getattr(self.model, "_bank", None) is not self:

@@ -199,3 +199,41 @@ def test_many_query_matcher_beyond_the_register_resident_score_chunks(model):
     ri16, _ = _torch_bruteforce(q - c, b16)
     i16 = ContextBank(model, bank, bank.view(N, 90, 256), bf16=True).query(q, return_distance=False)
     assert torch.equal(i16[:, 0].long(), ri16)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_top_k_query_and_soft_blend(model, bf16):
+    """BallTree.query(k > 1) semantics (optional): the k nearest rows, exact, distances ascending, ties to the
+    lower index; fewer rows than k -> -1 / inf; and the softmax-weighted blend of the neighbours' encoded entries."""
+    from mocha_sigasia2023_amd import ContextBank
+    N, Q, k = 203, 11, 5
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    bank = torch.randn((N, 90 * 256), device="cuda", generator=g)
+    enc = torch.randn((N, 90, 256), device="cuda", generator=g)
+    bank[17] = bank[3]                                             # an exact tie: rows 3 and 17
+    q = torch.randn((Q, 90 * 256), device="cuda", generator=g)
+    q[0] = bank[3] + 0.01 * q[0]
+    b = ContextBank(model, bank, enc, bf16=bf16)
+    dist, idx = b.query(q, k=k)
+    if bf16:
+        c = bank.double().mean(0).float()
+        ref_bank, ref_q = (bank - c).to(torch.bfloat16).double(), (q - c).double()
+    else:
+        ref_bank, ref_q = bank.double(), q.double()
+    d = torch.cdist(ref_q, ref_bank)
+    order = torch.argsort(d + 1e-15 * torch.arange(N, device="cuda")[None], dim=1, stable=True)[:, :k]
+    assert torch.equal(idx.long(), order)
+    assert idx[0, 0].item() == 3 and idx[0, 1].item() == 17         # the tie goes to the lower index first
+    assert torch.allclose(dist.double(), torch.gather(d, 1, order), rtol=1e-5)
+    d1, i1 = b.query(q)                                             # k = 1 fast path agrees with the first column
+    assert torch.equal(i1[:, 0], idx[:, 0]) and torch.allclose(d1[:, 0], dist[:, 0], rtol=1e-5)
+    out = b.gather_blend(idx, dist, temperature=2.0)
+    w = torch.softmax(-dist.double() / 2.0, dim=1)
+    ref = (w[:, :, None, None] * enc.double()[idx.long()]).sum(1)
+    assert float((out.double() - ref).abs().max()) < 1e-5
+    small = ContextBank(model, bank[:3].contiguous(), enc[:3].contiguous(), bf16=bf16)
+    ds, js = small.query(q[:2], k=5)                                # fewer rows than k
+    assert (js[:, 3:] == -1).all() and torch.isinf(ds[:, 3:]).all() and (js[:, :3] >= 0).all()
+    assert torch.isfinite(small.gather_blend(js, ds)).all()
+    with pytest.raises(ValueError):
+        b.query(q, k=0)
