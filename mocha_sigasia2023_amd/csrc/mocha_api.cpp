@@ -1380,6 +1380,9 @@ int mocha_bank_broadcast(mocha_ctx* c, void* comm_, int root, int64_t N, int fla
     const size_t D = 90 * 256;
     if (rank == root) {
         if (!c->bank_cnt || c->bank_N != N) return fail(c, MOCHA_ERR_STATE, "root has no current bank of %lld entries", (long long)N);
+        if (c->bank_is_bf16 != ((flags & MOCHA_BANK_BF16) != 0))
+            return fail(c, MOCHA_ERR_ARG, "root's bank was set %s MOCHA_BANK_BF16 but the broadcast asks for the opposite: every rank must match against the same bank",
+                        c->bank_is_bf16 ? "with" : "without");
     } else {
         if (c->bank_cap < (size_t)N) {
             HIPCHK(c, hipDeviceSynchronize());
