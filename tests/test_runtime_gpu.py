@@ -167,3 +167,38 @@ def test_bench_one_rank_over_rccl_and_launcher_refuses_missing_gpus():
     n = torch.cuda.device_count()
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(n + 1)], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "exposes" in (r.stderr + r.stdout)
+
+
+def test_step_graph_raw_poses(model):
+    """mocha_step_graph with raw = 1: un-normalised poses with the root bone in, de-normalised poses out (rows a1 / a13 fused),
+    equal to the batched raw call bit for bit (same kernels at B = 1)."""
+    from mocha_sigasia2023_amd.generator import _ptr, _stream
+    rng = np.random.Generator(np.random.PCG64(8))
+    Xm = rng.standard_normal((25, 15)).astype(np.float32); Xs = rng.uniform(0.5, 2.0, (25, 15)).astype(np.float32)
+    Ym = rng.standard_normal((25, 15)).astype(np.float32); Ys = rng.uniform(0.5, 2.0, (25, 15)).astype(np.float32)
+    model.set_pose_norm(Xm, Xs, Ym, Ys)
+    mean, std = _norm()
+    tm, ts = torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda()
+    cha = torch.from_numpy((rng.standard_normal((12, 60, 25, 15)) * 2 + 1).astype(np.float32)).cuda()
+    src = torch.from_numpy((rng.standard_normal((3, 60, 25, 15)) * 2 + 1).astype(np.float32)).cuda()
+    e, c, n = model.encode(cha, mean, std, raw=True)
+    bank = ContextBank(model, n, e)
+    x = torch.empty((1, 60, 25, 15), device="cuda"); y = torch.empty((1, 60, 24, 15), device="cuda")
+    idx = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    for i in range(3):
+        Yb, ib = bank.characterize(src[i:i + 1].contiguous(), mean, std, return_index=True, raw=True)
+        x.copy_(src[i:i + 1])
+        model._ctx.call("mocha_step_graph", _ptr(x), _ptr(tm), _ptr(ts), _ptr(y), _ptr(idx), 1, _stream())
+        torch.cuda.synchronize()
+        assert int(idx.item()) == int(ib.item()) and torch.equal(y, Yb)
+
+
+@pytest.mark.timeout(900)
+def test_bank4k_workload_runs():
+    """bench.py --workload bank4k (BASELINE configs[2]): one short run end to end."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--workload", "bank4k", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["value"] > 1e4 and line["n_gpus"] == 1
