@@ -34,7 +34,9 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
                                                          const float* __restrict__ b1, const float* __restrict__ AP,
                                                          float* __restrict__ out, int nframes, int V, int Cin,
                                                          const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
-    __shared__ __attribute__((aligned(16))) float xs_all[4][32 * 16];
+    // rows of 20 floats (16 + 4 pad): the per-lane ds_read_b128 of a joint's 8 features hit 16 distinct 16-byte units per 16-lane
+    // service group (5 l mod 16 is a bijection); with 16-float rows they were 4-way conflicts (PMC: 0.59 conflict cycles per LDS cycle)
+    __shared__ __attribute__((aligned(16))) float xs_all[4][32 * 20];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     float* xs = xs_all[wave];
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
         }
     }
     // staging map of this lane's (at most 8) elements of a frame: element e = lane + 64 i -> joint e / Cin, feature e % Cin,
-    // stored at joint * 16 + (feature & 1) * 8 + (feature >> 1) so that a lane's 8 features of one parity are contiguous
+    // stored at joint * 20 + (feature & 1) * 8 + (feature >> 1) so that a lane's 8 features of one parity are contiguous
     const int nelem = V * Cin;
     int slot[8];
     float zm[8], zs[8];
@@ -68,11 +70,11 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
     for (int i = 0; i < 8; ++i) {
         const int e = lane + 64 * i;
         const int v = e / Cin, ci = e - v * Cin;
-        slot[i] = e < nelem ? v * 16 + (ci & 1) * 8 + (ci >> 1) : -1;
+        slot[i] = e < nelem ? v * 20 + (ci & 1) * 8 + (ci >> 1) : -1;
         zm[i] = (xmean && e < nelem) ? xmean[raw_root * Cin + e] : 0.f;
         zs[i] = (xmean && e < nelem) ? xstd[raw_root * Cin + e] : 1.f;
     }
-    for (int i = lane; i < 32 * 16; i += 64) xs[i] = 0.f;          // padding joints / the padding feature stay zero
+    for (int i = lane; i < 32 * 20; i += 64) xs[i] = 0.f;          // padding joints / the padding feature stay zero
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
             if (slot[i] >= 0) xs[slot[i]] = xmean ? (xr[i] - zm[i]) / zs[i] : xr[i];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xs + l31 * 16 + hh * 8);
-        const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xs + l31 * 16 + hh * 8 + 4);
+        const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xs + l31 * 20 + hh * 8);
+        const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xs + l31 * 20 + hh * 8 + 4);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (frame + stride < nframes) fetch(frame + stride);       // next frame's loads fly under this frame's MFMAs
