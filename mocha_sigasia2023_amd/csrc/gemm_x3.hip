@@ -1,0 +1,355 @@
+// fp32 GEMM on the bf16 matrix pipe of gfx950: C = epilogue(Aop · W^T) with both operands carried as three bf16 planes.
+//
+//   x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)       (round to nearest even; |x - x0 - x1 - x2| <= 2^-27 |x|)
+//   a·b = a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0) + (terms <= 2^-26 |ab|)
+//
+// Six v_mfma_f32_32x32x16_bf16 (fp32 accumulate, every bf16 x bf16 product exact in fp32) reproduce the fp32 product to
+// 2^-26 relative - below the 2^-24 rounding of the fp32 accumulation itself, which is the same as in the exact-f32 kernel of
+// gemm_f32.hip.  The bf16 pipe runs 16x the fp32 MFMA rate, so six passes cost 0.375 of one v_mfma_f32_32x32x2_f32 pass.
+//
+// Structure:
+//   * 128 x 128 tile per 256-thread workgroup, four waves of 64 x 64; K step 16 (one MFMA k): per step and wave 12 ds_read_b128
+//     feed 24 MFMAs, i.e. half a read per MFMA (the LDS array sustains two).
+//   * Weights are packed once (mocha_pack_x3) into the image the kernel consumes: [n tile][k step][plane][k half][128 rows][8 bf16],
+//     12 KB per (tile, step), fetched straight into LDS by three buffer_load ... lds per thread (no VGPR staging, no ds_write).
+//   * Activations stay fp32 in HBM (plain rows, or the temporal-conv gather of kernels.h); a thread fetches two 16-byte pieces per
+//     step, splits them into the three planes (v_cvt_pk_bf16_f32 + a subtraction per level) and writes them with ds_write_b64.
+//     The fetch of step s + 2 is issued as soon as step s + 1's registers have been split, so it has a whole step to land.
+//   * Two LDS stages of 24.8 KB, one barrier per step: while step s is multiplied, step s + 1 is written into the other stage.
+//     49.5 KB per workgroup -> three workgroups per CU cover each other's prologues, barriers and epilogues.
+//   * LDS image per plane: [k half][row][8 bf16] - the 16 lanes a ds_read_b128 serves together read 256 contiguous bytes;
+//     the A halves are 128 bytes further apart than 2 KB so that the b64 writes of a 32-lane group cover all banks once.
+//   * Operands swapped as in gemm_f32.hip (C^T accumulators), same epilogue: transposition through LDS, whole-line stores.
+#include "kernels.h"
+#include "device_utils.h"
+#include <type_traits>
+
+namespace mocha {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#ifndef X3_MAXSUM
+#define X3_MAXSUM 2         // products a_i b_j with i + j <= 2; tools/ builds an ablation with fewer (wrong results, timing only)
+#endif
+static constexpr int XM = 128, XN = 128, XK = 16;
+static constexpr int XA_HALF = 128 * 8 + 64;            // bf16 per k half of an A plane (2 KB + 128 B)
+static constexpr int XA_PLANE = 2 * XA_HALF;            // 2176 bf16
+static constexpr int XB_PLANE = 128 * 16;               // 2048 bf16, [k half][row][8]
+static constexpr int XB_OFF = 3 * XA_PLANE;             // B planes follow the A planes of a stage
+static constexpr int X_STAGE = XB_OFF + 3 * XB_PLANE;   // 12 672 bf16 = 25 344 B
+static constexpr int XW_BLOCK = 3 * XB_PLANE;           // packed weights per (n tile, k step): 6144 bf16 = 12 KB
+
+__device__ __forceinline__ float x3_lrelu(float x) { return x > 0.f ? x : 0.2f * x; }
+__device__ __forceinline__ float x3_gelu(float x) { return 0.5f * x * (1.0f + mocha_erf(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));       // v_cvt_pk_bf16_f32: low half = bf16(a)
+}
+
+// four floats -> three planes of four bf16 (8 bytes each)
+__device__ __forceinline__ void split4_rn(const f32x4 v, u32x2 (&out)[3]) {
+    float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const unsigned p01 = cvt_pk_bf16(r0, r1), p23 = cvt_pk_bf16(r2, r3);
+        out[q][0] = p01; out[q][1] = p23;
+        if (q < 2) {
+            r0 -= __uint_as_float(p01 << 16); r1 -= __uint_as_float(p01 & 0xffff0000u);
+            r2 -= __uint_as_float(p23 << 16); r3 -= __uint_as_float(p23 & 0xffff0000u);
+        }
+    }
+}
+
+// W [N][K] fp32 -> packed planes.  One thread per (row, 8 consecutive k).
+__global__ void mocha_pack_x3(const float* __restrict__ W, int N, int K, unsigned short* __restrict__ out) {
+    const int ksteps = K / XK;
+    const long long total = (long long)((N + XN - 1) / XN) * XN * (K / 8);
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int k8 = (int)(t % (K / 8));
+    const int n = (int)(t / (K / 8));
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+    if (n < N) {
+        lo = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k8 * 8);
+        hi = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k8 * 8 + 4);
+    }
+    u32x2 a[3], b[3];
+    split4_rn(lo, a); split4_rn(hi, b);
+    const int nt = n / XN, r = n % XN, ks = k8 >> 1, h = k8 & 1;
+    unsigned short* blk = out + ((size_t)nt * ksteps + ks) * XW_BLOCK;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const u32x4 v = {a[q][0], a[q][1], b[q][0], b[q][1]};
+        *reinterpret_cast<u32x4*>(blk + q * XB_PLANE + h * 1024 + r * 8) = v;
+    }
+}
+
+size_t gemm_x3_packed_elems(int N, int K) { return (size_t)((N + XN - 1) / XN) * (K / XK) * XW_BLOCK; }
+
+hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s) {
+    if (K % XK != 0) return hipErrorInvalidValue;
+    const long long total = (long long)((N + XN - 1) / XN) * XN * (K / 8);
+    hipLaunchKernelGGL(mocha_pack_x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, N, K, out);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void mocha_gemm_x3(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short x3_sm[];          // [2][X_STAGE]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int n_tiles = (p.N + XN - 1) / XN;
+    const int m_tiles = (p.M + XM - 1) / XM;
+    const int bid = blockIdx.x;
+    int mt, nt;
+    if (m_tiles >= 8) {                 // XCD-aware order: the n-tiles of one m-tile share an XCD (bid % 8)
+        const int grp = bid / (8 * n_tiles);
+        const int rem = bid - grp * 8 * n_tiles;
+        mt = grp * 8 + (rem & 7);
+        nt = rem >> 3;
+    } else {
+        mt = bid / n_tiles;
+        nt = bid - mt * n_tiles;
+    }
+    if (mt >= m_tiles) return;
+    const int m0 = mt * XM, n0 = nt * XN;
+    const int nsteps = p.K / XK;
+
+    // ---- A loader: four lanes cover the 64-byte row segment of a step; a thread takes rows lrow and lrow + 64
+    const int lrow = tid >> 2;
+    const int lc = tid & 3;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.gather ? p.A : p.A + (size_t)(m0 < p.M ? m0 : 0) * p.lda);
+    int a_rb[2], a_t[2];
+    unsigned a_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + lrow + 64 * i;
+        m = m < p.M ? m : p.M - 1;
+        if (p.gather) {
+            const int v = m % p.V;
+            const int bt = m / p.V;
+            a_t[i] = bt % p.T_out;
+            a_rb[i] = (bt / p.T_out) * p.T_src * p.V + v;
+            a_off[i] = 0;
+        } else {
+            a_rb[i] = m; a_t[i] = 0;
+            a_off[i] = ((unsigned)(m - m0) * (unsigned)p.lda + lc * 4) * 4u;
+        }
+    }
+    f32x4 ra[2];
+    auto load_a = [&](int s) __attribute__((always_inline)) {
+        const int k0 = s * XK;
+        if (!p.gather) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ra[i] = bload(rsA, a_off[i], (unsigned)k0 * 4u);
+        } else {
+            const int tap = k0 / p.Cc;
+            const int cin = k0 - tap * p.Cc;
+            if (cin == 0 || s == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    int tf = a_t[i] * p.stride + tap - p.pad;
+                    tf = tf < 0 ? -tf : tf;
+                    tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
+                    a_off[i] = ((unsigned)(a_rb[i] + (tf >> p.tshift) * p.V) * (unsigned)p.lda + lc * 4) * 4u;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ra[i] = bload(rsA, a_off[i], (unsigned)cin * 4u);
+        }
+    };
+    // plane q of (row, piece lc): k half lc >> 1, 8 bytes at (lc & 1)
+    const int a_wr = (lc >> 1) * XA_HALF + lrow * 8 + (lc & 1) * 4;
+    auto split_store = [&](unsigned short* st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            f32x4 v = ra[i];
+            if (p.a_lrelu) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
+            u32x2 pl[3];
+            split4_rn(v, pl);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(st + q * XA_PLANE + a_wr + i * 64 * 8) = pl[q];
+        }
+    };
+    // ---- W: linear copy of the packed 12 KB block of (nt, step) into the stage
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.Wsplit + (size_t)nt * nsteps * XW_BLOCK);
+    auto dma_w = [&](int s, unsigned short* st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + XB_OFF + (j * 4 + wave) * 512), 16,
+                                                     (unsigned)(j * 256 + tid) * 16u, (unsigned)s * (XW_BLOCK * 2u), 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment of lane (row l31, k half hh): 16 bytes
+    const int fa = hh * XA_HALF + (wm * 64 + l31) * 8;
+    const int fb = XB_OFF + hh * 1024 + (wn * 64 + l31) * 8;
+
+    // prologue: step 0 into stage 0, step 1's activations into registers
+    load_a(0);
+    dma_w(0, x3_sm);
+    split_store(x3_sm);
+    load_a(1);                                      // K >= 32 (gemm_x3_supports)
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    // One K step.  FETCH_W: step s + 1 exists (its weights are copied and its activations split into the other stage);
+    // FETCH_A: step s + 2 exists (its activations are fetched).  The three variants are straight-line code, so the compiler's own
+    // vmcnt bookkeeping for the activation registers is exact: the split waits for the two oldest fetches only, not for the copy.
+    auto step = [&](int s, auto fetch_w, auto fetch_a) __attribute__((always_inline)) {
+        constexpr bool FETCH_W = decltype(fetch_w)::value, FETCH_A = decltype(fetch_a)::value;
+        unsigned short* cur = x3_sm + (s & 1) * X_STAGE;
+        unsigned short* nxt = x3_sm + ((s & 1) ^ 1) * X_STAGE;
+        if (FETCH_W) dma_w(s + 1, nxt);             // first thing after the barrier: a whole step to land
+        s16x8 a[3][2], b[3][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[q][i] = *reinterpret_cast<const s16x8*>(cur + q * XA_PLANE + fa + i * 32 * 8);
+                b[q][i] = *reinterpret_cast<const s16x8*>(cur + q * XB_PLANE + fb + i * 32 * 8);
+            }
+        if (FETCH_W) split_store(nxt);
+        if (FETCH_A) load_a(s + 2);
+        // low-order products first, the dominant a0·b0 last
+#pragma unroll
+        for (int sum = X3_MAXSUM; sum >= 0; --sum)
+#pragma unroll
+            for (int pa = 0; pa <= sum; ++pa) {
+                const int pb = sum - pa;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[pb][j], a[pa][i], acc[i][j], 0, 0, 0);   // C^T tile
+            }
+        // the weights of step s + 1 have landed and this wave's plane writes are done; step s + 2's activations stay in flight
+        // (__syncthreads() would drain them: its fence waits for vmcnt(0))
+        if (FETCH_A) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    using T = std::true_type; using F = std::false_type;
+    for (int s = 0; s + 2 < nsteps; ++s) step(s, T{}, T{});
+    step(nsteps - 2, T{}, F{});
+    step(nsteps - 1, F{}, F{});
+
+    // ---- epilogue: as in gemm_f32.hip (acc[i][j] = C^T of MFMA tile (i, j): lane & 31 = row, regs 4g..4g+3 = 4 columns)
+    const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) && ((p.N & 3) == 0);
+    const __amdgpu_buffer_rsrc_t rsC = make_rsrc(p.C + (size_t)m0 * p.ldc + n0);
+    const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(p.bias ? p.bias + n0 : p.A);
+    const __amdgpu_buffer_rsrc_t rsRb = make_rsrc(p.rowbias ? p.rowbias + n0 : p.A);
+    const __amdgpu_buffer_rsrc_t rsRes = make_rsrc(p.residual ? p.residual + (size_t)m0 * p.ldr + n0 : p.A);
+
+    if (vec_ok && n0 + XN <= p.N) {
+        constexpr int LDP = XN + 4;
+        constexpr int C4 = XN / 4;
+        static_assert(64 * LDP * 4 <= 2 * X_STAGE * 2, "epilogue staging fits the operand stages");
+        float* stage = reinterpret_cast<float*>(x3_sm);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (wm == h) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float* srow = stage + (i * 32 + l31) * LDP + wn * 64 + 4 * hh;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            *reinterpret_cast<f32x4*>(srow + j * 32 + 8 * g) = v;
+                        }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 64 * C4 / 256; ++it) {
+                const int e = tid + 256 * it;
+                const int r = e / C4, c4 = e - r * C4;
+                const int rloc = 64 * h + r;
+                const int row = m0 + rloc;
+                if (row < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4);
+                    const unsigned cb = (unsigned)c4 * 16u;
+                    if (p.bias) v += bload(rsBias, cb, 0u);
+                    if (p.rowbias) v += bload(rsRb, (unsigned)(row % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);
+                    if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
+                    else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
+                    else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if (p.residual) v += bload(rsRes, (unsigned)rloc * (unsigned)p.ldr * 4u + cb, 0u);
+                    bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
+                }
+            }
+            if (h == 0) __syncthreads();
+        }
+        return;
+    }
+
+    // ragged tiles (N not a multiple of 128, unaligned leading dimensions): straight from the accumulators
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = m0 + wm * 64 + i * 32 + l31;
+        if (row >= p.M) continue;
+        const float* rbrow = p.rowbias ? p.rowbias + (size_t)(row % p.rb_mod) * p.N : nullptr;
+        const float* rsrow = p.residual ? p.residual + (size_t)row * p.ldr : nullptr;
+        float* crow = p.C + (size_t)row * p.ldc;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c1 = n0 + wn * 64 + j * 32 + 8 * g + 4 * hh + e;
+                    if (c1 >= p.N) continue;
+                    float x = acc[i][j][4 * g + e];
+                    if (p.bias) x += p.bias[c1];
+                    if (rbrow) x += rbrow[c1];
+                    if (p.act == 1) x = x3_gelu(x);
+                    else if (p.act == 2) x = x3_lrelu(x);
+                    else if (p.act == 3) x = fmaxf(x, 0.f);
+                    if (rsrow) x += rsrow[c1];
+                    crow[c1] = x;
+                }
+    }
+}
+
+static constexpr size_t x3_lds_bytes() { return (size_t)2 * X_STAGE * sizeof(unsigned short); }
+
+hipError_t gemm_x3_init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes());
+}
+
+// shapes this engine takes; everything else stays on the exact-f32 kernels
+bool gemm_x3_supports(const GemmParams& p) {
+    if (p.wsub || p.ksplit > 1 || p.K % XK != 0 || p.K < 2 * XK) return false;
+    if (p.gather && (p.R != 1 || p.Cc % XK != 0)) return false;
+    if (gemm_is_skinny(p) || gemm_is_small(p)) return false;
+    return true;
+}
+
+hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
+    if (p.M <= 0 || p.N <= 0) return hipSuccess;
+    if (!p.Wsplit || !gemm_x3_supports(p)) return hipErrorInvalidValue;
+    if (p.gather && (long long)p.M / p.T_out * p.T_src * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
+    if (128ll * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
+    const int m_tiles = (p.M + XM - 1) / XM;
+    const int m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
+    hipLaunchKernelGGL(mocha_gemm_x3, dim3(m_pad * ((p.N + XN - 1) / XN)), dim3(256), x3_lds_bytes(), s, p);
+    return hipGetLastError();
+}
+
+}  // namespace mocha

@@ -46,6 +46,13 @@ hipError_t gemm_split_init();
 hipError_t launch_gemm_split(const GemmParams& p, int planes, hipStream_t s);
 void split_weights_host(const float* w, size_t count, unsigned short* out /*3*count*/);   // true: 128x64 tiles (mocha_gemm_f32<64,...>), false: 128x128
 hipError_t gemm_init();           // one-time function attributes (dynamic LDS size)
+// fp32 GEMM on the bf16 matrix pipe (gemm_x3.hip): both operands as three bf16 planes, six MFMA passes, fp32-accurate.
+// p.Wsplit = the packed image of W made by launch_pack_x3 (gemm_x3_packed_elems(N, K) bf16).
+hipError_t gemm_x3_init();
+bool gemm_x3_supports(const GemmParams& p);
+size_t gemm_x3_packed_elems(int N, int K);
+hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s);
+hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Fused transformer-layer tail (xf_tail.hip; net/transformer.py:91-94):

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <deque>
 #include <map>
+#include <tuple>
 #include <string>
 #include <vector>
 
@@ -146,6 +147,9 @@ struct mocha_ctx {
     bool cvae_ready = false;
     int cvae_depth = 2, cvae_heads = 4, cvae_nc = 180, cvae_nq = 90;
     std::map<std::string, DevBuf> cws; int cvae_B = 0;
+    // fp32 GEMMs on the bf16 matrix pipe (gemm_x3.hip): packed three-plane images of the weights, made on first use
+    bool gemm_x3 = true;
+    std::map<std::tuple<const float*, int, int>, unsigned short*> x3w;
     bool fold_decoder = true;          // decoder key / value projections folded into the query / output weights
     bool gather_pool = false;          // AvgPool(4) folded into the k=5 temporal conv's A gather instead of mocha_window_sums
     bool fuse_tail = false; int fuse_tail_min_rows = 8192;      // out-proj + FF in one launch (xf_tail.hip) from this many token rows on
@@ -380,9 +384,43 @@ const char* gemm_kernel_name(const GemmParams& p) {
     return gemm_is_narrow(p) ? "mocha_gemm_f32<64,4,1,1,2>" : "mocha_gemm_f32<128,2,2,2,2>";
 }
 
+// packed weight image of the bf16x3 engine for (W, N, K); made on first use (not while the stream is capturing: the caller
+// then takes the exact-f32 kernel), dropped whenever weights are (re-)finalised
+int x3_image(mocha_ctx* c, hipStream_t s, const GemmParams& p, const unsigned short** out) {
+    *out = nullptr;
+    const auto key = std::make_tuple(p.W, p.N, p.K);
+    auto it = c->x3w.find(key);
+    if (it != c->x3w.end()) { *out = it->second; return 0; }
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return 0;
+    float* d = nullptr;
+    int rc = dev_alloc(c, &d, (gemm_x3_packed_elems(p.N, p.K) + 1) / 2);
+    if (rc) return rc;
+    HIPCHK(c, launch_pack_x3(p.W, p.N, p.K, reinterpret_cast<unsigned short*>(d), s));
+    HIPCHK(c, hipStreamSynchronize(s));             // once per weight: the image may be read from the other stream of a dual-stream step
+    c->x3w[key] = reinterpret_cast<unsigned short*>(d);
+    *out = c->x3w[key];
+    return 0;
+}
+
+void x3_drop_images(mocha_ctx* c) {
+    for (auto& kv : c->x3w) dev_free(c, reinterpret_cast<float*>(kv.second));
+    c->x3w.clear();
+}
+
 int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
     const double flops = 2.0 * p.M * (double)p.N * p.K;
     const double bytes = 4.0 * ((double)p.M * p.K / (p.gather ? p.ntaps : 1) * (p.R) + (double)p.N * p.K + (double)p.M * p.N * p.ksplit);
+    if (c->gemm_x3 && gemm_x3_supports(p)) {
+        const unsigned short* img = nullptr;
+        int rc = x3_image(c, s, p, &img);
+        if (rc) return rc;
+        if (img) {
+            GemmParams q = p; q.Wsplit = img;
+            LAUNCH(c, s, "mocha_gemm_x3", site, flops, bytes, launch_gemm_x3(q, s));
+            return 0;
+        }
+    }
     LAUNCH(c, s, gemm_kernel_name(p), site, flops, bytes, launch_gemm(p, s));
     return 0;
 }
@@ -736,6 +774,7 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = gemm_init();
     if (e == hipSuccess) e = gemm_split_init();
+    if (e == hipSuccess) e = gemm_x3_init();
     if (e == hipSuccess) e = match_mfma_init();
     if (e == hipSuccess) e = xf_tail_init();
     if (e == hipSuccess) e = featurize_init();
@@ -788,6 +827,8 @@ int mocha_finalize_weights(mocha_ctx* c) {
     for (auto& kv : c->expect)
         if (!c->host_w.count(kv.first)) return fail(c, MOCHA_ERR_STATE, "missing weight '%s'", kv.first.c_str());
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    x3_drop_images(c);                              // re-loaded weights keep their device addresses
     const Skeleton& sk = c->sk;
     const int V = sk.V;
     int rc = 0;
@@ -1491,6 +1532,8 @@ int mocha_cvae_finalize(mocha_ctx* c) {
     for (auto& kv : c->cvae_expect)
         if (!c->cvae_host.count(kv.first)) return fail(c, MOCHA_ERR_STATE, "missing CVAE weight '%s'", kv.first.c_str());
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipDeviceSynchronize());
+    x3_drop_images(c);
     for (auto& kv : c->cvae_host) {
         int rc = upload_to(c, c->cw, c->cwsize, kv.first, kv.second.data); if (rc) return rc;
     }
@@ -1721,6 +1764,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "fold_decoder") { c->fold_decoder = value != 0; return 0; }
     if (n == "fuse_tail") { c->fuse_tail = value != 0; return 0; }
     if (n == "gather_pool") { c->gather_pool = value != 0; return 0; }
+    if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; return 0; }
     if (n == "fuse_tail_min_rows") { c->fuse_tail_min_rows = value < 1 ? 1 : value; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);
 }

@@ -1,7 +1,14 @@
 #!/bin/bash
+# builds tools/bin/gemm_bench (and, with an argument, an ablation of gemm_x3.hip: build_gemm_bench.sh -DX3_MAXSUM=0 -> tools/bin/gemm_bench_abl)
 set -e
 cd "$(dirname "$0")/.."
 make -C mocha_sigasia2023_amd/csrc -j4 >/dev/null
 mkdir -p tools/bin
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -I mocha_sigasia2023_amd/csrc -c tools/gemm_bench.hip -o tools/bin/gemm_bench.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 tools/bin/gemm_bench.o mocha_sigasia2023_amd/csrc/gemm_f32.o mocha_sigasia2023_amd/csrc/gemm_split.o -o tools/bin/gemm_bench
+H="/opt/rocm/bin/hipcc --offload-arch=gfx950"
+$H -O3 -std=c++17 -w -I mocha_sigasia2023_amd/csrc -c tools/gemm_bench.hip -o tools/bin/gemm_bench.o
+C=mocha_sigasia2023_amd/csrc
+$H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_split.o $C/gemm_x3.o -o tools/bin/gemm_bench
+if [ -n "$1" ]; then
+  $H -O3 -fPIC -std=c++17 -w "$@" -c $C/gemm_x3.hip -o tools/bin/gemm_x3_abl.o
+  $H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_split.o tools/bin/gemm_x3_abl.o -o tools/bin/gemm_bench_abl
+fi

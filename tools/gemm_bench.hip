@@ -12,12 +12,12 @@ using namespace mocha;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
-__global__ void ref_gemm(const float* A, const float* W, float* C, int M, int N, int K) {
+__global__ void ref_gemm(const float* A, const float* W, double* C, int M, int N, int K) {
     int n = blockIdx.x * 16 + threadIdx.x, m = blockIdx.y * 16 + threadIdx.y;
     if (m >= M || n >= N) return;
     double a = 0;
     for (int k = 0; k < K; ++k) a += (double)A[(size_t)m * K + k] * W[(size_t)n * K + k];
-    C[(size_t)m * N + n] = (float)a;
+    C[(size_t)m * N + n] = a;
 }
 
 struct Shape { const char* name; int M, N, K; int gather; int T_out, V, ntaps, pad, stride, R, T_full, tshift, Cc, T_src; int lda; };
@@ -26,8 +26,8 @@ int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 585;
     int iters = argc > 2 ? atoi(argv[2]) : 20;
     int check = argc > 3 ? atoi(argv[3]) : 1;
-    int mode = argc > 4 ? atoi(argv[4]) : 0;      // 0 = exact f32 MFMA, 33 = split bf16 x6
-    CK(gemm_init()); CK(gemm_split_init());
+    int mode = argc > 4 ? atoi(argv[4]) : 0;      // 0 = exact f32 MFMA, 33 = first split-bf16 engine (gemm_split.hip), 36 = gemm_x3.hip
+    CK(gemm_init()); CK(gemm_split_init()); CK(gemm_x3_init());
     std::vector<Shape> shapes = {
         {"enc.qkv      ", B * 90, 1536, 256, 0},
         {"xf.out512    ", B * 90, 256, 512, 0},
@@ -61,17 +61,19 @@ int main(int argc, char** argv) {
         const bool zero = getenv("MOCHA_BENCH_ZERO") != nullptr;      // zero operands: the clock the chip holds without data toggling
         for (auto& v : ha) v = zero ? 0.f : (float)rand() / RAND_MAX * 2 - 1;
         for (auto& v : hw) v = zero ? 0.f : (float)rand() / RAND_MAX * 2 - 1;
-        float *dA, *dW, *dC, *dR;
+        float *dA, *dW, *dC; double* dR;
         CK(hipMalloc(&dA, na * 4)); CK(hipMalloc(&dW, nw * 4)); CK(hipMalloc(&dC, nc * 4 * (sh.M == 585 && sh.N == 585 ? 16 : 1)));
         CK(hipMemcpy(dA, ha.data(), na * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hw.data(), nw * 4, hipMemcpyHostToDevice));
         unsigned short* dWs = nullptr;
-        if (mode) { std::vector<unsigned short> hs(3 * nw); split_weights_host(hw.data(), nw, hs.data()); CK(hipMalloc(&dWs, 3 * nw * 2)); CK(hipMemcpy(dWs, hs.data(), 3 * nw * 2, hipMemcpyHostToDevice)); }
+        if (mode == 36) { CK(hipMalloc(&dWs, gemm_x3_packed_elems(sh.N, sh.K) * 2)); CK(launch_pack_x3(dW, sh.N, sh.K, dWs, 0)); }
+        else if (mode) { std::vector<unsigned short> hs(3 * nw); split_weights_host(hw.data(), nw, hs.data()); CK(hipMalloc(&dWs, 3 * nw * 2)); CK(hipMemcpy(dWs, hs.data(), 3 * nw * 2, hipMemcpyHostToDevice)); }
         GemmParams p; p.Wsplit = dWs; p.A = dA; p.W = dW; p.C = dC; p.M = sh.M; p.N = sh.N; p.K = sh.K; p.lda = lda; p.ldc = sh.N;
         if (sh.gather) { p.gather = 1; p.T_out = sh.T_out; p.V = sh.V; p.ntaps = sh.ntaps; p.pad = sh.pad; p.stride = sh.stride; p.R = sh.R;
                          p.T_full = sh.T_full; p.tshift = sh.tshift; p.Cc = sh.Cc; p.T_src = sh.T_src; p.ascale = sh.R > 1 ? 0.25f : 1.f; }
         if (sh.M == 585 && sh.N == 585) { p.ksplit = 16; p.slab_stride = (long long)sh.M * sh.N; }
-        auto run = [&]() { return mode ? launch_gemm_split(p, mode, 0) : launch_gemm(p, 0); };
-        if (mode && sh.gather && sh.R != 1) { printf("%s skipped (R != 1)\n", sh.name); CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(dWs)); continue; }
+        const bool x3 = mode == 36 && gemm_x3_supports(p);
+        auto run = [&]() { return x3 ? launch_gemm_x3(p, 0) : (mode && mode != 36) ? launch_gemm_split(p, mode, 0) : launch_gemm(p, 0); };
+        if (mode && mode != 36 && sh.gather && sh.R != 1) { printf("%s skipped (R != 1)\n", sh.name); CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(dWs)); continue; }
         for (int i = 0; i < 3; ++i) CK(run());
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, 0));
@@ -79,16 +81,18 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
         double tf = 2.0 * sh.M * sh.N * sh.K / (ms * 1e-3) / 1e12;
-        double err = -1;
+        double err = -1, rms = -1;
         if (check && !sh.gather && p.ksplit == 1 && (double)sh.M * sh.N * sh.K < 3e11) {
-            CK(hipMalloc(&dR, nc * 4));
+            CK(hipMalloc(&dR, nc * 8));
             hipLaunchKernelGGL(ref_gemm, dim3((sh.N + 15) / 16, (sh.M + 15) / 16), dim3(16, 16), 0, 0, dA, dW, dR, sh.M, sh.N, sh.K);
-            std::vector<float> hc(nc), hr(nc);
-            CK(hipMemcpy(hc.data(), dC, nc * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr.data(), dR, nc * 4, hipMemcpyDeviceToHost));
-            err = 0; for (size_t i = 0; i < nc; ++i) err = fmax(err, fabs((double)hc[i] - hr[i]));
+            std::vector<float> hc(nc); std::vector<double> hr(nc);
+            CK(hipMemcpy(hc.data(), dC, nc * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hr.data(), dR, nc * 8, hipMemcpyDeviceToHost));
+            err = 0; double se = 0;
+            for (size_t i = 0; i < nc; ++i) { const double d = (double)hc[i] - hr[i]; err = fmax(err, fabs(d)); se += d * d; }
+            rms = sqrt(se / nc);
             CK(hipFree(dR));
         }
-        printf("%s M=%7d N=%5d K=%5d  %9.1f us  %7.2f TFLOP/s  (%.1f%% of 157.3)  maxerr=%g\n", sh.name, sh.M, sh.N, sh.K, ms * 1e3, tf, tf / 157.3 * 100, err);
+        printf("%s M=%7d N=%5d K=%5d  %9.1f us  %7.2f TFLOP/s  (%.1f%% of 157.3)  %s maxerr=%.3g rms=%.3g\n", sh.name, sh.M, sh.N, sh.K, ms * 1e3, tf, tf / 157.3 * 100, x3 ? "x3 " : "f32", err, rms);
         CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); if (dWs) CK(hipFree(dWs));
     }
     return 0;
