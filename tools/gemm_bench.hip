@@ -46,6 +46,17 @@ int main(int argc, char** argv) {
         {"match 585    ", 585, 585, 23040, 0},
         {"square 4096  ", 4096, 4096, 4096, 0},
     };
+    if (getenv("MOCHA_BENCH_SHAPES")) {            // "M,N,K;M,N,K;..." plain shapes
+        shapes.clear();
+        static std::vector<std::string> names;
+        const char* q = getenv("MOCHA_BENCH_SHAPES");
+        while (*q) {
+            int m, n, k, used = 0;
+            if (sscanf(q, "%d,%d,%d%n", &m, &n, &k, &used) != 3) break;
+            shapes.push_back({"custom       ", m, n, k, 0});
+            q += used; if (*q == ';') ++q;
+        }
+    }
     if (getenv("MOCHA_BENCH_KSWEEP")) {            // time vs K at fixed M, N: intercept = per-launch fixed cost
         shapes.clear();
         static const int ks[] = {32, 64, 128, 256, 384, 512, 768, 1024, 1536, 2048};
@@ -90,6 +101,22 @@ int main(int argc, char** argv) {
             err = 0; double se = 0;
             for (size_t i = 0; i < nc; ++i) { const double d = (double)hc[i] - hr[i]; err = fmax(err, fabs(d)); se += d * d; }
             rms = sqrt(se / nc);
+            if (getenv("MOCHA_BENCH_DIAG")) {          // where are the wrong elements?
+                long bad = 0; std::vector<long> byrow(128, 0), bycol(128, 0); long first = -1;
+                std::vector<long> bymt((sh.M + 127) / 128, 0);
+                for (size_t i = 0; i < nc; ++i) {
+                    const double d = fabs((double)hc[i] - hr[i]);
+                    if (!(d < 1e-2)) { ++bad; if (first < 0) first = (long)i; byrow[(i / sh.N) % 128]++; bycol[(i % sh.N) % 128]++; bymt[(i / sh.N) / 128]++; }
+                }
+                long tiles_bad = 0; for (long v : bymt) tiles_bad += v > 0;
+                printf("  bad=%ld first=(%ld,%ld) bad m-tiles=%ld of %zu\n  rows-in-tile:", bad, first / sh.N, first % sh.N, tiles_bad, bymt.size());
+                for (int r = 0; r < 128; ++r) if (byrow[r]) printf(" %d:%ld", r, byrow[r]);
+                printf("\n  cols-in-tile:");
+                for (int r = 0; r < 128; ++r) if (bycol[r]) printf(" %d:%ld", r, bycol[r]);
+                printf("\n  bad m-tiles:"); int shown = 0;
+                for (size_t t = 0; t < bymt.size() && shown < 40; ++t) if (bymt[t]) { printf(" %zu:%ld", t, bymt[t]); ++shown; }
+                printf("\n");
+            }
             CK(hipFree(dR));
         }
         printf("%s M=%7d N=%5d K=%5d  %9.1f us  %7.2f TFLOP/s  (%.1f%% of 157.3)  %s maxerr=%.3g rms=%.3g\n", sh.name, sh.M, sh.N, sh.K, ms * 1e3, tf, tf / 157.3 * 100, x3 ? "x3 " : "f32", err, rms);
