@@ -126,6 +126,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     if (mt >= m_tiles) return;
     const int m0 = mt * XM, n0 = nt * XN;
     const int nsteps = p.K / XK;
+#ifdef X3_EXP_STAMPS       // diagnostic build (tools/): cycle stamps per workgroup into the buffer passed as p.wsub
+    long long stamp[4];
+    stamp[3] = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz, common to the chip
+    stamp[0] = (long long)__builtin_amdgcn_s_memtime();
+#define X3_STAMP(i) stamp[i] = (long long)__builtin_amdgcn_s_memtime()
+#define X3_STAMP_OUT() do { if (tid == 0) { long long* d = (long long*)p.wsub + (size_t)bid * 6; d[0] = stamp[0]; d[1] = stamp[1]; d[2] = stamp[2]; d[3] = (long long)__builtin_amdgcn_s_memtime(); d[4] = stamp[3]; d[5] = (long long)__builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define X3_STAMP(i)
+#define X3_STAMP_OUT()
+#endif
 
     // ---- A loader: four lanes cover the 64-byte row segment of a step; a thread takes rows lrow and lrow + 64
     const int lrow = tid >> 2;
@@ -280,10 +290,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (FETCH_A) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
+    X3_STAMP(1);
     using T = std::true_type; using F = std::false_type;
     for (int s = 0; s + 2 < nsteps; ++s) step(s, T{}, T{});
     step(nsteps - 2, T{}, F{});
     step(nsteps - 1, F{}, F{});
+    X3_STAMP(2);
 
     // ---- epilogue: as in gemm_f32.hip (acc[i][j] = C^T of MFMA tile (i, j): lane & 31 = row, regs 4g..4g+3 = 4 columns)
     const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) && ((p.N & 3) == 0);
@@ -333,6 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
             if (h == 0) __syncthreads();
         }
+        X3_STAMP_OUT();
         return;
     }
 
@@ -376,7 +389,11 @@ hipError_t gemm_x3_init() {
 
 // shapes this engine takes; everything else stays on the exact-f32 kernels
 bool gemm_x3_supports(const GemmParams& p) {
-    if (p.wsub || p.ksplit > 1 || p.K % XK != 0 || p.K < 2 * XK) return false;
+#ifndef X3_EXP_STAMPS
+    if (p.wsub) return false;
+#endif
+    if (p.ksplit > 1 || p.K % XK != 0 || p.K < 2 * XK) return false;
+    if (p.N % XN != 0) return false;                // N = 64 / 192 (to_mot's joint block): a padded 128-wide tile loses to the exact-f32 128 x 64 tile (measured)
     if (p.gather && (p.R != 1 || p.Cc % XK != 0)) return false;
     if (gemm_is_skinny(p) || gemm_is_small(p)) return false;
     return true;

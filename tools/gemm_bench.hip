@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <vector>
+#include <algorithm>
 #include <string>
 #include "kernels.h"
 using namespace mocha;
@@ -85,6 +86,8 @@ int main(int argc, char** argv) {
         const bool x3 = mode == 36 && gemm_x3_supports(p);
         auto run = [&]() { return x3 ? launch_gemm_x3(p, 0) : (mode && mode != 36) ? launch_gemm_split(p, mode, 0) : launch_gemm(p, 0); };
         if (mode && mode != 36 && sh.gather && sh.R != 1) { printf("%s skipped (R != 1)\n", sh.name); CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(dWs)); continue; }
+        long long* dstamp = nullptr;
+        if (getenv("MOCHA_BENCH_STAMPS") && x3) { CK(hipMalloc(&dstamp, (size_t)65536 * 32)); CK(hipMemset(dstamp, 0, (size_t)65536 * 32)); p.wsub = (const float*)dstamp; }
         for (int i = 0; i < 3; ++i) CK(run());
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, 0));
@@ -118,6 +121,23 @@ int main(int argc, char** argv) {
                 printf("\n");
             }
             CK(hipFree(dR));
+        }
+        if (dstamp) {
+            const int wgs = ((sh.M + 127) / 128 + 7) / 8 * 8 * ((sh.N + 127) / 128);
+            std::vector<long long> h((size_t)wgs * 6);
+            CK(hipMemcpy(h.data(), dstamp, h.size() * 8, hipMemcpyDeviceToHost));
+            double pro = 0, loop = 0, epi = 0, life_rt = 0; long n = 0; long long tmin = 0, tmax = 0;
+            for (int w = 0; w < wgs; ++w) {
+                const long long* d = &h[6 * (size_t)w];
+                if (!d[0]) continue;
+                pro += d[1] - d[0]; loop += d[2] - d[1]; epi += d[3] - d[2]; life_rt += d[5] - d[4]; ++n;
+                if (!tmin || d[4] < tmin) tmin = d[4];
+                if (d[5] > tmax) tmax = d[5];
+            }
+            const double span_us = (tmax - tmin) / 100.0, life_us = life_rt / n / 100.0;
+            printf("  %ld workgroups: prologue %.0f  K loop %.0f (%.1f per step)  epilogue %.0f shader cycles; lifetime %.1f us = %.2f GHz; first start to last end %.1f us; slot occupancy %.2f\n",
+                   n, pro / n, loop / n, loop / n / (sh.K / 16), epi / n, life_us, (pro + loop + epi) / n / life_us / 1e3, span_us, n * life_us / 768.0 / span_us);
+            CK(hipFree(dstamp));
         }
         printf("%s M=%7d N=%5d K=%5d  %9.1f us  %7.2f TFLOP/s  (%.1f%% of 157.3)  %s maxerr=%.3g rms=%.3g\n", sh.name, sh.M, sh.N, sh.K, ms * 1e3, tf, tf / 157.3 * 100, x3 ? "x3 " : "f32", err, rms);
         CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); if (dWs) CK(hipFree(dWs));
