@@ -40,6 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3     # MI355X dense f32 MFMA peak (MI355X_MICROARCH.md, chip table)
+PEAK_BF16_MFMA_TFLOPS = 16 * 157.3   # dense bf16 MFMA peak: the bf16 pipe runs 16 x the f32 MFMA rate per clock (same table: ~2.5 PF)
+X3_PASSES = 6                    # bf16 MFMA passes per fp32 product in mocha_gemm_x3 (gemm_x3.hip)
 PEAK_HBM_GBS = 8000.0
 METRIC = {22: "characterized frames/sec (whole node) at T=60, 22 joints; 1/2/4/8 GPU",          # BASELINE.json "metric", verbatim
           24: "characterized frames/sec (whole node) at T=60, 24 joints (the shipped model's layout); 1/2/4/8 GPU"}
@@ -370,6 +372,23 @@ def main():
                         "roofline numbers are quoted on the single-stream run above"}
         model.set_option("dual_stream", 0)
 
+    # extra (not the headline): the same step on the exact-f32 MFMA engine (mocha_set_option("gemm_bf16x3", 0))
+    exact_f32 = None
+    if world == 1 and not a.no_extras:
+        model.set_option("gemm_bf16x3", 0)
+        with torch.no_grad():
+            for _ in range(a.warmup):
+                step()
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            sync_all()
+            e3 = time.perf_counter() - t0
+        exact_f32 = {"value": W * a.steps / e3, "ms_per_step": e3 / a.steps * 1e3,
+                     "note": "same step with mocha_set_option(gemm_bf16x3=0): every GEMM on v_mfma_f32_32x32x2_f32 (gemm_f32.hip)"}
+        model.set_option("gemm_bf16x3", 1)
+
     out = None
     if rank == 0:
         # ---- roofline leg: the same step once more with a HIP-event pair around every launch
@@ -384,9 +403,18 @@ def main():
         total_ms = sum(k["ms"] for k in kern.values())
         ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
         traffic, traffic_src = pmc_traffic_for(dom)
+        # mocha_gemm_x3 computes every fp32 product as six bf16 MFMA passes: it is priced on the bf16 pipe with the FLOPs it
+        # executes (6 x the algorithmic fp32 FLOPs); the fp32-equivalent rate is given beside it
+        on_bf16 = dom.startswith("mocha_gemm_x3")
+        exe = ach * X3_PASSES if on_bf16 else ach
+        peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_F32_MFMA_TFLOPS
         roofline = {
-            "kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "kernel": dom, "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s",
+            "frac": exe / peak,
+            "pipe": ("bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate): each fp32 operand as three bf16 planes, six passes per "
+                     "product; 'achieved' counts the executed bf16 FLOPs") if on_bf16 else "f32 MFMA (v_mfma_f32_32x32x2_f32)",
+            "fp32_equivalent": {"achieved": ach, "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac": ach / PEAK_F32_MFMA_TFLOPS},
+            "traffic": traffic,
             "traffic_source": (f"from profile: {traffic_src} (rocprofv3 --pmc passes of this command, committed; PMC counters cannot "
                                "be read inside this process)") if traffic_src else None,
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
@@ -415,6 +443,7 @@ def main():
             "bank_broadcast_ms": bcast_ms, "bank_broadcast_error": bcast_err, "clip_broadcast_ms": clip_bcast_ms,
             "per_rank_frames_per_s": per_rank,
             "dual_stream": dual,
+            "exact_f32_engine": exact_f32,
         }
         if world == 1 and not a.no_extras:
             # extra records measured in the same process (not the headline): the matcher's own roofline on the shapes the

@@ -237,8 +237,23 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * "fold_decoder" (default 1): the decoder's key and value projections are folded into its query and output weights at
  * mocha_finalize_weights (possible because decoder_dim_head == dim; exact algebra, differences are fp32 rounding only),
  * which removes two of the four projection GEMMs per decoder layer; 0 runs the four projections as written in
- * net/transformer.py:62-76. */
+ * net/transformer.py:62-76.
+ * "gemm_bf16x3" (default 1): the large GEMM launches (every nn.Linear / conv-as-GEMM of the path whose batch fills the chip
+ * and whose output width is a multiple of 128) run on the bf16 matrix pipe with both fp32 operands carried as three bf16
+ * planes and six MFMA passes per product, fp32 accumulation (gemm_x3.hip): every bf16 x bf16 product is exact in fp32 and
+ * the dropped cross terms are below 2^-26 of a product, so the result is as accurate as an fp32 FMA chain (measured against
+ * float64: slightly more accurate than the exact-f32 MFMA kernel, tests/test_gemm_engines.py).  0 = every GEMM on
+ * v_mfma_f32_32x32x2_f32 (gemm_f32.hip). */
 int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
+
+/* y (M,N) = x (M,K) · w (N,K)^T + bias (N, may be NULL): nn.Linear (net/transformer.py:28-32, 57-61) as a stand-alone
+ * operator on device pointers, for tests and tooling that want one of the two GEMM engines directly.
+ * engine 0: the kernel the path would pick for this shape under the current options; 1: exact-f32 MFMA; 2: bf16 x 3 planes
+ * (MOCHA_ERR_ARG if the shape is outside that engine: K % 32, N % 128, at least 768 row tiles ... see gemm_x3_supports).
+ * With engine 2 (or 0 resolving to it) w is packed into the engine's image on every call (w may change between calls);
+ * the call synchronises the stream once to free that image.  K % 32 == 0. */
+int mocha_linear(mocha_ctx* ctx, const float* x, const float* w, const float* bias, float* y, int64_t M, int N, int K, int engine,
+                 void* stream);
 
 /* Introspection for tests and tooling. */
 int mocha_abi_version(void);

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmocha_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class mocha_cfg(C.Structure):
@@ -63,6 +63,7 @@ SIGNATURES = {
     "mocha_postprocess": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocha_column_stats": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "mocha_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "mocha_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
     "mocha_graph_constants": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mocha_generation": (_i64, [_vp]),
     "mocha_step_graph": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -746,7 +746,7 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
 // =========================================================================================== C ABI
 extern "C" {
 
-int mocha_abi_version(void) { return 2; }
+int mocha_abi_version(void) { return 3; }
 
 int64_t mocha_generation(const mocha_ctx* c) { return c ? c->generation : 0; }
 
@@ -1767,6 +1767,34 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; return 0; }
     if (n == "fuse_tail_min_rows") { c->fuse_tail_min_rows = value < 1 ? 1 : value; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);
+}
+
+int mocha_linear(mocha_ctx* c, const float* x, const float* w, const float* bias, float* y, int64_t M, int N, int K, int engine,
+                 void* stream) {
+    if (!c || !x || !w || !y) return fail(c, MOCHA_ERR_ARG, "null argument");
+    if (M < 0 || N < 1 || K < 32 || K % 32 != 0 || M > (1ll << 30) || engine < 0 || engine > 2)
+        return fail(c, MOCHA_ERR_ARG, "mocha_linear: M=%lld N=%d K=%d engine=%d (K %% 32 == 0, engine 0..2)", (long long)M, N, K, engine);
+    if (M == 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    GemmParams p = plain(x, K, w, y, N, (int)M, N, K);
+    p.bias = bias;
+    const bool x3 = engine == 2 || (engine == 0 && c->gemm_x3 && gemm_x3_supports(p));
+    if (!x3) {
+        const double flops = 2.0 * M * (double)N * K;
+        LAUNCH(c, s, gemm_kernel_name(p), "linear", flops, 4.0 * ((double)M * K + (double)N * K + (double)M * N), launch_gemm(p, s));
+        return 0;
+    }
+    if (!gemm_x3_supports(p)) return fail(c, MOCHA_ERR_ARG, "mocha_linear: M=%lld N=%d K=%d is outside the bf16x3 engine", (long long)M, N, K);
+    void* img = nullptr;
+    HIPCHK(c, hipMalloc(&img, gemm_x3_packed_elems(N, K) * sizeof(unsigned short)));
+    hipError_t e = launch_pack_x3(w, N, K, (unsigned short*)img, s);
+    p.Wsplit = (const unsigned short*)img;
+    if (e == hipSuccess) e = launch_gemm_x3(p, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(img);
+    if (e != hipSuccess) return fail(c, MOCHA_ERR_HIP, "mocha_linear: %s", hipGetErrorString(e));
+    return 0;
 }
 
 int mocha_profile_start(mocha_ctx* c) {

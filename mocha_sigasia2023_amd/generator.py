@@ -205,6 +205,19 @@ class Generator:
         self._ctx.call("mocha_set_option", name.encode(), int(value))
         return self
 
+    def linear(self, x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, engine: int = 0) -> torch.Tensor:
+        """``torch.nn.functional.linear(x, weight, bias)`` for 2-D fp32 device tensors through one of the library's GEMM engines
+        (``mocha_linear``): 0 = the kernel the path would pick, 1 = exact-f32 MFMA, 2 = bf16 x 3 planes."""
+        x = _dev_f32(x, self.device, name="x")
+        w = _dev_f32(weight, self.device, name="weight")
+        if x.dim() != 2 or w.dim() != 2 or x.shape[1] != w.shape[1]:
+            raise ValueError(f"linear: x {tuple(x.shape)} and weight {tuple(w.shape)} do not match")
+        b = None if bias is None else _dev_f32(bias, self.device, (w.shape[0],), "bias")
+        y = torch.empty((x.shape[0], w.shape[0]), dtype=torch.float32, device=self.device)
+        self._ctx.call("mocha_linear", _ptr(x), _ptr(w), _ptr(b), _ptr(y), int(x.shape[0]), int(w.shape[0]), int(x.shape[1]), int(engine),
+                       _stream())
+        return y
+
     # ---- measurement support -----------------------------------------------------------
     def profile_start(self):
         """Bracket every kernel launch with HIP events until ``profile_stop`` (bench.py)."""

@@ -1,0 +1,99 @@
+"""The two GEMM engines of the library against float64 (run with -m gpu).
+
+* exact-f32 MFMA (gemm_f32.hip, v_mfma_f32_32x32x2_f32) and
+* bf16 x 3 planes (gemm_x3.hip: both fp32 operands as three bf16 planes, six v_mfma_f32_32x32x16_bf16 passes, fp32 accumulate),
+  the default for the large launches of the path (mocha_set_option("gemm_bf16x3", 1)).
+
+Both replace nn.Linear / conv-as-GEMM of the reference (net/transformer.py:28-32, 57-61; net/blocks.py:57-66, 112-118), whose
+arithmetic is fp32.  The claim checked here is that the plane engine is an fp32 GEMM, not a reduced-precision one: its error
+against a float64 product is not larger than the exact-f32 MFMA kernel's on the same operands, on the path's shapes, including
+operands with a wide dynamic range; and the whole network gives the same poses on either engine (1e-4 is the north-star bound on
+the poses; the engines differ by far less)."""
+import numpy as np
+import pytest
+import torch
+
+from mocha_sigasia2023_amd import Generator, synthetic, weights
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _errors(model, x, w, b):
+    ref = x.double() @ w.double().T
+    if b is not None:
+        ref = ref + b.double()
+    out = {}
+    for name, engine in (("f32", 1), ("x3", 2)):
+        y = model.linear(x, w, b, engine=engine)
+        d = (y.double() - ref)
+        out[name] = (float(d.abs().max()), float(d.pow(2).mean().sqrt()))
+    return out, float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,bias", [(105300, 256, 512, True), (105300, 512, 256, False), (30001, 256, 1280, True), (421200, 256, 192, False)])
+def test_plane_engine_is_as_accurate_as_f32_mfma(M, N, K, bias):
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    x = torch.randn((M, K), generator=g, dtype=torch.float32).to(dev())
+    w = (torch.randn((N, K), generator=g, dtype=torch.float32) / np.sqrt(K)).to(dev())
+    b = torch.randn((N,), generator=g, dtype=torch.float32).to(dev()) if bias else None
+    model = Generator(layout="mixamo", device=dev())
+    err, scale = _errors(model, x, w, b)
+    # fp32 accumulation of K terms: a few 1e-6 at unit scale; the plane engine must not be worse than the exact-f32 MFMA kernel
+    assert err["x3"][1] <= err["f32"][1] * 1.02 + 1e-9, (err, scale)
+    assert err["x3"][0] <= err["f32"][0] * 1.5 + 1e-9, (err, scale)
+    assert err["f32"][1] < 2e-5 * max(1.0, scale), (err, scale)
+
+
+def test_plane_engine_wide_dynamic_range():
+    """Operands spanning 12 orders of magnitude per row (the planes are exact for every finite fp32 value that is not denormal in
+    bf16 range), with heavy cancellation in the sums."""
+    M, N, K = 98304, 256, 256
+    g = torch.Generator(device="cpu").manual_seed(7)
+    mag = torch.pow(10.0, torch.empty((M, K)).uniform_(-6, 6, generator=g))
+    x = (torch.randn((M, K), generator=g) * mag).float().to(dev())
+    w = (torch.randn((N, K), generator=g) * torch.pow(10.0, torch.empty((N, K)).uniform_(-3, 3, generator=g))).float().to(dev())
+    model = Generator(layout="mixamo", device=dev())
+    err, scale = _errors(model, x, w, None)
+    assert err["x3"][1] <= err["f32"][1] * 1.02, (err, scale)
+    assert np.isfinite(err["x3"][0])
+
+
+def test_engine_selection_and_errors():
+    model = Generator(layout="mixamo", device=dev())
+    x = torch.randn((256, 64), device=dev())
+    w = torch.randn((128, 64), device=dev())
+    y0 = model.linear(x, w, None, engine=0)                    # a small launch: the exact-f32 kernels either way
+    y1 = model.linear(x, w, None, engine=1)
+    assert torch.equal(y0, y1)
+    with pytest.raises(RuntimeError, match="outside the bf16x3 engine"):
+        model.linear(x, w, None, engine=2)
+    with pytest.raises(RuntimeError):
+        model.linear(torch.randn((256, 40), device=dev()), torch.randn((128, 40), device=dev()), None)     # K % 32
+
+
+@pytest.mark.timeout(900)
+def test_network_on_either_engine():
+    """The demo-pair step at its real size (585 + 585 windows) on both engines: same matches, poses equal to 2e-5."""
+    W, V = 585, 22
+    sd = weights.synthetic_state_dict(1777, 1.0, "mixamo")
+    model = Generator(layout="mixamo", device=dev()).load_state_dict(sd).eval()
+    src = torch.from_numpy(synthetic.pose_windows(1777, W, V)).to(dev())
+    cha = torch.from_numpy(synthetic.pose_windows(1778, W, V)).to(dev())
+    mean, std = synthetic.cnt_norm(7)
+    outs = {}
+    for flag in (1, 0):
+        model.set_option("gemm_bf16x3", flag)
+        model.profile_start()
+        Y, idx = model.characterize_pair(src, cha, mean, std, return_index=True)
+        prof_names = set(model.profile_stop()["kernels"])
+        assert ("mocha_gemm_x3" in prof_names) == bool(flag), prof_names
+        outs[flag] = (Y.cpu().numpy(), idx.cpu().numpy())
+    model.set_option("gemm_bf16x3", 1)
+    assert np.array_equal(outs[1][1], outs[0][1]) or (outs[1][1] != outs[0][1]).mean() < 0.01
+    same = outs[1][1] == outs[0][1]
+    assert np.abs(outs[1][0][same] - outs[0][0][same]).max() < 2e-5
