@@ -80,6 +80,8 @@ struct AttnParams {
     int hsk = -1, hsv = -1;       // column offset per head of k / v (default dh; 0 = all heads share the same rows)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
+// the same on the bf16 matrix pipe with exact three-plane operands (attention_x3.hip): nq, nk <= 96, dh = 128 / 256
+hipError_t launch_attention_x3(const AttnParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Small bandwidth-bound kernels

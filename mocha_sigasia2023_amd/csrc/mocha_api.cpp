@@ -149,6 +149,7 @@ struct mocha_ctx {
     std::map<std::string, DevBuf> cws; int cvae_B = 0;
     // fp32 GEMMs on the bf16 matrix pipe (gemm_x3.hip): packed three-plane images of the weights, made on first use
     bool gemm_x3 = true;
+    bool attn_x3 = true;               // the Generator's attention as plane products on the bf16 pipe (attention_x3.hip)
     std::map<std::tuple<const float*, int, int>, unsigned short*> x3w;
     bool fold_decoder = true;          // decoder key / value projections folded into the query / output weights
     bool gather_pool = false;          // AvgPool(4) folded into the k=5 temporal conv's A gather instead of mocha_window_sums
@@ -424,6 +425,14 @@ int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
     LAUNCH(c, s, gemm_kernel_name(p), site, flops, bytes, launch_gemm(p, s));
     return 0;
 }
+// the Generator's attention (90 tokens, head dim 128 / 256): plane products on the bf16 pipe unless switched off
+const char* attn_kernel_name(const mocha_ctx* c, int DH) {
+    const bool x3 = c->attn_x3 && (DH == 128 || DH == 256);
+    return x3 ? (DH == 128 ? "mocha_attention_x3<128>" : "mocha_attention_x3<256>") : (DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>");
+}
+hipError_t attention(const mocha_ctx* c, const AttnParams& a, hipStream_t s) {
+    return (c->attn_x3 && (a.dh == 128 || a.dh == 256) && a.nq <= 96 && a.nk <= 96) ? launch_attention_x3(a, s) : launch_attention(a, s);
+}
 #define GEMM(c, s, site, p) do { int rc__ = gemm((c), (s), (site), (p)); if (rc__) return rc__; } while (0)
 
 GemmParams plain(const float* A, int lda, const float* Wt, float* C, int ldc, int M, int N, int K) {
@@ -514,8 +523,8 @@ int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStr
         GEMM(c, s, "enc.qkv", q);
         AttnParams a{WS(c, "qkv"), WS(c, "qkv") + inner, WS(c, "qkv") + 2 * inner, WS(c, "ao"),
                      3 * inner, 3 * inner, 3 * inner, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5)};
-        LAUNCH(c, s, DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>", "enc.attn", 4.0 * b * H * 90.0 * 90 * DH,
-               4.0 * M * 4 * inner, launch_attention(a, s));
+        LAUNCH(c, s, attn_kernel_name(c, DH), "enc.attn", 4.0 * b * H * 90.0 * 90 * DH,
+               4.0 * M * 4 * inner, attention(c, a, s));
         float* out = (l == c->cfg.enc_depth - 1) ? encoded : WS(c, "xa");
         int rc = run_out_ff(c, p, WS(c, "ao"), inner, x, M, c->cfg.enc_mlp, out, s);
         if (rc) return rc;
@@ -550,8 +559,8 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
             GemmParams gq = plain(WS(c, "qin"), 256, DW(c, p + ".Wqk"), qb, inner, M, inner, 256);
             GEMM(c, s, "dec.q", gq);
             AttnParams a{qb, WS(c, "kin"), cha, WS(c, "ao"), inner, 256, 256, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5), 0, 0};
-            LAUNCH(c, s, "mocha_attention_f32<256>", "dec.attn", 4.0 * b * H * 90.0 * 90 * DH, 4.0 * M * (2 * inner + 2 * 256),
-                   launch_attention(a, s));
+            LAUNCH(c, s, attn_kernel_name(c, DH), "dec.attn", 4.0 * b * H * 90.0 * 90 * DH, 4.0 * M * (2 * inner + 2 * 256),
+                   attention(c, a, s));
             float* out = (l == c->cfg.dec_depth - 1) ? outp : WS(c, "xa");
             int rc = run_out_ff(c, p, WS(c, "ao"), inner, WS(c, "xad"), M, c->cfg.dec_mlp, out, s, ".Wvo");
             if (rc) return rc;
@@ -565,8 +574,8 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
         GemmParams gv = plain(cha, 256, DW(c, p + ".Wv"), vb, inner, M, inner, 256);
         GEMM(c, s, "dec.v", gv);
         AttnParams a{qb, kb, vb, WS(c, "ao"), inner, inner, inner, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5)};
-        LAUNCH(c, s, DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>", "dec.attn", 4.0 * b * H * 90.0 * 90 * DH,
-               4.0 * M * 4 * inner, launch_attention(a, s));
+        LAUNCH(c, s, attn_kernel_name(c, DH), "dec.attn", 4.0 * b * H * 90.0 * 90 * DH,
+               4.0 * M * 4 * inner, attention(c, a, s));
         float* out = (l == c->cfg.dec_depth - 1) ? outp : WS(c, "xa");
         int rc = run_out_ff(c, p, WS(c, "ao"), inner, WS(c, "xad"), M, c->cfg.dec_mlp, out, s);
         if (rc) return rc;
@@ -1765,6 +1774,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "fuse_tail") { c->fuse_tail = value != 0; return 0; }
     if (n == "gather_pool") { c->gather_pool = value != 0; return 0; }
     if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; return 0; }
+    if (n == "attention_bf16x3") { c->attn_x3 = value != 0; return 0; }
     if (n == "fuse_tail_min_rows") { c->fuse_tail_min_rows = value < 1 ? 1 : value; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);
 }
