@@ -376,6 +376,7 @@ def main():
     exact_f32 = None
     if world == 1 and not a.no_extras:
         model.set_option("gemm_bf16x3", 0)
+        model.set_option("attention_bf16x3", 0)
         with torch.no_grad():
             for _ in range(a.warmup):
                 step()
@@ -386,8 +387,10 @@ def main():
             sync_all()
             e3 = time.perf_counter() - t0
         exact_f32 = {"value": W * a.steps / e3, "ms_per_step": e3 / a.steps * 1e3,
-                     "note": "same step with mocha_set_option(gemm_bf16x3=0): every GEMM on v_mfma_f32_32x32x2_f32 (gemm_f32.hip)"}
+                     "note": "same step with mocha_set_option(gemm_bf16x3=0, attention_bf16x3=0): every GEMM and the attention on "
+                             "v_mfma_f32_32x32x2_f32 (gemm_f32.hip, attention.hip)"}
         model.set_option("gemm_bf16x3", 1)
+        model.set_option("attention_bf16x3", 1)
 
     out = None
     if rank == 0:

@@ -243,7 +243,11 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * planes and six MFMA passes per product, fp32 accumulation (gemm_x3.hip): every bf16 x bf16 product is exact in fp32 and
  * the dropped cross terms are below 2^-26 of a product, so the result is as accurate as an fp32 FMA chain (measured against
  * float64: slightly more accurate than the exact-f32 MFMA kernel, tests/test_gemm_engines.py).  0 = every GEMM on
- * v_mfma_f32_32x32x2_f32 (gemm_f32.hip). */
+ * v_mfma_f32_32x32x2_f32 (gemm_f32.hip).
+ * "attention_bf16x3" (default 1): the Generator's attention (net/transformer.py:65-76; 90 tokens, head dim 128 / 256) computes
+ * QK^T and PV the same way - K, Q, V and the softmax probabilities as three bf16 planes each, six MFMA passes per product,
+ * fp32 accumulation and an fp32 softmax (attention_x3.hip); 0 = v_mfma_f32_32x32x2_f32 (attention.hip).  The CVAE sampler's
+ * attention (head dim 64) always uses attention.hip. */
 int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
 
 /* y (M,N) = x (M,K) · w (N,K)^T + bias (N, may be NULL): nn.Linear (net/transformer.py:28-32, 57-61) as a stand-alone

@@ -88,12 +88,34 @@ def test_network_on_either_engine():
     outs = {}
     for flag in (1, 0):
         model.set_option("gemm_bf16x3", flag)
+        model.set_option("attention_bf16x3", flag)
         model.profile_start()
         Y, idx = model.characterize_pair(src, cha, mean, std, return_index=True)
         prof_names = set(model.profile_stop()["kernels"])
         assert ("mocha_gemm_x3" in prof_names) == bool(flag), prof_names
+        assert ("mocha_attention_x3<128>" in prof_names) == bool(flag) and ("mocha_attention_f32<128>" in prof_names) != bool(flag), prof_names
         outs[flag] = (Y.cpu().numpy(), idx.cpu().numpy())
     model.set_option("gemm_bf16x3", 1)
+    model.set_option("attention_bf16x3", 1)
     assert np.array_equal(outs[1][1], outs[0][1]) or (outs[1][1] != outs[0][1]).mean() < 0.01
     same = outs[1][1] == outs[0][1]
     assert np.abs(outs[1][0][same] - outs[0][0][same]).max() < 2e-5
+
+
+@pytest.mark.parametrize("B", [1, 7, 40])
+def test_attention_on_either_engine(B):
+    """Encoder and decoder on small batches (exact-f32 GEMMs either way at these sizes): only the attention kernel differs.
+    Ragged batches exercise the padded workgroups of the XCD-aware grid."""
+    sd = weights.synthetic_state_dict(31, 1.0, "mocha")
+    model = Generator(layout="mocha", device=dev()).load_state_dict(sd).eval()
+    tok = torch.from_numpy(synthetic.token_features(5, B)).to(dev())
+    cha = torch.from_numpy(synthetic.token_features(6, B)).to(dev())
+    outs = {}
+    for flag in (1, 0):
+        model.set_option("attention_bf16x3", flag)
+        enc = model.encoder(tok)
+        outs[flag] = (enc.cpu().numpy(), model.decoder(enc, cha).cpu().numpy())
+    model.set_option("attention_bf16x3", 1)
+    for a, b in zip(outs[1], outs[0]):
+        scale = max(1.0, float(np.abs(b).max()))
+        assert np.abs(a - b).max() < 2e-5 * scale, (np.abs(a - b).max(), scale)
