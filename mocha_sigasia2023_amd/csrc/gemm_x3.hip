@@ -67,23 +67,27 @@ __device__ __forceinline__ void split4_rn(const f32x4 v, u32x2 (&out)[3]) {
     }
 }
 
-// W [N][K] fp32 -> packed planes.  One thread per (row, 8 consecutive k).
-__global__ void mocha_pack_x3(const float* __restrict__ W, int N, int K, unsigned short* __restrict__ out) {
+// W [N][K] fp32 -> packed planes.  One workgroup per (n tile, k step) block: thread = (row, k half) reads 32 bytes and writes one
+// 16-byte piece per plane, so every wave writes 512-byte runs of the 12 KB block (the image is written once per weight, but once per
+// call for the matcher's transient bank).  wsub (K values, may be null) is subtracted from every row first (centred bank).
+__global__ __launch_bounds__(256) void mocha_pack_x3(const float* __restrict__ W, const float* __restrict__ wsub, int N, int K, unsigned short* __restrict__ out) {
     const int ksteps = K / XK;
-    const long long total = (long long)((N + XN - 1) / XN) * XN * (K / 8);
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    const int k8 = (int)(t % (K / 8));
-    const int n = (int)(t / (K / 8));
+    const int nt = blockIdx.x / ksteps, ks = blockIdx.x - nt * ksteps;
+    const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
+    const int n = nt * XN + r;
+    const int k = ks * XK + 8 * h;
     f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
     if (n < N) {
-        lo = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k8 * 8);
-        hi = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k8 * 8 + 4);
+        lo = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k);
+        hi = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + k + 4);
+        if (wsub) {
+            lo -= *reinterpret_cast<const f32x4*>(wsub + k);
+            hi -= *reinterpret_cast<const f32x4*>(wsub + k + 4);
+        }
     }
     u32x2 a[3], b[3];
     split4_rn(lo, a); split4_rn(hi, b);
-    const int nt = n / XN, r = n % XN, ks = k8 >> 1, h = k8 & 1;
-    unsigned short* blk = out + ((size_t)nt * ksteps + ks) * XW_BLOCK;
+    unsigned short* blk = out + (size_t)blockIdx.x * XW_BLOCK;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const u32x4 v = {a[q][0], a[q][1], b[q][0], b[q][1]};
@@ -93,10 +97,11 @@ __global__ void mocha_pack_x3(const float* __restrict__ W, int N, int K, unsigne
 
 size_t gemm_x3_packed_elems(int N, int K) { return (size_t)((N + XN - 1) / XN) * (K / XK) * XW_BLOCK; }
 
-hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s) {
+hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s, const float* wsub) {
     if (K % XK != 0) return hipErrorInvalidValue;
-    const long long total = (long long)((N + XN - 1) / XN) * XN * (K / 8);
-    hipLaunchKernelGGL(mocha_pack_x3, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, W, N, K, out);
+    const long long blocks = (long long)((N + XN - 1) / XN) * (K / XK);
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_pack_x3, dim3((unsigned)blocks), dim3(256), 0, s, W, wsub, N, K, out);
     return hipGetLastError();
 }
 
@@ -125,7 +130,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     if (mt >= m_tiles) return;
     const int m0 = mt * XM, n0 = nt * XN;
-    const int nsteps = p.K / XK;
+    // K split over gridDim.z (the matcher's 23 040-long contraction): this workgroup takes steps s0 .. s0 + nsteps - 1 and writes raw
+    // partial sums to slab blockIdx.z; the host guarantees at least two steps per slab
+    const int steps_total = p.K / XK;
+    const int per = (steps_total + p.ksplit - 1) / p.ksplit;
+    const int s0 = blockIdx.z * per;
+    const int nsteps = (s0 + per) <= steps_total ? per : steps_total - s0;
 #ifdef X3_EXP_STAMPS       // diagnostic build (tools/): cycle stamps per workgroup into the buffer passed as p.wsub
     long long stamp[4];
     stamp[3] = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz, common to the chip
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
     f32x4 ra[2];
     auto load_a = [&](int s) __attribute__((always_inline)) {
-        const int k0 = s * XK;
+        const int k0 = (s0 + s) * XK;
         if (!GATHER) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) ra[i] = bload(rsA, a_off[i], (unsigned)k0 * 4u);
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     };
     // ---- W: linear copy of the packed 12 KB block of (nt, step) into the stage
-    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.Wsplit + (size_t)nt * nsteps * XW_BLOCK);
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.Wsplit + ((size_t)nt * steps_total + s0) * XW_BLOCK);
     auto dma_w = [&](int s, unsigned short* st) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
@@ -299,7 +309,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
     // ---- epilogue: as in gemm_f32.hip (acc[i][j] = C^T of MFMA tile (i, j): lane & 31 = row, regs 4g..4g+3 = 4 columns)
     const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) && ((p.N & 3) == 0);
-    const __amdgpu_buffer_rsrc_t rsC = make_rsrc(p.C + (size_t)m0 * p.ldc + n0);
+    float* Cz = p.C + (size_t)blockIdx.z * p.slab_stride;
+    const __amdgpu_buffer_rsrc_t rsC = make_rsrc(Cz + (size_t)m0 * p.ldc + n0);
     const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(p.bias ? p.bias + n0 : p.A);
     const __amdgpu_buffer_rsrc_t rsRb = make_rsrc(p.rowbias ? p.rowbias + n0 : p.A);
     const __amdgpu_buffer_rsrc_t rsRes = make_rsrc(p.residual ? p.residual + (size_t)m0 * p.ldr + n0 : p.A);
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         if (row >= p.M) continue;
         const float* rbrow = p.rowbias ? p.rowbias + (size_t)(row % p.rb_mod) * p.N : nullptr;
         const float* rsrow = p.residual ? p.residual + (size_t)row * p.ldr : nullptr;
-        float* crow = p.C + (size_t)row * p.ldc;
+        float* crow = Cz + (size_t)row * p.ldc;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -392,9 +403,16 @@ bool gemm_x3_supports(const GemmParams& p) {
 #ifndef X3_EXP_STAMPS
     if (p.wsub) return false;
 #endif
-    if (p.ksplit > 1 || p.K % XK != 0 || p.K < 2 * XK) return false;
-    if (p.N % XN != 0) return false;                // N = 64 / 192 (to_mot's joint block): a padded 128-wide tile loses to the exact-f32 128 x 64 tile (measured)
+    if (p.K % XK != 0 || p.K < 2 * XK) return false;
     if (p.gather && (p.R != 1 || p.Cc % XK != 0)) return false;
+    if (p.ksplit > 1) {
+        // raw partial sums (the matcher): no epilogue operands, every K slab at least two steps, the 2 GiB window of the weight image
+        if (p.bias || p.rowbias || p.residual || p.act || p.gather) return false;
+        const int total = p.K / XK, per = (total + p.ksplit - 1) / p.ksplit;
+        if (total - (p.ksplit - 1) * per < 2) return false;
+        return (long long)total * XW_BLOCK * 2 < (1ll << 31);
+    }
+    if (p.N % XN != 0) return false;                // N = 64 / 192 (to_mot's joint block): a padded 128-wide tile loses to the exact-f32 128 x 64 tile (measured)
     if (gemm_is_skinny(p) || gemm_is_small(p)) return false;
     return true;
 }
@@ -406,7 +424,7 @@ hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
     if (128ll * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     const int m_tiles = (p.M + XM - 1) / XM;
     const int m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
-    const dim3 grid(m_pad * ((p.N + XN - 1) / XN));
+    const dim3 grid(m_pad * ((p.N + XN - 1) / XN), 1, p.ksplit > 1 ? p.ksplit : 1);
     if (p.a_lrelu) {
         if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3<true, true>), grid, dim3(256), x3_lds_bytes(), s, p);
         else hipLaunchKernelGGL((mocha_gemm_x3<true, false>), grid, dim3(256), x3_lds_bytes(), s, p);

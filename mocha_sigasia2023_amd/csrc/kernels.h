@@ -51,7 +51,7 @@ hipError_t gemm_init();           // one-time function attributes (dynamic LDS s
 hipError_t gemm_x3_init();
 bool gemm_x3_supports(const GemmParams& p);
 size_t gemm_x3_packed_elems(int N, int K);
-hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s);
+hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s, const float* wsub = nullptr);   // wsub: K values subtracted from every row
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------

@@ -157,6 +157,8 @@ struct mocha_ctx {
     int* bone_parents = nullptr;       // device: parents of the (V+1)-bone skeleton with the root bone in front
     float* pose_norm = nullptr;        // [x_mean | x_std | y_mean | y_std], (V+1)*C_in each (norm.npz of the reference)
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
+    // fp32 banks of up to X3_BANK_MAX rows also keep the plane engine's packed image of the centred bank (many-query matching)
+    unsigned short* bank_x3 = nullptr; size_t bank_x3_cap = 0; bool bank_x3_valid = false;
     unsigned long long* best_ws[2] = {nullptr, nullptr}; size_t best_ws_n[2] = {0, 0};
     unsigned long long* topk_keys = nullptr; size_t topk_keys_n = 0;       // every row's key of up to 8 queries (mocha_match_topk)
 
@@ -667,6 +669,8 @@ int grow(mocha_ctx* c, DevBuf& b, size_t need) {
     return 0;
 }
 
+static constexpr int64_t X3_BANK_MAX = 2048;       // rows: the packed image of a 2048-row bank is 283 MB
+
 // split of the many-query GEMM's K loop over gridDim.z so that a launch has about three tiles per CU
 int match_ksplit(int Q, int64_t N) {
     const long long tiles = (long long)((Q + 127) / 128) * ((N + 127) / 128);
@@ -740,8 +744,14 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     const int ksplit = match_ksplit(Q, N);
     GemmParams g = plain(qc, D, c->bank_cnt, mS.p, (int)N, Q, (int)N, D);
     g.ksplit = ksplit; g.slab_stride = (long long)Q * N;
-    g.wsub = c->bank_center;
-    GEMM(c, s, "match.qk", g);
+    if (c->bank_x3_valid && c->gemm_x3 && gemm_x3_supports(g)) {
+        g.Wsplit = c->bank_x3;                          // the centred bank as planes (bank_set_impl); same coarse-score accuracy as below
+        LAUNCH(c, s, "mocha_gemm_x3", "match.qk", 2.0 * Q * (double)N * D, 4.0 * ((double)Q * D + (double)Q * N * ksplit) + 6.0 * N * D,
+               launch_gemm_x3(g, s));
+    } else {
+        g.wsub = c->bank_center;
+        GEMM(c, s, "match.qk", g);
+    }
     // exact-f32 MFMA on centred operands: a coarse score is accurate to ~4e-7 (||q-c||^2 + ||b-c||^2); candidates within ten
     // times that of the best are re-evaluated in the direct form
     LAUNCH(c, s, "mocha_match_select", "match.select", 0.0, 4.0 * ksplit * Q * N + Q * 16.0 * D,
@@ -801,6 +811,7 @@ void mocha_destroy(mocha_ctx* c) {
     for (float* p : c->owned) (void)hipFree(p);
     for (int set = 0; set < 2; ++set) { if (c->idx_ws[set]) (void)hipFree(c->idx_ws[set]); if (c->best_ws[set]) (void)hipFree(c->best_ws[set]); }
     if (c->bank_bf16) (void)hipFree(c->bank_bf16);
+    if (c->bank_x3) (void)hipFree(c->bank_x3);
     if (c->topk_keys) (void)hipFree(c->topk_keys);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1111,6 +1122,19 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
         LAUNCH(c, s, "mocha_rownorm2_bf16", "bank.norms", 2.0 * N * D, 2.0 * N * D, launch_rownorm2_bf16(c->bank_bf16, c->bank_norm, N, (int)D, s));
     } else {
         LAUNCH(c, s, "mocha_rownorm2", "bank.norms", 2.0 * N * D, 4.0 * N * D, launch_rownorm2(c->bank_cnt, c->bank_center, c->bank_norm, N, (int)D, s));
+    }
+    // many-query matching against a small fp32 bank runs on the plane engine: centred bank as its packed image (6 B per value)
+    c->bank_x3_valid = false;
+    if (!c->bank_is_bf16 && c->gemm_x3 && N <= X3_BANK_MAX) {
+        const size_t need = gemm_x3_packed_elems((int)N, (int)D);
+        if (c->bank_x3_cap < need) {
+            if (c->bank_x3) (void)hipFree(c->bank_x3);
+            c->bank_x3 = nullptr; c->bank_x3_cap = 0;
+            HIPCHK(c, hipMalloc((void**)&c->bank_x3, need * sizeof(unsigned short)));
+            c->bank_x3_cap = need;
+        }
+        LAUNCH(c, s, "mocha_pack_x3", "bank.pack_x3", 0.0, 10.0 * N * D, launch_pack_x3(c->bank_cnt, (int)N, (int)D, c->bank_x3, s, c->bank_center));
+        c->bank_x3_valid = true;
     }
     return 0;
 }
