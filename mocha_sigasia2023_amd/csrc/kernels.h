@@ -91,7 +91,7 @@ hipError_t launch_attention_x3(const AttnParams& p, hipStream_t s);
 // raw_root = 1: X frames are (V+1, Cin) with the root bone first and are z-scored with xmean/xstd ((V+1)*Cin) on load
 hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP /*3*V*6*/,
                               float* out, int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root,
-                              hipStream_t s);
+                              hipStream_t s, bool planes = false);      // planes: both contractions as plane products on the bf16 pipe
 // rows (b,t,p) x 256 -> LeakyReLU -> body-part adjacency (2 hops) -> rows (b,t,w) x (k*256+c)
 hipError_t launch_body_front(const float* x, const float* A_b /*2*6*6*/, float* out, int rows6 /*B*15*/, hipStream_t s);
 // g rows (b,t',p) x (k*64+c) -> y2c rows (b,t',w) x 64 : sum_k sum_p AU[k][p][w] g[...]

@@ -453,13 +453,14 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     const int nn = (V + 1) * c->cfg.C_in;
     if (raw && !c->pose_norm) return fail(c, MOCHA_ERR_STATE, "raw input needs mocha_set_pose_norm first");
     // conv1 + lrelu + adjacency + joint->part pool (commuted)                  model.py:44-46
-    LAUNCH(c, s, "mocha_embed_front", "emb.front", b * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b * 60.0 * (V * 15 + 6 * 192) * 4,
+    const char* efk = c->gemm_x3 ? "mocha_embed_front_x3" : "mocha_embed_front";
+    LAUNCH(c, s, efk, "emb.front", b * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b * 60.0 * (V * 15 + 6 * 192) * 4,
            launch_embed_front(X, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar"), b * 60, V, c->cfg.C_in,
-                              raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s));
+                              raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s, c->gemm_x3));
     if (X2 && b2 > 0) {
-        LAUNCH(c, s, "mocha_embed_front", "emb.front", b2 * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b2 * 60.0 * (V * 15 + 6 * 192) * 4,
+        LAUNCH(c, s, efk, "emb.front", b2 * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b2 * 60.0 * (V * 15 + 6 * 192) * 4,
                launch_embed_front(X2, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar") + (size_t)b * 360 * 192, b2 * 60, V,
-                                  c->cfg.C_in, raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s));
+                                  c->cfg.C_in, raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s, c->gemm_x3));
         b += b2;
     }
     // gcn 1x1 conv on the pooled operand: (b*360, 192) x (256,192)^T + pooled bias

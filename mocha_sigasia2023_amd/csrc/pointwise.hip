@@ -125,13 +125,160 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// embed_front on the bf16 matrix pipe: the same two chained contractions as plane products (gemm_x3.hip: every fp32 operand as three
+// exact bf16 planes, six v_mfma_f32_32x32x16_bf16 passes per product, fp32 accumulate).  The first contraction's K (16 padded
+// features) is ONE MFMA k step, the second's (32 padded joints) two: 36 MFMAs of 32 cycles per frame instead of 48 of 64.  W1 and AP'
+// are per-lane plane constants; the frame's features are split after the LDS read; the accumulator h (lane = channel, registers =
+// joints) is split in registers - registers 8j..8j+7 are, for lane half h, the joints 16j + 8(e>>2) + 4h + (e&3), one B operand
+// of a K = 16 MFMA in that joint order (as P^T in attention_x3.hip), and AP' is held in the same order.
+// ---------------------------------------------------------------------------------------
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned ef_cvt_pk(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));       // v_cvt_pk_bf16_f32
+}
+// eight floats -> three planes of eight bf16
+__device__ __forceinline__ void ef_split8(const float (&x)[8], s16x8 (&out)[3]) {
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = x[e];
+    unsigned w[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned pk = ef_cvt_pk(r[2 * e], r[2 * e + 1]);
+            w[q][e] = pk;
+            if (q < 2) { r[2 * e] -= __uint_as_float(pk << 16); r[2 * e + 1] -= __uint_as_float(pk & 0xffff0000u); }
+        }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const u32x4 v = {w[q][0], w[q][1], w[q][2], w[q][3]};
+        out[q] = __builtin_bit_cast(s16x8, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restrict__ X, const float* __restrict__ W1,
+                                                            const float* __restrict__ b1, const float* __restrict__ AP,
+                                                            float* __restrict__ out, int nframes, int V, int Cin,
+                                                            const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
+    __shared__ __attribute__((aligned(16))) float xs_all[4][32 * 20];       // rows of 20 floats: conflict-free b128 row reads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    float* xs = xs_all[wave];
+
+    // ---- per-lane plane constants
+    s16x8 wpl[2][3], apl[2][3];
+    float bias[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int c = t * 32 + l31;
+        bias[t] = b1[c];
+        float w8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int feat = 8 * hh + e; w8[e] = feat < Cin ? W1[c * Cin + feat] : 0.f; }
+        ef_split8(w8, wpl[t]);
+    }
+    {
+        const int pk = l31, pp = pk / 3, kk = pk - pp * 3;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float a8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int joint = 16 * j + 8 * (e >> 2) + 4 * hh + (e & 3);
+                a8[e] = (pk < 18 && joint < V) ? AP[(kk * V + joint) * 6 + pp] : 0.f;
+            }
+            ef_split8(a8, apl[j]);
+        }
+    }
+    // staging map of this lane's (at most 8) elements of a frame: element e = lane + 64 i -> joint e / Cin, feature e % Cin
+    const int nelem = V * Cin;
+    int slot[8];
+    float zm[8], zs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = lane + 64 * i;
+        const int v = e / Cin, ci = e - v * Cin;
+        slot[i] = e < nelem ? v * 20 + ci : -1;
+        zm[i] = (xmean && e < nelem) ? xmean[raw_root * Cin + e] : 0.f;
+        zs[i] = (xmean && e < nelem) ? xstd[raw_root * Cin + e] : 1.f;
+    }
+    for (int i = lane; i < 32 * 20; i += 64) xs[i] = 0.f;          // padding joints / the padding feature stay zero
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};      // low-order products first
+    const int stride = gridDim.x * 4;
+    int frame = blockIdx.x * 4 + wave;
+    float xr[8];
+    auto fetch = [&](int f) __attribute__((always_inline)) {
+        const float* xf = X + (size_t)f * (V + raw_root) * Cin + raw_root * Cin;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr[i] = slot[i] >= 0 ? xf[lane + 64 * i] : 0.f;
+    };
+    if (frame < nframes) fetch(frame);
+    for (; frame < nframes; frame += stride) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (slot[i] >= 0) xs[slot[i]] = xmean ? (xr[i] - zm[i]) / zs[i] : xr[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xs + l31 * 20 + hh * 8);
+        const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xs + l31 * 20 + hh * 8 + 4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (frame + stride < nframes) fetch(frame + stride);       // next frame's loads fly under this frame's MFMAs
+        const float xa[8] = {xa0[0], xa0[1], xa0[2], xa0[3], xa1[0], xa1[1], xa1[2], xa1[3]};
+        s16x8 xpl[3];
+        ef_split8(xa, xpl);
+        float* of = out + (size_t)frame * 18 * 64;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) h[r] = 0.f;
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xpl[PA[pr]], wpl[t][PB[pr]], h, 0, 0, 0);
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float h8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h8[e] = lrelu02(h[8 * j + e] + bias[t]);
+                s16x8 hpl[3];
+                ef_split8(h8, hpl);
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apl[j][PA[pr]], hpl[PB[pr]], o, 0, 0, 0);
+            }
+            // o[r] = out[pk = (r&3) + 8 (r>>2) + 4 hh][channel t*32 + l31]; rows 18..31 are padding
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+                const int pk = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (pk < 18) of[pk * 64 + t * 32 + l31] = o[r];
+            }
+        }
+    }
+}
+
 hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP, float* out,
-                              int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root, hipStream_t s) {
+                              int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root, hipStream_t s, bool planes) {
     if (nframes <= 0) return hipSuccess;
     if (V > 32 || Cin > 16 || V * Cin > 512) return hipErrorInvalidValue;
     const int wgs = (nframes + 3) / 4;
-    hipLaunchKernelGGL(mocha_embed_front, dim3(wgs < 2048 ? wgs : 2048), dim3(256), 0, s, X, W1, b1, AP, out,
-                       nframes, V, Cin, xmean, xstd, raw_root);
+    if (planes)
+        hipLaunchKernelGGL(mocha_embed_front_x3, dim3(wgs < 2048 ? wgs : 2048), dim3(256), 0, s, X, W1, b1, AP, out,
+                           nframes, V, Cin, xmean, xstd, raw_root);
+    else
+        hipLaunchKernelGGL(mocha_embed_front, dim3(wgs < 2048 ? wgs : 2048), dim3(256), 0, s, X, W1, b1, AP, out,
+                           nframes, V, Cin, xmean, xstd, raw_root);
     return hipGetLastError();
 }
 
