@@ -670,7 +670,7 @@ int grow(mocha_ctx* c, DevBuf& b, size_t need) {
     return 0;
 }
 
-static constexpr int64_t X3_BANK_MAX = 2048;       // rows: the packed image of a 2048-row bank is 283 MB
+static constexpr int64_t X3_BANK_MAX = 4096;       // rows: the packed image of a 4096-row bank (BASELINE configs[2]) is 566 MB
 
 // split of the many-query GEMM's K loop over gridDim.z so that a launch has about three tiles per CU
 int match_ksplit(int Q, int64_t N) {
