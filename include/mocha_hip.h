@@ -102,7 +102,9 @@ int mocha_forward_features(mocha_ctx* ctx, const float* src_X, const float* cha_
 #define MOCHA_BANK_BORROW 1
 /* flags bit 1: additionally keep a bf16 copy of cnt_nm (round-to-nearest-even) and match against it
  * (half the HBM bytes per bank scan; BASELINE configs[2]); indices then agree with the fp32 search
- * except where the two nearest distances differ by less than the bf16 rounding of the bank. */
+ * except where the two nearest distances differ by less than the bf16 rounding of the bank.
+ * fp32 banks of up to 4096 rows additionally keep the packed three-plane image of the centred bank (6 bytes per value, made by
+ * mocha_bank_set) that many-query matching multiplies on the bf16 pipe when "gemm_bf16x3" is on - exact planes, the same indices. */
 #define MOCHA_BANK_BF16 2
 int mocha_bank_set(mocha_ctx* ctx, const float* cnt_nm, const float* encoded, int64_t N, int flags, void* stream);
 /* tree.query(q, k=1), test_fullframework.py:296,443: exact Euclidean 1-NN of each z-scored
