@@ -1,11 +1,13 @@
 // fp32 GEMM on the bf16 matrix pipe of gfx950: C = epilogue(Aop · W^T) with both operands carried as three bf16 planes.
 //
-//   x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)       (round to nearest even; |x - x0 - x1 - x2| <= 2^-27 |x|)
-//   a·b = a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0) + (terms <= 2^-26 |ab|)
+//   x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)       (round to nearest even; exact for practically every
+//                                                                                       fp32 value, residual <= 2^-24 |x| otherwise)
+//   a·b = a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0) + (terms <= 2^-24 |ab|)
 //
-// Six v_mfma_f32_32x32x16_bf16 (fp32 accumulate, every bf16 x bf16 product exact in fp32) reproduce the fp32 product to
-// 2^-26 relative - below the 2^-24 rounding of the fp32 accumulation itself, which is the same as in the exact-f32 kernel of
-// gemm_f32.hip.  The bf16 pipe runs 16x the fp32 MFMA rate, so six passes cost 0.375 of one v_mfma_f32_32x32x2_f32 pass.
+// Six v_mfma_f32_32x32x16_bf16 (fp32 accumulate, every bf16 x bf16 product exact in fp32) reproduce the fp32 product to the rounding
+// of ONE fp32 operation (tests/test_plane_split_numerics.py) - far below what the fp32 accumulation of a K-long dot product rounds
+// away, which is the same as in the exact-f32 kernel of gemm_f32.hip; measured against float64 the result is slightly MORE accurate
+// than that kernel's (tests/test_gemm_engines.py).  The bf16 pipe runs 16x the fp32 MFMA rate, so six passes cost 0.375 of one v_mfma_f32_32x32x2_f32 pass.
 //
 // Structure:
 //   * 128 x 128 tile per 256-thread workgroup, four waves of 64 x 64; K step 16 (one MFMA k): per step and wave 12 ds_read_b128
@@ -14,11 +16,14 @@
 //     12 KB per (tile, step), fetched straight into LDS by three buffer_load ... lds per thread (no VGPR staging, no ds_write).
 //   * Activations stay fp32 in HBM (plain rows, or the temporal-conv gather of kernels.h); a thread fetches two 16-byte pieces per
 //     step, splits them into the three planes (v_cvt_pk_bf16_f32 + a subtraction per level) and writes them with ds_write_b64.
-//     The fetch of step s + 2 is issued as soon as step s + 1's registers have been split, so it has a whole step to land.
-//   * Two LDS stages of 24.8 KB, one barrier per step: while step s is multiplied, step s + 1 is written into the other stage.
-//     49.5 KB per workgroup -> three workgroups per CU cover each other's prologues, barriers and epilogues.
-//   * LDS image per plane: [k half][row][8 bf16] - the 16 lanes a ds_read_b128 serves together read 256 contiguous bytes;
-//     the A halves are 128 bytes further apart than 2 KB so that the b64 writes of a 32-lane group cover all banks once.
+//     The split of step s + 1 is interleaved by hand with the MFMAs of step s (two VALU instructions per MFMA, fenced), the fetch of
+//     step s + 2 is issued once step s + 1's registers are free, so it has a whole step to land.
+//   * Two LDS stages of 25.5 KB, one barrier per step: while step s is multiplied, step s + 1 is written into the other stage.
+//     51 KB per workgroup -> three workgroups per CU cover each other's prologues, barriers and epilogues.
+//   * LDS image per plane (both operands): [k half][row][8 bf16] - the 16 lanes a ds_read_b128 serves together read 256 contiguous
+//     bytes; the halves are 64 bytes further apart than 2 KB so that the b64 plane stores of a 16-lane group (banked mod 32 dwords)
+//     cover all banks once.
+//   * K split over gridDim.z with raw partial sums per slab (the matcher's 23 040-long contraction).
 //   * Operands swapped as in gemm_f32.hip (C^T accumulators), same epilogue: transposition through LDS, whole-line stores.
 #include "kernels.h"
 #include "device_utils.h"
