@@ -2,7 +2,7 @@
 // (reference: Attention.forward, net/transformer.py:65-76; same interface and results as attention.hip).
 //
 // Both contractions run as plane products (gemm_x3.hip): every fp32 operand is the exact sum of three bf16 values, six
-// v_mfma_f32_32x32x16_bf16 passes (fp32 accumulate) reproduce the fp32 product to 2^-26 - 6/16 of the fp32 MFMA's cycles.
+// v_mfma_f32_32x32x16_bf16 passes (fp32 accumulate) reproduce the fp32 product to within one fp32 rounding - at 6/16 of the fp32 MFMA's cycles.
 //
 // One workgroup of three waves per (window, head); wave w owns query block 32w..32w+31, keys are padded to 96.
 //   1. S^T = K · Q^T, head dim in chunks of 32: a thread fetches four 16-byte pieces of K and of Q one chunk ahead, splits them
