@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             a_off[i] = ((unsigned)(m - m0) * (unsigned)p.lda + lc * 4) * 4u;
         }
     }
-    f32x4 ra[2];
-    auto load_a = [&](int s) __attribute__((always_inline)) {
+    f32x4 rset[2][2];                               // step t's activations wait in set t & 1, fetched two steps ahead
+    auto load_a = [&](int s, f32x4 (&ra)[2]) __attribute__((always_inline)) {
         const int k0 = (s0 + s) * XK;
         if (!GATHER) {
 #pragma unroll
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     };
     // plane q of (row, piece lc): k half lc >> 1, 8 bytes at (lc & 1)
     const int a_wr = (lc >> 1) * XA_HALF + lrow * 8 + (lc & 1) * 4;
-    auto split_store = [&](unsigned short* st) __attribute__((always_inline)) {
+    auto split_store = [&](const f32x4 (&ra)[2], unsigned short* st) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             f32x4 v = ra[i];
@@ -231,24 +231,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
     // prologue: step 0 into stage 0, step 1's activations into registers.  The counted waits below (and in the steps) rely on the
     // issue order of the copies relative to the register fetches; both are independent loads to the scheduler, so they are fenced.
-    load_a(0);
+    load_a(0, rset[0]);
     __builtin_amdgcn_sched_barrier(0);
     dma_w(0, x3_sm);
     __builtin_amdgcn_sched_barrier(0);
-    split_store(x3_sm);
-    load_a(1);                                      // K >= 32 (gemm_x3_supports)
+    split_store(rset[0], x3_sm);
+    load_a(1, rset[1]);                             // K >= 32 (gemm_x3_supports)
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // One K step.  FETCH_W: step s + 1 exists (its weights are copied and its activations split into the other stage);
     // FETCH_A: step s + 2 exists (its activations are fetched).  The three variants are straight-line code, so the compiler's own
     // vmcnt bookkeeping for the activation registers is exact: the split waits for the two oldest fetches only, not for the copy.
-    auto step = [&](int s, auto fetch_w, auto fetch_a) __attribute__((always_inline)) {
+    auto step = [&](int s, auto parity, auto fetch_w, auto fetch_a) __attribute__((always_inline)) {
         constexpr bool FETCH_W = decltype(fetch_w)::value, FETCH_A = decltype(fetch_a)::value;
-        unsigned short* cur = x3_sm + (s & 1) * X_STAGE;
-        unsigned short* nxt = x3_sm + ((s & 1) ^ 1) * X_STAGE;
+        constexpr int P = decltype(parity)::value;      // s & 1
+        unsigned short* cur = x3_sm + P * X_STAGE;
+        unsigned short* nxt = x3_sm + (P ^ 1) * X_STAGE;
         if (FETCH_W) dma_w(s + 1, nxt);             // first thing after the barrier: a whole step to land
         __builtin_amdgcn_sched_barrier(0);          // ... and older than this step's register fetches (counted wait at the end)
+        // step s + 2's activations into the set step s's came from (split during step s - 1): a whole step to land, not the
+        // few MFMAs left when the fetch waited for step s + 1's registers to be free (the latency was exposed on every step)
+        if (FETCH_A) load_a(s + 2, rset[P]);
+        __builtin_amdgcn_sched_barrier(0);
         s16x8 a[3][2], b[3][2];
         auto rd_a = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         unsigned pk[4][3], hi[4][2];
         if (FETCH_W) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { x[e] = ra[e >> 2][e & 3]; if (LRELU) x[e] = fmaxf(x[e], 0.2f * x[e]); }
+            for (int e = 0; e < 8; ++e) { x[e] = rset[P ^ 1][e >> 2][e & 3]; if (LRELU) x[e] = fmaxf(x[e], 0.2f * x[e]); }
         }
         auto split_op = [&](int k) __attribute__((always_inline)) {     // op k of 44: pair k / 11 (two values), step k % 11
             const int pr = k / 11, o = k % 11, lvl = o / 5;
@@ -297,7 +302,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             if (FETCH_W && m < 22) { split_op(2 * m); split_op(2 * m + 1); }
             if (FETCH_W && m == 10) write_row(0);
             if (FETCH_W && m == 21) write_row(1);
-            if (FETCH_A && m == 22) load_a(s + 2);
             __builtin_amdgcn_sched_barrier(0);
         }
         // the weights of step s + 1 have landed and this wave's plane writes are done; step s + 2's activations stay in flight
@@ -307,9 +311,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     };
     X3_STAMP(1);
     using T = std::true_type; using F = std::false_type;
-    for (int s = 0; s + 2 < nsteps; ++s) step(s, T{}, T{});
-    step(nsteps - 2, T{}, F{});
-    step(nsteps - 1, F{}, F{});
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+    for (int s = 0; s + 2 < nsteps; s += 2) {           // an even number of steps (gemm_x3_supports)
+        step(s, P0{}, T{}, T{});
+        step(s + 1, P1{}, T{}, T{});
+    }
+    step(nsteps - 2, P0{}, T{}, F{});
+    step(nsteps - 1, P1{}, F{}, F{});
     X3_STAMP(2);
 
     // ---- epilogue: as in gemm_f32.hip (acc[i][j] = C^T of MFMA tile (i, j): lane & 31 = row, regs 4g..4g+3 = 4 columns)
@@ -408,13 +416,13 @@ bool gemm_x3_supports(const GemmParams& p) {
 #ifndef X3_EXP_STAMPS
     if (p.wsub) return false;
 #endif
-    if (p.K % XK != 0 || p.K < 2 * XK) return false;
+    if (p.K % (2 * XK) != 0) return false;          // an even number of K steps (the register sets alternate)
     if (p.gather && (p.R != 1 || p.Cc % XK != 0)) return false;
     if (p.ksplit > 1) {
         // raw partial sums (the matcher): no epilogue operands, every K slab at least two steps, the 2 GiB window of the weight image
         if (p.bias || p.rowbias || p.residual || p.act || p.gather) return false;
         const int total = p.K / XK, per = (total + p.ksplit - 1) / p.ksplit;
-        if (total - (p.ksplit - 1) * per < 2) return false;
+        if ((per & 1) || total - (p.ksplit - 1) * per < 2 || ((total - (p.ksplit - 1) * per) & 1)) return false;   // every slab: an even number of steps, at least two
         return (long long)total * XW_BLOCK * 2 < (1ll << 31);
     }
     if (p.N % XN != 0) return false;                // N = 64 / 192 (to_mot's joint block): a padded 128-wide tile loses to the exact-f32 128 x 64 tile (measured)
