@@ -745,18 +745,26 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     const int ksplit = match_ksplit(Q, N);
     GemmParams g = plain(qc, D, c->bank_cnt, mS.p, (int)N, Q, (int)N, D);
     g.ksplit = ksplit; g.slab_stride = (long long)Q * N;
+    if (c->bank_x3_valid && c->gemm_x3) {
+        // the plane engine wants an even number of K steps in every slab: the largest split <= ksplit that divides 23040 / 32
+        int kx = ksplit;
+        while (kx > 1 && (D / 32) % kx != 0) --kx;
+        g.ksplit = kx;
+    }
     if (c->bank_x3_valid && c->gemm_x3 && gemm_x3_supports(g)) {
         g.Wsplit = c->bank_x3;                          // the centred bank as planes (bank_set_impl); same coarse-score accuracy as below
-        LAUNCH(c, s, "mocha_gemm_x3", "match.qk", 2.0 * Q * (double)N * D, 4.0 * ((double)Q * D + (double)Q * N * ksplit) + 6.0 * N * D,
+        LAUNCH(c, s, "mocha_gemm_x3", "match.qk", 2.0 * Q * (double)N * D, 4.0 * ((double)Q * D + (double)Q * N * g.ksplit) + 6.0 * N * D,
                launch_gemm_x3(g, s));
     } else {
+        g.ksplit = ksplit;
         g.wsub = c->bank_center;
         GEMM(c, s, "match.qk", g);
     }
+    const int nslab = g.ksplit;
     // exact-f32 MFMA on centred operands: a coarse score is accurate to ~4e-7 (||q-c||^2 + ||b-c||^2); candidates within ten
     // times that of the best are re-evaluated in the direct form
-    LAUNCH(c, s, "mocha_match_select", "match.select", 0.0, 4.0 * ksplit * Q * N + Q * 16.0 * D,
-           launch_match_select(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, c->bank_cnt, nullptr, 4e-6f,
+    LAUNCH(c, s, "mocha_match_select", "match.select", 0.0, 4.0 * nslab * Q * N + Q * 16.0 * D,
+           launch_match_select(mS.p, nslab, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, c->bank_cnt, nullptr, 4e-6f,
                                Q, N, D, idx, dist, s));
     return 0;
 }
