@@ -21,10 +21,8 @@ namespace mocha {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -34,24 +32,6 @@ static constexpr int AX_PLANE = 4 * AX_BLK;              // a 32-wide chunk: 2 k
 static constexpr int AX_OPER = 3 * AX_PLANE;             // K or Q chunk, three planes: 9408 bf16
 static constexpr int AX_VPLANE = AX_ROWS * 64;           // V pass plane: [key][64 dims]
 static constexpr int AX_LDS = 2 * AX_OPER > 3 * AX_VPLANE ? 2 * AX_OPER : 3 * AX_VPLANE;     // 18 816 bf16 = 37 632 B
-
-__device__ __forceinline__ unsigned ax_cvt_pk(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));       // v_cvt_pk_bf16_f32
-}
-// four floats -> three planes of four bf16
-__device__ __forceinline__ void ax_split4(const f32x4 v, u32x2 (&out)[3]) {
-    float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const unsigned p01 = ax_cvt_pk(r0, r1), p23 = ax_cvt_pk(r2, r3);
-        out[q][0] = p01; out[q][1] = p23;
-        if (q < 2) {
-            r0 -= __uint_as_float(p01 << 16); r1 -= __uint_as_float(p01 & 0xffff0000u);
-            r2 -= __uint_as_float(p23 << 16); r3 -= __uint_as_float(p23 & 0xffff0000u);
-        }
-    }
-}
 
 template <int DH>
 __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) void mocha_attention_x3(AttnParams p) {
@@ -108,8 +88,8 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x2 pk[3], pq[3];
-            ax_split4(kr[i], pk);
-            ax_split4(qr[i], pq);
+            plane_split4(kr[i], pk);
+            plane_split4(qr[i], pq);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 *reinterpret_cast<u32x2*>(Ks + q * AX_PLANE + st_off[i]) = pk[q];
@@ -117,7 +97,6 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         }
     };
-    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};        // low-order products first, a0·b0 last
     fetch_kq(0);
     stage_kq();
     __syncthreads();
@@ -137,7 +116,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int pr = 0; pr < 6; ++pr)
 #pragma unroll
                 for (int t = 0; t < NKT; ++t)
-                    st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[pr]][t], bq[PB[pr]], st[t], 0, 0, 0);
+                    st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PLANE_PA[pr]][t], bq[PLANE_PB[pr]], st[t], 0, 0, 0);
         }
         __syncthreads();
         if (c + 1 < DH / 32) stage_kq();
@@ -179,7 +158,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const f32x4 lo = {st[t][8 * j] * inv, st[t][8 * j + 1] * inv, st[t][8 * j + 2] * inv, st[t][8 * j + 3] * inv};
             const f32x4 hi = {st[t][8 * j + 4] * inv, st[t][8 * j + 5] * inv, st[t][8 * j + 6] * inv, st[t][8 * j + 7] * inv};
             u32x2 a[3], b2[3];
-            ax_split4(lo, a); ax_split4(hi, b2);
+            plane_split4(lo, a); plane_split4(hi, b2);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const u32x4 v = {a[q][0], a[q][1], b2[q][0], b2[q][1]};
@@ -210,7 +189,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             u32x2 pv[3];
-            ax_split4(vr[i], pv);
+            plane_split4(vr[i], pv);
 #pragma unroll
             for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(Vs + q * AX_VPLANE + vs_off[i]) = pv[q];
         }
@@ -244,7 +223,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     }
 #pragma unroll
                     for (int pr = 0; pr < 6; ++pr)
-                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[pr]], pp[t][j][PB[pr]], o[d], 0, 0, 0);
+                        o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PLANE_PA[pr]], pp[t][j][PLANE_PB[pr]], o[d], 0, 0, 0);
                 }
         // o[d][r] = O[query][dcol = dp*64 + d*32 + (r&3) + 8(r>>2) + 4hh]: regs 4g..4g+3 are 4 consecutive dims
         if (query < nq) {

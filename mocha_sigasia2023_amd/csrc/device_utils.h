@@ -44,4 +44,47 @@ __device__ __forceinline__ float mocha_erf(float a) {
     return t > 0.927734375f ? big : small;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Plane split (gemm_x3.hip, attention_x3.hip, pointwise.hip): x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0),
+// x2 = bf16(x - x0 - x1), round to nearest even (v_cvt_pk_bf16_f32).  Exact for practically every fp32 value, residual <= 2^-24 |x|
+// otherwise; bf16 x bf16 products are exact in fp32, so six MFMA passes reproduce an fp32 product to within one fp32 rounding
+// (tests/test_plane_split_numerics.py).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));       // low half = bf16(a)
+}
+// four floats -> three planes of four bf16 (8 bytes each)
+__device__ __forceinline__ void plane_split4(const f32x4_t v, u32x2_t (&out)[3]) {
+    float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const unsigned p01 = cvt_pk_bf16(r0, r1), p23 = cvt_pk_bf16(r2, r3);
+        out[q][0] = p01; out[q][1] = p23;
+        if (q < 2) {
+            r0 -= __uint_as_float(p01 << 16); r1 -= __uint_as_float(p01 & 0xffff0000u);
+            r2 -= __uint_as_float(p23 << 16); r3 -= __uint_as_float(p23 & 0xffff0000u);
+        }
+    }
+}
+// eight floats -> three planes of eight bf16: one MFMA operand (K = 16, this lane's k half) per plane
+__device__ __forceinline__ void plane_split8(const float (&x)[8], s16x8_t (&out)[3]) {
+    const f32x4_t lo = {x[0], x[1], x[2], x[3]}, hi = {x[4], x[5], x[6], x[7]};
+    u32x2_t a[3], b[3];
+    plane_split4(lo, a); plane_split4(hi, b);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const u32x4_t v = {a[q][0], a[q][1], b[q][0], b[q][1]};
+        out[q] = __builtin_bit_cast(s16x8_t, v);
+    }
+}
+// the order the six products a_i b_j (i + j <= 2) are accumulated in: low-order ones first, a0 b0 last
+static constexpr int PLANE_PA[6] = {0, 1, 2, 0, 1, 0}, PLANE_PB[6] = {2, 1, 0, 1, 0, 0};
+
 }  // namespace mocha

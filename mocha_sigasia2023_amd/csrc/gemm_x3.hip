@@ -33,9 +33,7 @@ namespace mocha {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -52,25 +50,6 @@ static constexpr int XW_BLOCK = 3 * XB_PLANE;           // packed weights per (n
 
 __device__ __forceinline__ float x3_lrelu(float x) { return x > 0.f ? x : 0.2f * x; }
 __device__ __forceinline__ float x3_gelu(float x) { return 0.5f * x * (1.0f + mocha_erf(x * 0.70710678118654752440f)); }
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));       // v_cvt_pk_bf16_f32: low half = bf16(a)
-}
-
-// four floats -> three planes of four bf16 (8 bytes each)
-__device__ __forceinline__ void split4_rn(const f32x4 v, u32x2 (&out)[3]) {
-    float r0 = v[0], r1 = v[1], r2 = v[2], r3 = v[3];
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const unsigned p01 = cvt_pk_bf16(r0, r1), p23 = cvt_pk_bf16(r2, r3);
-        out[q][0] = p01; out[q][1] = p23;
-        if (q < 2) {
-            r0 -= __uint_as_float(p01 << 16); r1 -= __uint_as_float(p01 & 0xffff0000u);
-            r2 -= __uint_as_float(p23 << 16); r3 -= __uint_as_float(p23 & 0xffff0000u);
-        }
-    }
-}
 
 // W [N][K] fp32 -> packed planes.  One workgroup per (n tile, k step) block: thread = (row, k half) reads 32 bytes and writes one
 // 16-byte piece per plane, so every wave writes 512-byte runs of the 12 KB block (the image is written once per weight, but once per
@@ -91,7 +70,7 @@ __global__ __launch_bounds__(256) void mocha_pack_x3(const float* __restrict__ W
         }
     }
     u32x2 a[3], b[3];
-    split4_rn(lo, a); split4_rn(hi, b);
+    plane_split4(lo, a); plane_split4(hi, b);
     unsigned short* blk = out + (size_t)blockIdx.x * XW_BLOCK;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -201,7 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             f32x4 v = ra[i];
             if (LRELU) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
             u32x2 pl[3];
-            split4_rn(v, pl);
+            plane_split4(v, pl);
 #pragma unroll
             for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(st + q * XA_PLANE + a_wr + i * 64 * 8) = pl[q];
         }
@@ -295,8 +274,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < 24; ++m) {
-            constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};
-            const int pa = PA[m >> 2], pb = PB[m >> 2], i = (m >> 1) & 1, j = m & 1;
+            const int pa = PLANE_PA[m >> 2], pb = PLANE_PB[m >> 2], i = (m >> 1) & 1, j = m & 1;
             if (X3_MAXSUM == 2 || (m >> 2) == 5)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[pb][j], a[pa][i], acc[i][j], 0, 0, 0);       // C^T tile
             if (FETCH_W && m < 22) { split_op(2 * m); split_op(2 * m + 1); }

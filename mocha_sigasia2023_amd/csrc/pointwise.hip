@@ -2,6 +2,7 @@
 // norms, the final 64->15 projection, bank utilities.  All coalesced on the channel axis
 // (activations are kept channel-last: rows = (window, time, node), columns = channels).
 #include "kernels.h"
+#include "device_utils.h"
 
 namespace mocha {
 
@@ -134,34 +135,6 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
 // of a K = 16 MFMA in that joint order (as P^T in attention_x3.hip), and AP' is held in the same order.
 // ---------------------------------------------------------------------------------------
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned ef_cvt_pk(float a, float b) {
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));       // v_cvt_pk_bf16_f32
-}
-// eight floats -> three planes of eight bf16
-__device__ __forceinline__ void ef_split8(const float (&x)[8], s16x8 (&out)[3]) {
-    float r[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) r[e] = x[e];
-    unsigned w[3][4];
-#pragma unroll
-    for (int q = 0; q < 3; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const unsigned pk = ef_cvt_pk(r[2 * e], r[2 * e + 1]);
-            w[q][e] = pk;
-            if (q < 2) { r[2 * e] -= __uint_as_float(pk << 16); r[2 * e + 1] -= __uint_as_float(pk & 0xffff0000u); }
-        }
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        const u32x4 v = {w[q][0], w[q][1], w[q][2], w[q][3]};
-        out[q] = __builtin_bit_cast(s16x8, v);
-    }
-}
 
 __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restrict__ X, const float* __restrict__ W1,
                                                             const float* __restrict__ b1, const float* __restrict__ AP,
@@ -182,7 +155,7 @@ __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restr
         float w8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const int feat = 8 * hh + e; w8[e] = feat < Cin ? W1[c * Cin + feat] : 0.f; }
-        ef_split8(w8, wpl[t]);
+        plane_split8(w8, wpl[t]);
     }
     {
         const int pk = l31, pp = pk / 3, kk = pk - pp * 3;
@@ -194,7 +167,7 @@ __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restr
                 const int joint = 16 * j + 8 * (e >> 2) + 4 * hh + (e & 3);
                 a8[e] = (pk < 18 && joint < V) ? AP[(kk * V + joint) * 6 + pp] : 0.f;
             }
-            ef_split8(a8, apl[j]);
+            plane_split8(a8, apl[j]);
         }
     }
     // staging map of this lane's (at most 8) elements of a frame: element e = lane + 64 i -> joint e / Cin, feature e % Cin
@@ -213,7 +186,6 @@ __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restr
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
-    constexpr int PA[6] = {0, 1, 2, 0, 1, 0}, PB[6] = {2, 1, 0, 1, 0, 0};      // low-order products first
     const int stride = gridDim.x * 4;
     int frame = blockIdx.x * 4 + wave;
     float xr[8];
@@ -236,7 +208,7 @@ __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restr
         if (frame + stride < nframes) fetch(frame + stride);       // next frame's loads fly under this frame's MFMAs
         const float xa[8] = {xa0[0], xa0[1], xa0[2], xa0[3], xa1[0], xa1[1], xa1[2], xa1[3]};
         s16x8 xpl[3];
-        ef_split8(xa, xpl);
+        plane_split8(xa, xpl);
         float* of = out + (size_t)frame * 18 * 64;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -244,7 +216,7 @@ __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restr
 #pragma unroll
             for (int r = 0; r < 16; ++r) h[r] = 0.f;
 #pragma unroll
-            for (int pr = 0; pr < 6; ++pr) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xpl[PA[pr]], wpl[t][PB[pr]], h, 0, 0, 0);
+            for (int pr = 0; pr < 6; ++pr) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xpl[PLANE_PA[pr]], wpl[t][PLANE_PB[pr]], h, 0, 0, 0);
             f32x16 o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
@@ -254,9 +226,9 @@ __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restr
 #pragma unroll
                 for (int e = 0; e < 8; ++e) h8[e] = lrelu02(h[8 * j + e] + bias[t]);
                 s16x8 hpl[3];
-                ef_split8(h8, hpl);
+                plane_split8(h8, hpl);
 #pragma unroll
-                for (int pr = 0; pr < 6; ++pr) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apl[j][PA[pr]], hpl[PB[pr]], o, 0, 0, 0);
+                for (int pr = 0; pr < 6; ++pr) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apl[j][PLANE_PA[pr]], hpl[PLANE_PB[pr]], o, 0, 0, 0);
             }
             // o[r] = out[pk = (r&3) + 8 (r>>2) + 4 hh][channel t*32 + l31]; rows 18..31 are padding
 #pragma unroll
