@@ -21,7 +21,7 @@ struct GemmParams {
     const float* A = nullptr;     // source activations
     const float* W = nullptr;     // [N][K], k contiguous (nn.Linear / repacked conv layout)
     const float* wsub = nullptr;              // [K] vector subtracted from every W row while it is staged (centred bank)
-    const unsigned short* Wsplit = nullptr;   // [planes][N][K] bf16 planes of W (gemm_split.hip), or a bf16 bank
+    const unsigned short* Wsplit = nullptr;   // gemm_x3.hip: the packed three-plane image of W (launch_pack_x3)
     float* C = nullptr;
     const float* bias = nullptr;      // [N] or null
     const float* rowbias = nullptr;   // [rb_mod][N] or null, indexed by (row % rb_mod)
@@ -41,10 +41,6 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 bool gemm_is_narrow(const GemmParams& p);
 bool gemm_is_small(const GemmParams& p);    // true: mid-size launch -> 64 x 64 tiles
 bool gemm_is_skinny(const GemmParams& p);   // true: a handful of windows -> mocha_gemm_skinny (32x32 tile per workgroup, 4-way in-workgroup split-K)
-// split-precision engine (gemm_split.hip): planes = 33 (fp32-accurate, 6 bf16 MFMAs) or 31 (3 query planes x bf16 bank)
-hipError_t gemm_split_init();
-hipError_t launch_gemm_split(const GemmParams& p, int planes, hipStream_t s);
-void split_weights_host(const float* w, size_t count, unsigned short* out /*3*count*/);   // true: 128x64 tiles (mocha_gemm_f32<64,...>), false: 128x128
 hipError_t gemm_init();           // one-time function attributes (dynamic LDS size)
 // fp32 GEMM on the bf16 matrix pipe (gemm_x3.hip): both operands as three bf16 planes, six MFMA passes, fp32-accurate.
 // p.Wsplit = the packed image of W made by launch_pack_x3 (gemm_x3_packed_elems(N, K) bf16).

@@ -801,7 +801,6 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     build_expectations(c);
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = gemm_init();
-    if (e == hipSuccess) e = gemm_split_init();
     if (e == hipSuccess) e = gemm_x3_init();
     if (e == hipSuccess) e = match_mfma_init();
     if (e == hipSuccess) e = xf_tail_init();

@@ -7,8 +7,8 @@ mkdir -p tools/bin
 H="/opt/rocm/bin/hipcc --offload-arch=gfx950"
 $H -O3 -std=c++17 -w -I mocha_sigasia2023_amd/csrc -c tools/gemm_bench.hip -o tools/bin/gemm_bench.o
 C=mocha_sigasia2023_amd/csrc
-$H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_split.o $C/gemm_x3.o -o tools/bin/gemm_bench
+$H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_x3.o -o tools/bin/gemm_bench
 if [ -n "$1" ]; then
   $H -O3 -fPIC -std=c++17 -w "$@" -c $C/gemm_x3.hip -o tools/bin/gemm_x3_abl.o
-  $H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_split.o tools/bin/gemm_x3_abl.o -o tools/bin/gemm_bench_abl
+  $H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_x3_abl.o -o tools/bin/gemm_bench_abl
 fi

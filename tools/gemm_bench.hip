@@ -27,8 +27,8 @@ int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 585;
     int iters = argc > 2 ? atoi(argv[2]) : 20;
     int check = argc > 3 ? atoi(argv[3]) : 1;
-    int mode = argc > 4 ? atoi(argv[4]) : 0;      // 0 = exact f32 MFMA, 33 = first split-bf16 engine (gemm_split.hip), 36 = gemm_x3.hip
-    CK(gemm_init()); CK(gemm_split_init()); CK(gemm_x3_init());
+    int mode = argc > 4 ? atoi(argv[4]) : 0;      // 0 = exact f32 MFMA (gemm_f32.hip), 36 = bf16 x 3 planes (gemm_x3.hip)
+    CK(gemm_init()); CK(gemm_x3_init());
     std::vector<Shape> shapes = {
         {"enc.qkv      ", B * 90, 1536, 256, 0},
         {"xf.out512    ", B * 90, 256, 512, 0},
@@ -78,14 +78,12 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dA, ha.data(), na * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hw.data(), nw * 4, hipMemcpyHostToDevice));
         unsigned short* dWs = nullptr;
         if (mode == 36) { CK(hipMalloc(&dWs, gemm_x3_packed_elems(sh.N, sh.K) * 2)); CK(launch_pack_x3(dW, sh.N, sh.K, dWs, 0)); }
-        else if (mode) { std::vector<unsigned short> hs(3 * nw); split_weights_host(hw.data(), nw, hs.data()); CK(hipMalloc(&dWs, 3 * nw * 2)); CK(hipMemcpy(dWs, hs.data(), 3 * nw * 2, hipMemcpyHostToDevice)); }
         GemmParams p; p.Wsplit = dWs; p.A = dA; p.W = dW; p.C = dC; p.M = sh.M; p.N = sh.N; p.K = sh.K; p.lda = lda; p.ldc = sh.N;
         if (sh.gather) { p.gather = 1; p.T_out = sh.T_out; p.V = sh.V; p.ntaps = sh.ntaps; p.pad = sh.pad; p.stride = sh.stride; p.R = sh.R;
                          p.T_full = sh.T_full; p.tshift = sh.tshift; p.Cc = sh.Cc; p.T_src = sh.T_src; p.ascale = sh.R > 1 ? 0.25f : 1.f; }
         if (sh.M == 585 && sh.N == 585) { p.ksplit = 16; p.slab_stride = (long long)sh.M * sh.N; }
         const bool x3 = mode == 36 && gemm_x3_supports(p);
-        auto run = [&]() { return x3 ? launch_gemm_x3(p, 0) : (mode && mode != 36) ? launch_gemm_split(p, mode, 0) : launch_gemm(p, 0); };
-        if (mode && mode != 36 && sh.gather && sh.R != 1) { printf("%s skipped (R != 1)\n", sh.name); CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); CK(hipFree(dWs)); continue; }
+        auto run = [&]() { return x3 ? launch_gemm_x3(p, 0) : launch_gemm(p, 0); };
         long long* dstamp = nullptr;
         if (getenv("MOCHA_BENCH_STAMPS") && x3) { CK(hipMalloc(&dstamp, (size_t)65536 * 32)); CK(hipMemset(dstamp, 0, (size_t)65536 * 32)); p.wsub = (const float*)dstamp; }
         for (int i = 0; i < 3; ++i) CK(run());
