@@ -40,7 +40,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifndef X3_MAXSUM
 #define X3_MAXSUM 2         // products a_i b_j with i + j <= 2; tools/ builds an ablation with fewer (wrong results, timing only)
 #endif
-static constexpr int XM = 128, XN = 128, XK = 16;
+static constexpr int XN = 128, XK = 16;                  // tile width, K step; tile height = 64 TM rows
 static constexpr int XA_HALF = 128 * 8 + 32;            // bf16 per k half of an A plane (2 KB + 64 B)
 static constexpr int XA_PLANE = 2 * XA_HALF;            // 2176 bf16
 static constexpr int XB_PLANE = 128 * 16;               // 2048 bf16, [k half][row][8]
@@ -91,8 +91,11 @@ hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hip
 
 // LRELU: LeakyReLU(0.2) on the activations as they are split; GATHER: temporal-conv gather (kernels.h) instead of plain rows.
 // Compile-time so that a K step is one basic block the scheduler can interleave.
-template <bool LRELU, bool GATHER>
+// TM: 32-row MFMA blocks per wave: 2 = the 128-row tile; 1 = a 64-row tile (four waves of 32 x 64) for mid-size launches
+// (a few dozen to a few hundred windows), where 128-row tiles would leave most workgroup slots empty.
+template <bool LRELU, bool GATHER, int TM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void mocha_gemm_x3(GemmParams p) {
+    constexpr int TILE_M = TM * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned short x3_sm[];          // [2][X_STAGE]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int wm = wave >> 1, wn = wave & 1;
 
     const int n_tiles = (p.N + XN - 1) / XN;
-    const int m_tiles = (p.M + XM - 1) / XM;
+    const int m_tiles = (p.M + TILE_M - 1) / TILE_M;
     const int bid = blockIdx.x;
     int mt, nt;
     if (m_tiles >= 8) {                 // XCD-aware order: the n-tiles of one m-tile share an XCD (bid % 8)
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         nt = bid - mt * n_tiles;
     }
     if (mt >= m_tiles) return;
-    const int m0 = mt * XM, n0 = nt * XN;
+    const int m0 = mt * TILE_M, n0 = nt * XN;
     // K split over gridDim.z (the matcher's 23 040-long contraction): this workgroup takes steps s0 .. s0 + nsteps - 1 and writes raw
     // partial sums to slab blockIdx.z; the host guarantees at least two steps per slab
     const int steps_total = p.K / XK;
@@ -135,10 +138,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int lrow = tid >> 2;
     const int lc = tid & 3;
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(GATHER ? p.A : p.A + (size_t)(m0 < p.M ? m0 : 0) * p.lda);
-    int a_rb[2], a_t[2];
-    unsigned a_off[2];
+    int a_rb[TM], a_t[TM];
+    unsigned a_off[TM];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
         int m = m0 + lrow + 64 * i;
         m = m < p.M ? m : p.M - 1;
         if (GATHER) {
@@ -152,18 +155,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             a_off[i] = ((unsigned)(m - m0) * (unsigned)p.lda + lc * 4) * 4u;
         }
     }
-    f32x4 rset[2][2];                               // step t's activations wait in set t & 1, fetched two steps ahead
-    auto load_a = [&](int s, f32x4 (&ra)[2]) __attribute__((always_inline)) {
+    f32x4 rset[2][TM];                              // step t's activations wait in set t & 1, fetched two steps ahead
+    auto load_a = [&](int s, f32x4 (&ra)[TM]) __attribute__((always_inline)) {
         const int k0 = (s0 + s) * XK;
         if (!GATHER) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) ra[i] = bload(rsA, a_off[i], (unsigned)k0 * 4u);
+            for (int i = 0; i < TM; ++i) ra[i] = bload(rsA, a_off[i], (unsigned)k0 * 4u);
         } else {
             // the row of tap k0 / Cc, recomputed every step (a handful of VALU instructions hidden between the MFMAs; no branch)
             const int tap = k0 / p.Cc;
             const int cin = k0 - tap * p.Cc;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM; ++i) {
                 int tf = a_t[i] * p.stride + tap - p.pad;
                 tf = tf < 0 ? -tf : tf;
                 tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
@@ -174,9 +177,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     };
     // plane q of (row, piece lc): k half lc >> 1, 8 bytes at (lc & 1)
     const int a_wr = (lc >> 1) * XA_HALF + lrow * 8 + (lc & 1) * 4;
-    auto split_store = [&](const f32x4 (&ra)[2], unsigned short* st) __attribute__((always_inline)) {
+    auto split_store = [&](const f32x4 (&ra)[TM], unsigned short* st) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
             f32x4 v = ra[i];
             if (LRELU) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
             u32x2 pl[3];
@@ -196,16 +199,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                                                      (unsigned)(j * 256 + tid) * 16u, (unsigned)s * (XW_BLOCK * 2u), 0, 0);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // fragment of lane (row l31, k half hh): 16 bytes
-    const int fa = hh * XA_HALF + (wm * 64 + l31) * 8;
+    const int fa = hh * XA_HALF + (wm * TM * 32 + l31) * 8;
     const int fb = XB_OFF + hh * XA_HALF + (wn * 64 + l31) * 8;
 
     // prologue: step 0 into stage 0, step 1's activations into registers.  The counted waits below (and in the steps) rely on the
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     split_store(rset[0], x3_sm);
     load_a(1, rset[1]);                             // K >= 32 (gemm_x3_supports)
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TM) : "memory");     // step 1's TM fetches stay in flight
 
     // One K step.  FETCH_W: step s + 1 exists (its weights are copied and its activations split into the other stage);
     // FETCH_A: step s + 2 exists (its activations are fetched).  The three variants are straight-line code, so the compiler's own
@@ -233,10 +236,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // few MFMAs left when the fetch waited for step s + 1's registers to be free (the latency was exposed on every step)
         if (FETCH_A) load_a(s + 2, rset[P]);
         __builtin_amdgcn_sched_barrier(0);
-        s16x8 a[3][2], b[3][2];
+        s16x8 a[3][TM], b[3][2];
         auto rd_a = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[q][i] = *reinterpret_cast<const s16x8*>(cur + q * XA_PLANE + fa + i * 32 * 8);
+            for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const s16x8*>(cur + q * XA_PLANE + fa + i * 32 * 8);
         };
         auto rd_b = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
@@ -246,11 +249,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         // Hand-interleaved issue order (fenced so that the scheduler keeps it): after every MFMA two of the 44 VALU instructions that
         // split step s + 1's activations (an MFMA holds the vector issue port for 8 of its 32 cycles), the plane writes as soon as a
         // row's planes are complete, the fetch of step s + 2 when the registers are free.  Low-order products first, a0·b0 last.
-        float x[8];
-        unsigned pk[4][3], hi[4][2];
+        float x[4 * TM];
+        unsigned pk[2 * TM][3], hi[2 * TM][2];
         if (FETCH_W) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { x[e] = rset[P ^ 1][e >> 2][e & 3]; if (LRELU) x[e] = fmaxf(x[e], 0.2f * x[e]); }
+            for (int e = 0; e < 4 * TM; ++e) { x[e] = rset[P ^ 1][e >> 2][e & 3]; if (LRELU) x[e] = fmaxf(x[e], 0.2f * x[e]); }
         }
         auto split_op = [&](int k) __attribute__((always_inline)) {     // op k of 44: pair k / 11 (two values), step k % 11
             const int pr = k / 11, o = k % 11, lvl = o / 5;
@@ -273,18 +276,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         };
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 24; ++m) {
-            const int pa = PLANE_PA[m >> 2], pb = PLANE_PB[m >> 2], i = (m >> 1) & 1, j = m & 1;
-            if (X3_MAXSUM == 2 || (m >> 2) == 5)
+        for (int m = 0; m < 12 * TM; ++m) {
+            const int pr = m / (2 * TM), pa = PLANE_PA[pr], pb = PLANE_PB[pr], i = (m >> 1) % TM, j = m & 1;
+            if (X3_MAXSUM == 2 || pr == 5)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[pb][j], a[pa][i], acc[i][j], 0, 0, 0);       // C^T tile
-            if (FETCH_W && m < 22) { split_op(2 * m); split_op(2 * m + 1); }
+            if (FETCH_W && m < 11 * TM) { split_op(2 * m); split_op(2 * m + 1); }
             if (FETCH_W && m == 10) write_row(0);
-            if (FETCH_W && m == 21) write_row(1);
+            if (FETCH_W && TM == 2 && m == 21) write_row(1);
             __builtin_amdgcn_sched_barrier(0);
         }
         // the weights of step s + 1 have landed and this wave's plane writes are done; step s + 2's activations stay in flight
         // (__syncthreads() would drain them: its fence waits for vmcnt(0))
-        if (FETCH_A) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (FETCH_A) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TM) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     };
     X3_STAMP(1);
@@ -312,19 +315,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         static_assert(64 * LDP * 4 <= 2 * X_STAGE * 2, "epilogue staging fits the operand stages");
         float* stage = reinterpret_cast<float*>(x3_sm);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (wm == h) {
+        for (int h = 0; h < TM; ++h) {                // 64 rows of the tile per pass
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    float* srow = stage + (i * 32 + l31) * LDP + wn * 64 + 4 * hh;
+            for (int i = 0; i < TM; ++i) {
+                const int rblk = wm * TM + i;           // this wave's 32-row block of the tile
+                if ((rblk >> 1) != h) continue;         // wave-uniform
+                float* srow = stage + ((rblk & 1) * 32 + l31) * LDP + wn * 64 + 4 * hh;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                            *reinterpret_cast<f32x4*>(srow + j * 32 + 8 * g) = v;
-                        }
-                }
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(srow + j * 32 + 8 * g) = v;
+                    }
             }
             __syncthreads();
 #pragma unroll
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
                 }
             }
-            if (h == 0) __syncthreads();
+            if (h + 1 < TM) __syncthreads();
         }
         X3_STAMP_OUT();
         return;
@@ -353,8 +356,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
     // ragged tiles (N not a multiple of 128, unaligned leading dimensions): straight from the accumulators
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = m0 + wm * 64 + i * 32 + l31;
+    for (int i = 0; i < TM; ++i) {
+        const int row = m0 + (wm * TM + i) * 32 + l31;
         if (row >= p.M) continue;
         const float* rbrow = p.rowbias ? p.rowbias + (size_t)(row % p.rb_mod) * p.N : nullptr;
         const float* rsrow = p.residual ? p.residual + (size_t)row * p.ldr : nullptr;
@@ -381,11 +384,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 static constexpr size_t x3_lds_bytes() { return (size_t)2 * X_STAGE * sizeof(unsigned short); }
 
+template <bool L, bool G, int TM>
+static hipError_t x3_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3<L, G, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes());
+}
+
 hipError_t gemm_x3_init() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes());
+    hipError_t e = x3_attr<false, false, 2>();
+    if (e == hipSuccess) e = x3_attr<true, false, 2>();
+    if (e == hipSuccess) e = x3_attr<false, true, 2>();
+    if (e == hipSuccess) e = x3_attr<true, true, 2>();
+    if (e == hipSuccess) e = x3_attr<false, false, 1>();
+    if (e == hipSuccess) e = x3_attr<true, false, 1>();
+    if (e == hipSuccess) e = x3_attr<false, true, 1>();
+    if (e == hipSuccess) e = x3_attr<true, true, 1>();
     return e;
 }
 
@@ -404,8 +416,22 @@ bool gemm_x3_supports(const GemmParams& p) {
         return (long long)total * XW_BLOCK * 2 < (1ll << 31);
     }
     if (p.N % XN != 0) return false;                // N = 64 / 192 (to_mot's joint block): a padded 128-wide tile loses to the exact-f32 128 x 64 tile (measured)
-    if (gemm_is_skinny(p) || gemm_is_small(p)) return false;
+    if (gemm_is_skinny(p)) return false;            // a handful of windows: latency-bound, mocha_gemm_skinny
     return true;
+}
+
+template <int TM>
+static void x3_launch(const GemmParams& p, hipStream_t s) {
+    const int m_tiles = (p.M + TM * 64 - 1) / (TM * 64);
+    const int m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
+    const dim3 grid(m_pad * ((p.N + XN - 1) / XN), 1, p.ksplit > 1 ? p.ksplit : 1);
+    if (p.a_lrelu) {
+        if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3<true, true, TM>), grid, dim3(256), x3_lds_bytes(), s, p);
+        else hipLaunchKernelGGL((mocha_gemm_x3<true, false, TM>), grid, dim3(256), x3_lds_bytes(), s, p);
+    } else {
+        if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3<false, true, TM>), grid, dim3(256), x3_lds_bytes(), s, p);
+        else hipLaunchKernelGGL((mocha_gemm_x3<false, false, TM>), grid, dim3(256), x3_lds_bytes(), s, p);
+    }
 }
 
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
@@ -413,16 +439,9 @@ hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
     if (!p.Wsplit || !gemm_x3_supports(p)) return hipErrorInvalidValue;
     if (p.gather && (long long)p.M / p.T_out * p.T_src * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     if (128ll * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
-    const int m_tiles = (p.M + XM - 1) / XM;
-    const int m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
-    const dim3 grid(m_pad * ((p.N + XN - 1) / XN), 1, p.ksplit > 1 ? p.ksplit : 1);
-    if (p.a_lrelu) {
-        if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3<true, true>), grid, dim3(256), x3_lds_bytes(), s, p);
-        else hipLaunchKernelGGL((mocha_gemm_x3<true, false>), grid, dim3(256), x3_lds_bytes(), s, p);
-    } else {
-        if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3<false, true>), grid, dim3(256), x3_lds_bytes(), s, p);
-        else hipLaunchKernelGGL((mocha_gemm_x3<false, false>), grid, dim3(256), x3_lds_bytes(), s, p);
-    }
+    // mid-size launches (fewer than 768 tiles of 128 x 64: a few dozen to a few hundred windows) take 64-row tiles, twice the workgroups
+    if (p.ksplit <= 1 && gemm_is_small(p)) x3_launch<1>(p, s);
+    else x3_launch<2>(p, s);
     return hipGetLastError();
 }
 
