@@ -22,12 +22,9 @@
  *     mocha_last_error(ctx) gives the message.  The caller owns every in/out buffer; the
  *     context owns the device copies of the weights, the bank (unless borrowed) and the
  *     workspaces.  One context per device per host thread.
- *   - known limitation: keep the work of one device on one stream at a time when the plane GEMM engine ("gemm_bf16x3", default on)
- *     is active.  With two contexts driven concurrently from two same-priority streams of one process, a kernel of one stream was
- *     observed (intermittently, in one test ordering; not with streams of different priority, not with "gemm_bf16x3" = 0, never on a
- *     single stream) to read a producer's output of its own stream before it was complete while a large plane-GEMM launch of the
- *     other stream was resident.  The cause has not been found (tools/experiments/README.md).  Multi-GPU use is one process per
- *     GPU and is not affected.
+ *   - several contexts of one process may be driven concurrently from different streams (tests/test_runtime_gpu.py runs two whole
+ *     pipelines side by side on same-priority and on different-priority streams and compares them bit for bit with the sequential
+ *     results); a context itself serves one call at a time.
  */
 #ifndef MOCHA_HIP_H
 #define MOCHA_HIP_H

@@ -2,6 +2,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Kernels that must not contain packed fp32 instructions (v_pk_fma_f32 ...): see mocha_body_front in pointwise.hip.  The attribute
+// only means something to the device pass.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MOCHA_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define MOCHA_NO_PACKED_F32
+#endif
+
 namespace mocha {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));

@@ -5,6 +5,7 @@
 // One thread per (window, frame); the per-bone global transforms a thread needs for its children live in
 // LDS ([bone][component][thread], conflict-free).  Quaternions are (w, x, y, z) as in the reference.
 #include "kernels.h"
+#include "device_utils.h"
 
 namespace mocha {
 
@@ -34,7 +35,8 @@ __device__ __forceinline__ V3 qrot(Q q, V3 v) {
 static constexpr int FT = 64;       // threads per workgroup
 static constexpr int FC = 13;       // floats kept per bone: rot 4, pos 3, vel 3, ang 3
 
-__global__ __launch_bounds__(FT) void mocha_featurize(const float* __restrict__ Yrot, const float* __restrict__ Ypos,
+// no packed fp32 instructions: LDS-fed v_pk_*_f32 with op_sel is the combination that misbehaved in mocha_body_front (pointwise.hip)
+__global__ __launch_bounds__(FT) MOCHA_NO_PACKED_F32 void mocha_featurize(const float* __restrict__ Yrot, const float* __restrict__ Ypos,
                                                       const float* __restrict__ Yvel, const float* __restrict__ Yang,
                                                       const int* __restrict__ parents, float* __restrict__ X, int frames /*B*T*/,
                                                       int T, int J) {

@@ -414,9 +414,7 @@ void x3_drop_images(mocha_ctx* c) {
 int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
     const double flops = 2.0 * p.M * (double)p.N * p.K;
     const double bytes = 4.0 * ((double)p.M * p.K / (p.gather ? p.ntaps : 1) * (p.R) + (double)p.N * p.K + (double)p.M * p.N * p.ksplit);
-    // two-stream mode keeps its mid-size launches on the exact-f32 kernel: overlapped with the other half's kernels the 64-row plane
-    // tile showed the ordering problem described in mocha_hip.h (Conventions)
-    if (c->gemm_x3 && gemm_x3_supports(p) && !(c->dual_stream && gemm_is_small(p))) {
+    if (c->gemm_x3 && gemm_x3_supports(p)) {
         const unsigned short* img = nullptr;
         int rc = x3_image(c, s, p, &img);
         if (rc) return rc;

@@ -3,6 +3,7 @@
 // (activations are kept channel-last: rows = (window, time, node), columns = channels).
 #include "kernels.h"
 #include "device_utils.h"
+#include <cstdlib>
 
 namespace mocha {
 
@@ -257,13 +258,14 @@ hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, 
 // ---------------------------------------------------------------------------------------
 // body_front: LeakyReLU then the body-part adjacency (commuted in front of the 1x1 conv):
 //   out[(f,w)][k*256+c] = sum_v A_b[k][v][w] lrelu(x[(f,v)][c])      (blocks.py:131, :64)
-// one thread per (frame f, 4 channels)
+// one thread per (frame f, 4 channels); the 72 coefficients are wave-uniform scalar loads.
+// No packed fp32 instructions here, and no LDS copy of the coefficients: the build that kept them in LDS and let the compiler form
+// v_pk_fma_f32 with op_sel (the low result taking the high register of a coefficient pair) intermittently produced 0 for that low
+// result in lanes 48-63 when workgroups of another stream's plane GEMM shared the CU - found with a re-run-and-compare hook in
+// the two-context test; either change alone made it disappear (tools/experiments/README.md, "two streams").
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void mocha_body_front(const float* __restrict__ x, const float* __restrict__ Ab,
-                                                        float* __restrict__ out, int frames) {
-    __shared__ float a[72];
-    if (threadIdx.x < 72) a[threadIdx.x] = Ab[threadIdx.x];
-    __syncthreads();
+__global__ __launch_bounds__(256) MOCHA_NO_PACKED_F32
+void mocha_body_front(const float* __restrict__ x, const float* __restrict__ Ab, float* __restrict__ out, int frames) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int f = gid >> 6, c4 = (gid & 63) * 4;
     if (f >= frames) return;
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(256) void mocha_body_front(const float* __restrict_
         for (int k = 0; k < 2; ++k) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int v = 0; v < 6; ++v) acc += xv[v] * a[(k * 6 + v) * 6 + w];
+            for (int v = 0; v < 6; ++v) acc += xv[v] * Ab[(k * 6 + v) * 6 + w];
             *reinterpret_cast<f32x4*>(out + ((size_t)f * 6 + w) * 512 + k * 256 + c4) = acc;
         }
 }

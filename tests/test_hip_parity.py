@@ -301,6 +301,9 @@ def test_dual_stream_option_matches_single_stream():
     model.set_option("dual_stream", 1).set_option("dual_min", 64)
     Y2, i2 = bank.characterize(src, mean, std, return_index=True)
     Y3 = model(src[:130].contiguous(), src[20:150].contiguous())
+    for _ in range(10):                                          # the two halves overlap on the CUs: still the same bits every time
+        Yr, ir = bank.characterize(src, mean, std, return_index=True)
+        assert torch.equal(Yr, Y2) and torch.equal(ir, i2)
     model.set_option("dual_stream", 0)
     Y4 = model(src[:130].contiguous(), src[20:150].contiguous())
     assert torch.equal(i1, i2)
