@@ -70,3 +70,17 @@ def test_bench_launcher_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "64"], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
     assert "exposes" in (r.stderr + r.stdout)
+
+
+def test_device_code_has_no_packed_fp32_op_sel_pattern():
+    """tools/isa_lint.py over the built library: no kernel outside its allow-list contains ``v_pk_*_f32`` with ``op_sel`` on a high
+    register - the pattern that, fed from LDS, made mocha_body_front depend on what shared its CU (Concurrency)."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    _built()
+    spec = importlib.util.spec_from_file_location("isa_lint", os.path.join(REPO, "tools", "isa_lint.py"))
+    lint = importlib.util.module_from_spec(spec); spec.loader.exec_module(lint)
+    found = lint.scan(_C.LIB_PATH)
+    bad = {k: v for k, v in found.items() if not any(a in k for a in lint.ALLOW)}
+    assert not bad, bad
