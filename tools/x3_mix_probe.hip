@@ -1,0 +1,125 @@
+// What would a 128 x 256 tile buy mocha_gemm_x3?  The instruction mix of one K step, without the memory side, at the two shapes:
+//   TN = 2 (shipped, 128 x 128 tile, wave = 64 x 64):  24 MFMAs, 12 ds_read_b128, 44 split VALU, 6 ds_write_b64, 1 barrier; 2 WGs / CU here (the probe keeps its plane writes beside the operands: 60 KB)
+//   TN = 4 (128 x 256 tile, wave = 64 x 128):          48 MFMAs, 18 ds_read_b128, 44 split VALU, 6 ds_write_b64, 1 barrier; 2 WGs / CU
+// launched back to back for a few seconds (the board settles at the clock it holds under that load).  Operands are random bf16.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mocha_sigasia2023_amd/csrc tools/x3_mix_probe.hip -o tools/bin/x3_mix_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "device_utils.h"
+using namespace mocha;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int TN, bool SPLIT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 2 ? 3 : 2, TN == 2 ? 3 : 2)))
+void mix(const s16x8_t* __restrict__ src, float* __restrict__ out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) s16x8_t sm[];      // operands: (6 + 3 TN) x 256 fragments, then 6 x 256 x 8 B of plane writes
+    constexpr int NFRAG = 6 + 3 * TN;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < NFRAG * 256; i += 256) sm[i] = src[i % (12 * 256)];
+    u32x2_t* wr = reinterpret_cast<u32x2_t*>(sm + NFRAG * 256);
+    __syncthreads();
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float xs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) xs[e] = 0.37f * (tid + 1) + e;
+    for (int it = 0; it < iters; ++it) {
+        s16x8_t a[3][2], b[3][TN];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[q][i] = sm[(q * 2 + i) * 256 + ((tid + it) & 255)];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[q][j] = sm[(6 + q * TN + j) * 256 + ((tid + 7 * it) & 255)];
+        }
+        float x[8];
+        unsigned pk[4][3], hi[4][2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = xs[e];
+        auto split_op = [&](int k) __attribute__((always_inline)) {
+            const int pr = k / 11, o = k % 11, lvl = o / 5;
+            float& x0 = x[2 * pr]; float& x1 = x[2 * pr + 1];
+            if (o == 10) { pk[pr][2] = cvt_pk_bf16(x0, x1); return; }
+            switch (o % 5) {
+                case 0: pk[pr][lvl] = cvt_pk_bf16(x0, x1); break;
+                case 1: hi[pr][0] = pk[pr][lvl] << 16; break;
+                case 2: hi[pr][1] = pk[pr][lvl] & 0xffff0000u; break;
+                case 3: x0 -= __uint_as_float(hi[pr][0]); break;
+                default: x1 -= __uint_as_float(hi[pr][1]); break;
+            }
+        };
+        auto write_row = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const u32x2_t v = {pk[2 * i][q], pk[2 * i + 1][q]}; wr[(q * 2 + i) * 256 + tid] = v; }
+        };
+        constexpr int NM = 12 * TN;                      // MFMAs per step
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            const int pr = m / (2 * TN), r = m % (2 * TN), i = r / TN, j = r % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PLANE_PB[pr]][j], a[PLANE_PA[pr]][i], acc[i][j], 0, 0, 0);
+            if (SPLIT) {
+                if (TN == 2) { if (m < 22) { split_op(2 * m); split_op(2 * m + 1); } if (m == 10) write_row(0); if (m == 21) write_row(1); }
+                else { if (m < 44) split_op(m); if (m == 21) write_row(0); if (m == 43) write_row(1); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xs[e] += 0.001f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s + xs[0];
+}
+
+template <int TN, bool SPLIT>
+static void run(const s16x8_t* d, float* o, int iters, double seconds, const char* name) {
+    const size_t lds = (size_t)(6 + 3 * TN) * 256 * 16 + 6 * 256 * 8;
+    CK(hipFuncSetAttribute((const void*)mix<TN, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int wgs = 256 * (TN == 2 ? 3 : 2) * 2;
+    auto launch = [&]() { hipLaunchKernelGGL((mix<TN, SPLIT>), dim3(wgs), dim3(256), lds, 0, d, o, iters); };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    launch(); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0)); launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms1; CK(hipEventElapsedTime(&ms1, e0, e1));
+    const int n = (int)(seconds * 1e3 / ms1) + 1;
+    for (int i = 0; i < n; ++i) launch();
+    const int tail = n / 10 + 1;
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < tail; ++i) launch();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double flops = (double)wgs * 4 * iters * (12 * TN) * (2.0 * 32 * 32 * 16);
+    printf("%-72s first %7.1f   settled %7.1f TFLOP/s = %.2f of 2516.8   (LDS %zu B)\n", name, flops / (ms1 * 1e-3) / 1e12, flops * tail / (ms * 1e-3) / 1e12,
+           flops * tail / (ms * 1e-3) / 1e12 / 2516.8, lds);
+}
+
+int main(int argc, char** argv) {
+    const int iters = argc > 1 ? atoi(argv[1]) : 1000;
+    const double seconds = argc > 2 ? atof(argv[2]) : 2.0;
+    std::vector<unsigned short> h(12 * 256 * 8);
+    for (auto& v : h) { const unsigned r = (unsigned)rand(); v = (unsigned short)(((r & 1) << 15) | ((126 + ((r >> 1) & 1)) << 7) | ((r >> 2) & 0x7f)); }
+    s16x8_t* d; float* o;
+    CK(hipMalloc(&d, h.size() * 2)); CK(hipMalloc(&o, (size_t)4096 * 256 * 4));
+    CK(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    run<2, false>(d, o, iters, seconds, "128 x 128 tile: 24 MFMA + 12 reads + barrier");
+    run<2, true>(d, o, iters, seconds, "128 x 128 tile: 24 MFMA + 12 reads + 44 split VALU + 6 writes + barrier");
+    run<4, false>(d, o, iters / 2, seconds, "128 x 256 tile: 48 MFMA + 18 reads + barrier");
+    run<4, true>(d, o, iters / 2, seconds, "128 x 256 tile: 48 MFMA + 18 reads + 44 split VALU + 6 writes + barrier");
+    return 0;
+}
