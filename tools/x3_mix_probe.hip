@@ -1,6 +1,7 @@
 // What would a 128 x 256 tile buy mocha_gemm_x3?  The instruction mix of one K step, without the memory side, at the two shapes:
-//   TN = 2 (shipped, 128 x 128 tile, wave = 64 x 64):  24 MFMAs, 12 ds_read_b128, 44 split VALU, 6 ds_write_b64, 1 barrier; 2 WGs / CU here (the probe keeps its plane writes beside the operands: 60 KB)
+//   TN = 2 (shipped, 128 x 128 tile, wave = 64 x 64):  24 MFMAs, 12 ds_read_b128, 44 split VALU, 6 ds_write_b64, 1 barrier; 3 WGs / CU
 //   TN = 4 (128 x 256 tile, wave = 64 x 128):          48 MFMAs, 18 ds_read_b128, 44 split VALU, 6 ds_write_b64, 1 barrier; 2 WGs / CU
+// optionally with the memory side of the step (two 16-byte activation loads per thread, the 12 KB x TN / 2 weight copy by LDS-DMA),
 // launched back to back for a few seconds (the board settles at the clock it holds under that load).  Operands are random bf16.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I mocha_sigasia2023_amd/csrc tools/x3_mix_probe.hip -o tools/bin/x3_mix_probe
 #include <hip/hip_runtime.h>
@@ -13,11 +14,11 @@ using namespace mocha;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int TN, bool SPLIT>
+template <int TN, bool SPLIT, int LOADS>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 2 ? 3 : 2, TN == 2 ? 3 : 2)))
-void mix(const s16x8_t* __restrict__ src, float* __restrict__ out, int iters) {
-    extern __shared__ __attribute__((aligned(16))) s16x8_t sm[];      // operands: (6 + 3 TN) x 256 fragments, then 6 x 256 x 8 B of plane writes
-    constexpr int NFRAG = 6 + 3 * TN;
+void mix(const s16x8_t* __restrict__ src, float* __restrict__ out, int iters, const float* __restrict__ act, const unsigned short* __restrict__ wimg) {
+    extern __shared__ __attribute__((aligned(16))) s16x8_t sm[];      // operands: 6 x 256 fragments, then 6 x 256 x 8 B of plane writes, then the copied weights
+    constexpr int NFRAG = 6;                          // six 4 KB fragment slots shared by the A and B reads (the counts are what matters)
     const int tid = threadIdx.x;
     for (int i = tid; i < NFRAG * 256; i += 256) sm[i] = src[i % (12 * 256)];
     u32x2_t* wr = reinterpret_cast<u32x2_t*>(sm + NFRAG * 256);
@@ -32,14 +33,35 @@ void mix(const s16x8_t* __restrict__ src, float* __restrict__ out, int iters) {
     float xs[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) xs[e] = 0.37f * (tid + 1) + e;
+    // the memory side of a K step (LOADS bit 0: the activation fetch, two 16-byte loads per thread from this workgroup's 128 rows of
+    // a (rows x 256) fp32 matrix, 64 bytes per row and step; bit 1: the weight copy, 12 KB x TN / 2 per step by LDS-DMA from an
+    // L2-resident image)
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(act + (size_t)(blockIdx.x % 800) * 128 * 256);
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(wimg + (size_t)(blockIdx.x & 1) * 16 * 6144 * (TN / 2));
+    const unsigned a_off = ((unsigned)(tid >> 2) * 256u + (tid & 3) * 4u) * 4u;
+    unsigned short* dma_dst = reinterpret_cast<unsigned short*>(sm + NFRAG * 256) + 6 * 256 * 4;      // after the plane writes
+    f32x4_t fa[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int it = 0; it < iters; ++it) {
+        if (LOADS & 2) {
+#pragma unroll
+            for (int j = 0; j < 3 * (TN / 2); ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dma_dst + (j * 4 + (tid >> 6)) * 512), 16,
+                                                         (unsigned)(j * 256 + tid) * 16u, (unsigned)(it & 15) * (6144u * 2u * (TN / 2)), 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (LOADS & 1) {
+            xs[0] += fa[0][0] + fa[1][1];              // consume the previous step's fetch
+            fa[0] = bload(rsA, a_off, (unsigned)(it & 15) * 64u);
+            fa[1] = bload(rsA, a_off + 64u * 256u * 4u, (unsigned)(it & 15) * 64u);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         s16x8_t a[3][2], b[3][TN];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[q][i] = sm[(q * 2 + i) * 256 + ((tid + it) & 255)];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[q][j] = sm[(6 + q * TN + j) * 256 + ((tid + 7 * it) & 255)];
+            for (int j = 0; j < TN; ++j) b[q][j] = sm[((q * TN + j) % 6) * 256 + ((tid + 7 * it + 64 * ((q * TN + j) / 6)) & 255)];
         }
         float x[8];
         unsigned pk[4][3], hi[4][2];
@@ -73,7 +95,8 @@ void mix(const s16x8_t* __restrict__ src, float* __restrict__ out, int iters) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (LOADS & 1) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int e = 0; e < 8; ++e) xs[e] += 0.001f;
     }
@@ -84,15 +107,15 @@ void mix(const s16x8_t* __restrict__ src, float* __restrict__ out, int iters) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += acc[i][j][r];
-    out[blockIdx.x * 256 + tid] = s + xs[0];
+    out[blockIdx.x * 256 + tid] = s + xs[0] + fa[0][2] + fa[1][3];
 }
 
-template <int TN, bool SPLIT>
-static void run(const s16x8_t* d, float* o, int iters, double seconds, const char* name) {
-    const size_t lds = (size_t)(6 + 3 * TN) * 256 * 16 + 6 * 256 * 8;
-    CK(hipFuncSetAttribute((const void*)mix<TN, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+template <int TN, bool SPLIT, int LOADS>
+static void run(const s16x8_t* d, float* o, int iters, double seconds, const char* name, const float* act, const unsigned short* wimg) {
+    const size_t lds = (size_t)6 * 256 * 16 + 6 * 256 * 8 + (size_t)12288 * (TN / 2);
+    CK(hipFuncSetAttribute((const void*)mix<TN, SPLIT, LOADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int wgs = 256 * (TN == 2 ? 3 : 2) * 2;
-    auto launch = [&]() { hipLaunchKernelGGL((mix<TN, SPLIT>), dim3(wgs), dim3(256), lds, 0, d, o, iters); };
+    auto launch = [&]() { hipLaunchKernelGGL((mix<TN, SPLIT, LOADS>), dim3(wgs), dim3(256), lds, 0, d, o, iters, act, wimg); };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     launch(); CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0, 0)); launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
@@ -117,9 +140,16 @@ int main(int argc, char** argv) {
     s16x8_t* d; float* o;
     CK(hipMalloc(&d, h.size() * 2)); CK(hipMalloc(&o, (size_t)4096 * 256 * 4));
     CK(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-    run<2, false>(d, o, iters, seconds, "128 x 128 tile: 24 MFMA + 12 reads + barrier");
-    run<2, true>(d, o, iters, seconds, "128 x 128 tile: 24 MFMA + 12 reads + 44 split VALU + 6 writes + barrier");
-    run<4, false>(d, o, iters / 2, seconds, "128 x 256 tile: 48 MFMA + 18 reads + barrier");
-    run<4, true>(d, o, iters / 2, seconds, "128 x 256 tile: 48 MFMA + 18 reads + 44 split VALU + 6 writes + barrier");
+    float* act; unsigned short* wimg;
+    CK(hipMalloc(&act, (size_t)800 * 128 * 256 * 4)); CK(hipMemset(act, 0, (size_t)800 * 128 * 256 * 4));       // 105 MB of activations (zeros: they only feed xs)
+    CK(hipMalloc(&wimg, (size_t)4 * 16 * 6144 * 2 * 2)); CK(hipMemset(wimg, 0, (size_t)4 * 16 * 6144 * 2 * 2));
+    run<2, false, 0>(d, o, iters, seconds, "128 x 128: 24 MFMA + 12 reads + barrier", act, wimg);
+    run<2, true, 0>(d, o, iters, seconds, "128 x 128: + 44 split VALU + 6 plane writes", act, wimg);
+    run<2, true, 1>(d, o, iters, seconds, "128 x 128: + split + activation fetch (8 KB / step)", act, wimg);
+    run<2, true, 2>(d, o, iters, seconds, "128 x 128: + split + weight copy by LDS-DMA (12 KB / step)", act, wimg);
+    run<2, true, 3>(d, o, iters, seconds, "128 x 128: + split + both (a K step of mocha_gemm_x3)", act, wimg);
+    run<4, false, 0>(d, o, iters / 2, seconds, "128 x 256: 48 MFMA + 18 reads + barrier", act, wimg);
+    run<4, true, 0>(d, o, iters / 2, seconds, "128 x 256: + 44 split VALU + 6 plane writes", act, wimg);
+    run<4, true, 3>(d, o, iters / 2, seconds, "128 x 256: + split + fetch (8 KB) + weight copy (24 KB)", act, wimg);
     return 0;
 }
