@@ -23,6 +23,8 @@
 //   * LDS image per plane (both operands): [k half][row][8 bf16] - the 16 lanes a ds_read_b128 serves together read 256 contiguous
 //     bytes; the halves are 64 bytes further apart than 2 KB so that the b64 plane stores of a 16-lane group (banked mod 32 dwords)
 //     cover all banks once.
+//   * Two more tile shapes from the same code (template parameters TM, TN): 64 x 128 for mid-size launches (twice the workgroups),
+//     128 x 64 for N = 64 / 192 (one 64-row half of a packed block per stage; 44 split instructions over 12 MFMAs).
 //   * K split over gridDim.z with raw partial sums per slab (the matcher's 23 040-long contraction).
 //   * Operands swapped as in gemm_f32.hip (C^T accumulators), same epilogue: transposition through LDS, whole-line stores.
 #include "kernels.h"
@@ -47,6 +49,14 @@ static constexpr int XB_PLANE = 128 * 16;               // 2048 bf16, [k half][r
 static constexpr int XB_OFF = 3 * XA_PLANE;             // B planes follow the A planes of a stage
 static constexpr int X_STAGE = XB_OFF + 3 * XA_PLANE;   // 13 056 bf16 = 26 112 B (the B planes use the padded A layout in LDS)
 static constexpr int XW_BLOCK = 3 * XB_PLANE;           // packed weights per (n tile, k step): 6144 bf16 = 12 KB
+// tile width 64 TN: the B planes of a stage hold 64 TN rows per k half (TN = 2: the layout above; TN = 1: one 64-row half of a packed block)
+template <int TN> struct XT {
+    static constexpr int TILE_N = 64 * TN;
+    static constexpr int B_HALF = TILE_N * 8 + 32;
+    static constexpr int B_PLANE = 2 * B_HALF;
+    static constexpr int STAGE = XB_OFF + 3 * B_PLANE;
+};
+static_assert(XT<2>::STAGE == X_STAGE && XT<2>::B_HALF == XA_HALF, "TN = 2 is the 128-wide layout");
 
 __device__ __forceinline__ float x3_lrelu(float x) { return x > 0.f ? x : 0.2f * x; }
 __device__ __forceinline__ float x3_gelu(float x) { return 0.5f * x * (1.0f + mocha_erf(x * 0.70710678118654752440f)); }
@@ -93,16 +103,20 @@ hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hip
 // Compile-time so that a K step is one basic block the scheduler can interleave.
 // TM: 32-row MFMA blocks per wave: 2 = the 128-row tile; 1 = a 64-row tile (four waves of 32 x 64) for mid-size launches
 // (a few dozen to a few hundred windows), where 128-row tiles would leave most workgroup slots empty.
-template <bool LRELU, bool GATHER, int TM>
+// TN: 32-column MFMA blocks per wave: 2 = the 128-wide tile; 1 = a 128 x 64 tile (waves of 64 x 32) for N = 64 / 192 (to_mot's joint
+// block), where a padded 128-wide tile would idle half the pipe.  (A 128 x 256 tile, TN = 4, was measured and not kept:
+// tools/experiments/gemm_x3_tile_128x256.patch.txt.)
+template <bool LRELU, bool GATHER, int TM, int TN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void mocha_gemm_x3(GemmParams p) {
     constexpr int TILE_M = TM * 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned short x3_sm[];          // [2][X_STAGE]
+    constexpr int TILE_N = XT<TN>::TILE_N, B_HALF = XT<TN>::B_HALF, B_PLANE = XT<TN>::B_PLANE, STAGE = XT<TN>::STAGE;
+    extern __shared__ __attribute__((aligned(16))) unsigned short x3_sm[];          // [2][STAGE]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
 
-    const int n_tiles = (p.N + XN - 1) / XN;
+    const int n_tiles = (p.N + TILE_N - 1) / TILE_N;
     const int m_tiles = (p.M + TILE_M - 1) / TILE_M;
     const int bid = blockIdx.x;
     int mt, nt;
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         nt = bid - mt * n_tiles;
     }
     if (mt >= m_tiles) return;
-    const int m0 = mt * TILE_M, n0 = nt * XN;
+    const int m0 = mt * TILE_M, n0 = nt * TILE_N;
     // K split over gridDim.z (the matcher's 23 040-long contraction): this workgroup takes steps s0 .. s0 + nsteps - 1 and writes raw
     // partial sums to slab blockIdx.z; the host guarantees at least two steps per slab
     const int steps_total = p.K / XK;
@@ -189,27 +203,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         }
     };
     // ---- W: linear copy of the packed 12 KB block of (nt, step) into the stage
-    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.Wsplit + ((size_t)nt * steps_total + s0) * XW_BLOCK);
+    const int wblock = TN == 1 ? nt >> 1 : nt;           // the packed image is in 128-column blocks; a 64-wide tile takes one half of one
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.Wsplit + ((size_t)wblock * steps_total + s0) * XW_BLOCK);
     auto dma_w = [&](int s, unsigned short* st) __attribute__((always_inline)) {
+        if (TN == 2) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-            // piece j * 4 + wave of the packed block = (plane, k half, 64-row half): same padded halves as the A planes
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + XB_OFF + ((j * 4 + wave) >> 2) * XA_PLANE +
-                                                     (((j * 4 + wave) >> 1) & 1) * XA_HALF + ((j * 4 + wave) & 1) * 512), 16,
-                                                     (unsigned)(j * 256 + tid) * 16u, (unsigned)s * (XW_BLOCK * 2u), 0, 0);
+            for (int j = 0; j < 3; ++j)
+                // piece j * 4 + wave of the packed block = (plane, k half, 64-row half): same padded halves as the A planes
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + XB_OFF + ((j * 4 + wave) >> 2) * B_PLANE +
+                                                         (((j * 4 + wave) >> 1) & 1) * B_HALF + ((j * 4 + wave) & 1) * 512), 16,
+                                                         (unsigned)(j * 256 + tid) * 16u, (unsigned)s * (XW_BLOCK * 2u), 0, 0);
+        } else {
+            // six 1 KB pieces (plane, k half) of this tile's 64-row half: waves 0 and 1 copy two, waves 2 and 3 one
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int pc = j * 4 + wave;                 // (plane, k half) = (pc >> 1, pc & 1)
+                if (pc < 6)                                  // wave-uniform
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + XB_OFF + (pc >> 1) * B_PLANE + (pc & 1) * B_HALF), 16,
+                                                             (unsigned)(((pc >> 1) * 4 + (pc & 1) * 2 + (nt & 1)) * 64 + lane) * 16u, (unsigned)s * (XW_BLOCK * 2u), 0, 0);
+            }
+        }
     };
 
-    f32x16 acc[TM][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // fragment of lane (row l31, k half hh): 16 bytes
     const int fa = hh * XA_HALF + (wm * TM * 32 + l31) * 8;
-    const int fb = XB_OFF + hh * XA_HALF + (wn * 64 + l31) * 8;
+    const int fb = XB_OFF + hh * B_HALF + (wn * 32 * TN + l31) * 8;
 
     // prologue: step 0 into stage 0, step 1's activations into registers.  The counted waits below (and in the steps) rely on the
     // issue order of the copies relative to the register fetches; both are independent loads to the scheduler, so they are fenced.
@@ -228,22 +254,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     auto step = [&](int s, auto parity, auto fetch_w, auto fetch_a) __attribute__((always_inline)) {
         constexpr bool FETCH_W = decltype(fetch_w)::value, FETCH_A = decltype(fetch_a)::value;
         constexpr int P = decltype(parity)::value;      // s & 1
-        unsigned short* cur = x3_sm + P * X_STAGE;
-        unsigned short* nxt = x3_sm + (P ^ 1) * X_STAGE;
+        unsigned short* cur = x3_sm + P * STAGE;
+        unsigned short* nxt = x3_sm + (P ^ 1) * STAGE;
         if (FETCH_W) dma_w(s + 1, nxt);             // first thing after the barrier: a whole step to land
         __builtin_amdgcn_sched_barrier(0);          // ... and older than this step's register fetches (counted wait at the end)
         // step s + 2's activations into the set step s's came from (split during step s - 1): a whole step to land, not the
         // few MFMAs left when the fetch waited for step s + 1's registers to be free (the latency was exposed on every step)
         if (FETCH_A) load_a(s + 2, rset[P]);
         __builtin_amdgcn_sched_barrier(0);
-        s16x8 a[3][TM], b[3][2];
+        s16x8 a[3][TM], b[3][TN];
         auto rd_a = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const s16x8*>(cur + q * XA_PLANE + fa + i * 32 * 8);
         };
         auto rd_b = [&](int q) __attribute__((always_inline)) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) b[q][i] = *reinterpret_cast<const s16x8*>(cur + q * XA_PLANE + fb + i * 32 * 8);
+            for (int i = 0; i < TN; ++i) b[q][i] = *reinterpret_cast<const s16x8*>(cur + q * B_PLANE + fb + i * 32 * 8);
         };
         rd_a(0); rd_b(2); rd_a(1); rd_b(1); rd_a(2); rd_b(0);           // in the order the products below consume them
         // Hand-interleaved issue order (fenced so that the scheduler keeps it): after every MFMA two of the 44 VALU instructions that
@@ -276,13 +302,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         };
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 12 * TM; ++m) {
-            const int pr = m / (2 * TM), pa = PLANE_PA[pr], pb = PLANE_PB[pr], i = (m >> 1) % TM, j = m & 1;
+        for (int m = 0; m < 6 * TM * TN; ++m) {
+            const int pr = m / (TM * TN), pa = PLANE_PA[pr], pb = PLANE_PB[pr], i = (m % (TM * TN)) / TN, j = m % TN;
             if (X3_MAXSUM == 2 || pr == 5)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[pb][j], a[pa][i], acc[i][j], 0, 0, 0);       // C^T tile
-            if (FETCH_W && m < 11 * TM) { split_op(2 * m); split_op(2 * m + 1); }
-            if (FETCH_W && m == 10) write_row(0);
-            if (FETCH_W && TM == 2 && m == 21) write_row(1);
+            if (TN == 2) {                              // 22 TM split instructions over the first 11 TM MFMAs
+                if (FETCH_W && m < 11 * TM) { split_op(2 * m); split_op(2 * m + 1); }
+                if (FETCH_W && m == 10) write_row(0);
+                if (FETCH_W && TM == 2 && m == 21) write_row(1);
+            } else {                                    // TN = 1, TM = 2: 44 split instructions over 11 of the 12 MFMAs
+                static_assert(TN == 2 || TM == 2, "the 64-wide tile is built for 128 rows");
+                if (FETCH_W && m < 11) { split_op(4 * m); split_op(4 * m + 1); split_op(4 * m + 2); split_op(4 * m + 3); }
+                if (FETCH_W && m == 5) write_row(0);
+                if (FETCH_W && m == 10) write_row(1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // the weights of step s + 1 have landed and this wave's plane writes are done; step s + 2's activations stay in flight
@@ -309,10 +342,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const __amdgpu_buffer_rsrc_t rsRb = make_rsrc(p.rowbias ? p.rowbias + n0 : p.A);
     const __amdgpu_buffer_rsrc_t rsRes = make_rsrc(p.residual ? p.residual + (size_t)m0 * p.ldr + n0 : p.A);
 
-    if (vec_ok && n0 + XN <= p.N) {
-        constexpr int LDP = XN + 4;
-        constexpr int C4 = XN / 4;
-        static_assert(64 * LDP * 4 <= 2 * X_STAGE * 2, "epilogue staging fits the operand stages");
+    if (vec_ok && n0 + TILE_N <= p.N) {
+        constexpr int LDP = TILE_N + 4;
+        constexpr int C4 = TILE_N / 4;
+        static_assert(64 * LDP * 4 <= 2 * STAGE * 2, "epilogue staging fits the operand stages");
         float* stage = reinterpret_cast<float*>(x3_sm);
 #pragma unroll
         for (int h = 0; h < TM; ++h) {                // 64 rows of the tile per pass
@@ -320,9 +353,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             for (int i = 0; i < TM; ++i) {
                 const int rblk = wm * TM + i;           // this wave's 32-row block of the tile
                 if ((rblk >> 1) != h) continue;         // wave-uniform
-                float* srow = stage + ((rblk & 1) * 32 + l31) * LDP + wn * 64 + 4 * hh;
+                float* srow = stage + ((rblk & 1) * 32 + l31) * LDP + wn * (32 * TN) + 4 * hh;
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
@@ -363,12 +396,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const float* rsrow = p.residual ? p.residual + (size_t)row * p.ldr : nullptr;
         float* crow = Cz + (size_t)row * p.ldc;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int c1 = n0 + wn * 64 + j * 32 + 8 * g + 4 * hh + e;
+                    const int c1 = n0 + wn * (32 * TN) + j * 32 + 8 * g + 4 * hh + e;
                     if (c1 >= p.N) continue;
                     float x = acc[i][j][4 * g + e];
                     if (p.bias) x += p.bias[c1];
@@ -382,22 +415,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
-static constexpr size_t x3_lds_bytes() { return (size_t)2 * X_STAGE * sizeof(unsigned short); }
+template <int TN> static constexpr size_t x3_lds_bytes() { return (size_t)2 * XT<TN>::STAGE * sizeof(unsigned short); }
 
-template <bool L, bool G, int TM>
+template <bool L, bool G, int TM, int TN>
 static hipError_t x3_attr() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3<L, G, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes());
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3<L, G, TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<TN>());
 }
 
 hipError_t gemm_x3_init() {
-    hipError_t e = x3_attr<false, false, 2>();
-    if (e == hipSuccess) e = x3_attr<true, false, 2>();
-    if (e == hipSuccess) e = x3_attr<false, true, 2>();
-    if (e == hipSuccess) e = x3_attr<true, true, 2>();
-    if (e == hipSuccess) e = x3_attr<false, false, 1>();
-    if (e == hipSuccess) e = x3_attr<true, false, 1>();
-    if (e == hipSuccess) e = x3_attr<false, true, 1>();
-    if (e == hipSuccess) e = x3_attr<true, true, 1>();
+    hipError_t e = x3_attr<false, false, 2, 2>();
+    if (e == hipSuccess) e = x3_attr<true, false, 2, 2>();
+    if (e == hipSuccess) e = x3_attr<false, true, 2, 2>();
+    if (e == hipSuccess) e = x3_attr<true, true, 2, 2>();
+    if (e == hipSuccess) e = x3_attr<false, false, 1, 2>();
+    if (e == hipSuccess) e = x3_attr<true, false, 1, 2>();
+    if (e == hipSuccess) e = x3_attr<false, true, 1, 2>();
+    if (e == hipSuccess) e = x3_attr<true, true, 1, 2>();
+    if (e == hipSuccess) e = x3_attr<false, false, 2, 1>();
+    if (e == hipSuccess) e = x3_attr<true, false, 2, 1>();
+    if (e == hipSuccess) e = x3_attr<false, true, 2, 1>();
+    if (e == hipSuccess) e = x3_attr<true, true, 2, 1>();
     return e;
 }
 
@@ -415,22 +452,23 @@ bool gemm_x3_supports(const GemmParams& p) {
         if ((per & 1) || total - (p.ksplit - 1) * per < 2 || ((total - (p.ksplit - 1) * per) & 1)) return false;   // every slab: an even number of steps, at least two
         return (long long)total * XW_BLOCK * 2 < (1ll << 31);
     }
-    if (p.N % XN != 0) return false;                // N = 64 / 192 (to_mot's joint block): a padded 128-wide tile loses to the exact-f32 128 x 64 tile (measured)
+    if (p.N % 64 != 0) return false;
+    if (p.N % XN != 0 && gemm_is_small(p)) return false;    // N = 64 / 192 (to_mot's joint block): the 64-wide tile exists for large launches only
     if (gemm_is_skinny(p)) return false;            // a handful of windows: latency-bound, mocha_gemm_skinny
     return true;
 }
 
-template <int TM>
+template <int TM, int TN>
 static void x3_launch(const GemmParams& p, hipStream_t s) {
     const int m_tiles = (p.M + TM * 64 - 1) / (TM * 64);
     const int m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
-    const dim3 grid(m_pad * ((p.N + XN - 1) / XN), 1, p.ksplit > 1 ? p.ksplit : 1);
+    const dim3 grid(m_pad * ((p.N + 64 * TN - 1) / (64 * TN)), 1, p.ksplit > 1 ? p.ksplit : 1);
     if (p.a_lrelu) {
-        if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3<true, true, TM>), grid, dim3(256), x3_lds_bytes(), s, p);
-        else hipLaunchKernelGGL((mocha_gemm_x3<true, false, TM>), grid, dim3(256), x3_lds_bytes(), s, p);
+        if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3<true, true, TM, TN>), grid, dim3(256), x3_lds_bytes<TN>(), s, p);
+        else hipLaunchKernelGGL((mocha_gemm_x3<true, false, TM, TN>), grid, dim3(256), x3_lds_bytes<TN>(), s, p);
     } else {
-        if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3<false, true, TM>), grid, dim3(256), x3_lds_bytes(), s, p);
-        else hipLaunchKernelGGL((mocha_gemm_x3<false, false, TM>), grid, dim3(256), x3_lds_bytes(), s, p);
+        if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3<false, true, TM, TN>), grid, dim3(256), x3_lds_bytes<TN>(), s, p);
+        else hipLaunchKernelGGL((mocha_gemm_x3<false, false, TM, TN>), grid, dim3(256), x3_lds_bytes<TN>(), s, p);
     }
 }
 
@@ -439,9 +477,11 @@ hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
     if (!p.Wsplit || !gemm_x3_supports(p)) return hipErrorInvalidValue;
     if (p.gather && (long long)p.M / p.T_out * p.T_src * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     if (128ll * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
-    // mid-size launches (fewer than 768 tiles of 128 x 64: a few dozen to a few hundred windows) take 64-row tiles, twice the workgroups
-    if (p.ksplit <= 1 && gemm_is_small(p)) x3_launch<1>(p, s);
-    else x3_launch<2>(p, s);
+    // mid-size launches (fewer than 768 tiles of 128 x 64: a few dozen to a few hundred windows) take 64-row tiles, twice the workgroups;
+    // N = 64 / 192 the 64-wide tile
+    if (p.ksplit <= 1 && p.N % XN != 0) x3_launch<2, 1>(p, s);
+    else if (p.ksplit <= 1 && gemm_is_small(p)) x3_launch<1, 2>(p, s);
+    else x3_launch<2, 2>(p, s);
     return hipGetLastError();
 }
 

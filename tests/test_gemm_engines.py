@@ -36,7 +36,8 @@ def _errors(model, x, w, b):
 
 
 @pytest.mark.parametrize("M,N,K,bias", [(105300, 256, 512, True), (105300, 512, 256, False), (30001, 256, 1280, True), (421200, 256, 192, False),
-                                        (200000, 128, 32, True), (98305, 384, 64, False)])      # the shortest K loops: two and four steps
+                                        (200000, 128, 32, True), (98305, 384, 64, False),       # the shortest K loops: two and four steps
+                                        (210001, 64, 320, True), (105300, 192, 256, False)])     # the 64-wide tile (to_mot's joint block)
 def test_plane_engine_is_as_accurate_as_f32_mfma(M, N, K, bias):
     g = torch.Generator(device="cpu").manual_seed(M + N + K)
     x = torch.randn((M, K), generator=g, dtype=torch.float32).to(dev())

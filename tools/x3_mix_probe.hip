@@ -1,5 +1,6 @@
 // What would a 128 x 256 tile buy mocha_gemm_x3?  The instruction mix of one K step, without the memory side, at the two shapes:
 //   TN = 2 (shipped, 128 x 128 tile, wave = 64 x 64):  24 MFMAs, 12 ds_read_b128, 44 split VALU, 6 ds_write_b64, 1 barrier; 3 WGs / CU
+//   TN = 1 (128 x 64 tile, wave = 64 x 32, shipped for N = 64 / 192): 12 MFMAs, 9 ds_read_b128, 44 split VALU, 6 ds_write_b64; 3 WGs / CU
 //   TN = 4 (128 x 256 tile, wave = 64 x 128):          48 MFMAs, 18 ds_read_b128, 44 split VALU, 6 ds_write_b64, 1 barrier; 2 WGs / CU
 // optionally with the memory side of the step (two 16-byte activation loads per thread, the 12 KB x TN / 2 weight copy by LDS-DMA),
 // launched back to back for a few seconds (the board settles at the clock it holds under that load).  Operands are random bf16.
@@ -15,7 +16,7 @@ using namespace mocha;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int TN, bool SPLIT, int LOADS>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 2 ? 3 : 2, TN == 2 ? 3 : 2)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 4 ? 2 : 3, TN == 4 ? 2 : 3)))
 void mix(const s16x8_t* __restrict__ src, float* __restrict__ out, int iters, const float* __restrict__ act, const unsigned short* __restrict__ wimg) {
     extern __shared__ __attribute__((aligned(16))) s16x8_t sm[];      // operands: 6 x 256 fragments, then 6 x 256 x 8 B of plane writes, then the copied weights
     constexpr int NFRAG = 6;                          // six 4 KB fragment slots shared by the A and B reads (the counts are what matters)
@@ -37,16 +38,16 @@ void mix(const s16x8_t* __restrict__ src, float* __restrict__ out, int iters, co
     // a (rows x 256) fp32 matrix, 64 bytes per row and step; bit 1: the weight copy, 12 KB x TN / 2 per step by LDS-DMA from an
     // L2-resident image)
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(act + (size_t)(blockIdx.x % 800) * 128 * 256);
-    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(wimg + (size_t)(blockIdx.x & 1) * 16 * 6144 * (TN / 2));
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(wimg + (size_t)(blockIdx.x & 1) * 16 * 3072 * TN);
     const unsigned a_off = ((unsigned)(tid >> 2) * 256u + (tid & 3) * 4u) * 4u;
     unsigned short* dma_dst = reinterpret_cast<unsigned short*>(sm + NFRAG * 256) + 6 * 256 * 4;      // after the plane writes
     f32x4_t fa[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int it = 0; it < iters; ++it) {
         if (LOADS & 2) {
 #pragma unroll
-            for (int j = 0; j < 3 * (TN / 2); ++j)
+            for (int j = 0; j < (3 * TN + 1) / 2; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(dma_dst + (j * 4 + (tid >> 6)) * 512), 16,
-                                                         (unsigned)(j * 256 + tid) * 16u, (unsigned)(it & 15) * (6144u * 2u * (TN / 2)), 0, 0);
+                                                         (unsigned)(j * 256 + tid) * 16u, (unsigned)(it & 15) * (6144u * TN), 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (LOADS & 1) {
@@ -90,7 +91,8 @@ void mix(const s16x8_t* __restrict__ src, float* __restrict__ out, int iters, co
             const int pr = m / (2 * TN), r = m % (2 * TN), i = r / TN, j = r % TN;
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[PLANE_PB[pr]][j], a[PLANE_PA[pr]][i], acc[i][j], 0, 0, 0);
             if (SPLIT) {
-                if (TN == 2) { if (m < 22) { split_op(2 * m); split_op(2 * m + 1); } if (m == 10) write_row(0); if (m == 21) write_row(1); }
+                if (TN == 1) { if (m < 11) { split_op(4 * m); split_op(4 * m + 1); split_op(4 * m + 2); split_op(4 * m + 3); } if (m == 5) write_row(0); if (m == 10) write_row(1); }
+                else if (TN == 2) { if (m < 22) { split_op(2 * m); split_op(2 * m + 1); } if (m == 10) write_row(0); if (m == 21) write_row(1); }
                 else { if (m < 44) split_op(m); if (m == 21) write_row(0); if (m == 43) write_row(1); }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -112,9 +114,9 @@ void mix(const s16x8_t* __restrict__ src, float* __restrict__ out, int iters, co
 
 template <int TN, bool SPLIT, int LOADS>
 static void run(const s16x8_t* d, float* o, int iters, double seconds, const char* name, const float* act, const unsigned short* wimg) {
-    const size_t lds = (size_t)6 * 256 * 16 + 6 * 256 * 8 + (size_t)12288 * (TN / 2);
+    const size_t lds = (size_t)6 * 256 * 16 + 6 * 256 * 8 + (size_t)6144 * TN + 2048;
     CK(hipFuncSetAttribute((const void*)mix<TN, SPLIT, LOADS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int wgs = 256 * (TN == 2 ? 3 : 2) * 2;
+    const int wgs = 256 * (TN == 4 ? 2 : 3) * 2;
     auto launch = [&]() { hipLaunchKernelGGL((mix<TN, SPLIT, LOADS>), dim3(wgs), dim3(256), lds, 0, d, o, iters, act, wimg); };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     launch(); CK(hipDeviceSynchronize());
@@ -148,6 +150,7 @@ int main(int argc, char** argv) {
     run<2, true, 1>(d, o, iters, seconds, "128 x 128: + split + activation fetch (8 KB / step)", act, wimg);
     run<2, true, 2>(d, o, iters, seconds, "128 x 128: + split + weight copy by LDS-DMA (12 KB / step)", act, wimg);
     run<2, true, 3>(d, o, iters, seconds, "128 x 128: + split + both (a K step of mocha_gemm_x3)", act, wimg);
+    run<1, true, 3>(d, o, iters * 2, seconds, "128 x  64: 12 MFMA + 9 reads + split + fetch (8 KB) + weight copy (8 KB)", act, wimg);
     run<4, false, 0>(d, o, iters / 2, seconds, "128 x 256: 48 MFMA + 18 reads + barrier", act, wimg);
     run<4, true, 0>(d, o, iters / 2, seconds, "128 x 256: + 44 split VALU + 6 plane writes", act, wimg);
     run<4, true, 3>(d, o, iters / 2, seconds, "128 x 256: + split + fetch (8 KB) + weight copy (24 KB)", act, wimg);
