@@ -259,10 +259,10 @@ hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, 
 // body_front: LeakyReLU then the body-part adjacency (commuted in front of the 1x1 conv):
 //   out[(f,w)][k*256+c] = sum_v A_b[k][v][w] lrelu(x[(f,v)][c])      (blocks.py:131, :64)
 // one thread per (frame f, 4 channels); the 72 coefficients are wave-uniform scalar loads.
-// No packed fp32 instructions here, and no LDS copy of the coefficients: the build that kept them in LDS and let the compiler form
-// v_pk_fma_f32 with op_sel (the low result taking the high register of a coefficient pair) intermittently produced 0 for that low
-// result in lanes 48-63 when workgroups of another stream's plane GEMM shared the CU - found with a re-run-and-compare hook in
-// the two-context test; either change alone made it disappear (tools/experiments/README.md, "two streams").
+// No packed fp32 instructions here: the build whose compiler-formed v_pk_fma_f32 took the HIGH register of a coefficient pair for
+// the low result (op_sel) intermittently produced 0 there, lanes 48-63, whenever workgroups of another stream's plane GEMM - bf16
+// MFMAs with ordinary VALU instructions issued between them - shared the CU (tools/body_front_repro.hip reproduces it standalone;
+// tools/experiments/README.md, "two streams").  The coefficients come from scalar loads, so no LDS and no barrier either.
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) MOCHA_NO_PACKED_F32
 void mocha_body_front(const float* __restrict__ x, const float* __restrict__ Ab, float* __restrict__ out, int frames) {
