@@ -25,6 +25,12 @@
  *   - several contexts of one process may be driven concurrently from different streams (tests/test_runtime_gpu.py runs two whole
  *     pipelines side by side on same-priority and on different-priority streams and compares them bit for bit with the sequential
  *     results); a context itself serves one call at a time.
+ *   - a platform hazard found in round 2, for applications that run THEIR OWN kernels on another stream while this library works:
+ *     a kernel that issues ordinary VALU instructions between bf16 MFMAs (the plane engines do) was observed to corrupt the results
+ *     of `v_pk_fma_f32 ... op_sel` (low result from a high VGPR) in OTHER kernels sharing its CU - lanes 48-63, value 0
+ *     (tools/body_front_repro.hip reproduces it without this library's pipeline).  The library's own device code is kept free of
+ *     that instruction pattern (tools/isa_lint.py).  If foreign kernels must overlap with the library's calls and may contain it,
+ *     order them after the library's stream, or run with mocha_set_option "gemm_bf16x3" = 0 and "attention_bf16x3" = 0.
  */
 #ifndef MOCHA_HIP_H
 #define MOCHA_HIP_H
