@@ -143,6 +143,9 @@ int main(int argc, char** argv) {
     for (auto& v : hx) v = (float)rand() / RAND_MAX * 2 - 1;
     for (int k = 0; k < 2; ++k) for (int v = 0; v < 6; ++v) for (int w = 0; w < 6; ++w)          // a sparse adjacency: self loops and neighbours
         hab[(k * 6 + v) * 6 + w] = (k == 0 ? (v == w ? 0.5f : 0.f) : ((v + 1) % 6 == w || (w + 1) % 6 == v ? 0.25f : 0.f));
+    const int cpat = argc > 5 ? atoi(argv[5]) : 0;             // coefficient pattern: 0 the sparse adjacency, 1 both halves of every register pair equal, 2 all distinct
+    if (cpat == 1) for (int i = 0; i < 72; ++i) hab[i] = 0.125f * (1 + i / 2);
+    if (cpat == 2) for (int i = 0; i < 72; ++i) hab[i] = 0.03125f * (1 + i);
     float *x, *ab, *o1, *o2; unsigned long long* bad;
     CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&ab, 72 * 4)); CK(hipMalloc(&o1, no * 4)); CK(hipMalloc(&o2, no * 4)); CK(hipMalloc(&bad, 8)); CK(hipMemset(bad, 0, 8));
     CK(hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(ab, hab.data(), 72 * 4, hipMemcpyHostToDevice));
@@ -200,5 +203,6 @@ int main(int argc, char** argv) {
     const char* an[17] = {"nothing beside it", "mocha_gemm_x3 on a second stream", "mocha_gemm_f32 on a second stream", "bf16 MFMA + LDS reads", "... + plane split (cvt_pk, ds_write)", "... + split + buffer loads", "... + split + LDS-DMA", "... + split + loads + LDS-DMA", "v_cvt_pk_bf16_f32 only", "v_lshlrev / v_and / v_sub_f32 only", "ds_write_b64 + ds_read only", "v_pk_mul_f32 only", "bf16 MFMA + v_cvt_pk_bf16_f32", "bf16 MFMA + v_lshlrev_b32", "bf16 MFMA + v_sub_f32", "bf16 MFMA + v_mov_b32", "bf16 MFMA + v_and_b32 (literal)"};
     const char* vn[6] = {"LDS coefficients at use + packed fmas (the original)", "LDS coefficients read up front + packed fmas", "LDS coefficients via readfirstlane + packed fmas", "LDS coefficients at use + scalar fmas", "coefficients by vector global loads + packed fmas", "LDS coefficient PAIRS read up front + packed fmas"};
     printf("%-52s | %-34s | %d x %d windows: %llu elements differ between two runs on the same input\n", vn[var], an[aggressor], reps, windows, hb);
+    if (cpat) printf("   (coefficient pattern %d: %s)\n", cpat, cpat == 1 ? "both halves of every coefficient pair equal" : "all coefficients distinct");
     return 0;
 }

@@ -24,6 +24,9 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void victim(unsigned long long* bad /*[8][2][4]*/, int iters, float seed) {
     const int lane = threadIdx.x & 63;
+#ifdef PROBE_BIG_ALLOC
+    asm volatile("v_mov_b32 v125, 0" ::: "v125");       // a 128-register allocation per wave, as mocha_body_front had: waves sit all over the 512-entry file
+#endif
     f32x2 a = {seed + 0.5f * lane, 1.25f + 0.25f * lane}, b = {2.0f + lane, -3.0f - 0.5f * lane}, c = {0.125f * lane, 7.0f};
     unsigned wrong[8][2] = {};
     for (int it = 0; it < iters; ++it) {
