@@ -250,7 +250,7 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * which removes two of the four projection GEMMs per decoder layer; 0 runs the four projections as written in
  * net/transformer.py:62-76.
  * "gemm_bf16x3" (default 1): the large GEMM launches (every nn.Linear / conv-as-GEMM of the path whose batch fills the chip
- * and whose output width is a multiple of 128) run on the bf16 matrix pipe with both fp32 operands carried as three bf16
+ * and whose output width is a multiple of 64) run on the bf16 matrix pipe with both fp32 operands carried as three bf16
  * planes and six MFMA passes per product, fp32 accumulation (gemm_x3.hip): every bf16 x bf16 product is exact in fp32 and
  * the dropped cross terms are below 2^-26 of a product, so the result is as accurate as an fp32 FMA chain (measured against
  * float64: slightly more accurate than the exact-f32 MFMA kernel, tests/test_gemm_engines.py).  0 = every GEMM on
