@@ -70,13 +70,26 @@ def parse():
     return ap.parse_args()
 
 
+def count_gpus():
+    """GPUs visible to a process with this environment, counted by a short-lived CHILD (torch.cuda.device_count() there):
+    the count honours *_VISIBLE_DEVICES and container device filtering exactly, and whatever the child initialises dies
+    with it - this process makes no HIP call."""
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+    try:
+        return int(out.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        raise SystemExit(f"bench.py: could not count GPUs: {out.stderr.strip()[-300:]}")
+
+
 def spawn_ranks(a):
     """`python bench.py --gpus N` without a launcher: start N fresh ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
-    MASTER_* set, rendezvous over 127.0.0.1) and wait for them.  This process has not touched a GPU and never will:
-    counting devices does not initialise HIP, and the children are new processes, not re-execs of this one."""
+    MASTER_* set, rendezvous over 127.0.0.1) and wait for them.  The children are new processes, not re-execs of this
+    one, and this process never uses a GPU: devices are counted by a child process too (torch.cuda.device_count() may fall
+    back to hipGetDeviceCount, which initialises the runtime)."""
     import socket
     import subprocess
-    n_dev = torch.cuda.device_count()
+    n_dev = count_gpus()
     if a.gpus > n_dev:
         raise SystemExit(f"bench.py --gpus {a.gpus}: this node exposes {n_dev} GPU(s)")
     with socket.socket() as sk:

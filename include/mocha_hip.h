@@ -167,6 +167,10 @@ int mocha_comm_unique_id(mocha_ctx* ctx, void* id128);
 int mocha_comm_init(mocha_ctx* ctx, const void* id128, int nranks, int rank);
 int mocha_comm_destroy(mocha_ctx* ctx);
 int mocha_bank_broadcast(mocha_ctx* ctx, void* comm, int root, int64_t N, int flags, void* stream);
+/* The plan mocha_bank_broadcast follows for one tensor of `count` floats over `world` ranks (host-side, pure; exposed so
+ * that the split can be tested without a GPU): out = {offset of this rank's chunk, chunk length, offset of the tail, tail
+ * length}.  Chunk r is scattered root -> r and all-gathered; the count % world tail is broadcast whole. */
+int mocha_bcast_plan(int64_t count, int world, int rank, int64_t out[4]);
 
 /* Pose normalisation of the demo fused into the path: the four norm.npz
  * arrays of the reference (test_fullframework.py:64-71), HOST fp32, (V+1)*C_in each with the root bone
@@ -272,6 +276,11 @@ int mocha_linear(mocha_ctx* ctx, const float* x, const float* w, const float* bi
 
 /* Introspection for tests and tooling. */
 int mocha_abi_version(void);
+/* Build provenance: the HIP toolchain libmocha_hip.so was compiled with ("hipcc HIP 7.2.26015-fc0010cf6a gfx950", static
+ * string) and the HIP runtime version of the process that loaded it (hipRuntimeGetVersion; no device needed).  The built
+ * library ships to the GPU box, whose ROCm may be older than the build container's: smoke() prints both. */
+const char* mocha_build_info(void);
+int mocha_runtime_version(void);
 /* Monotonic counter, bumped whenever the context replaces a device buffer a captured graph may hold (workspaces, match
  * scratch, CVAE workspace) or its current bank changes.  Host-side; no synchronisation. */
 int64_t mocha_generation(const mocha_ctx* ctx);

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmocha_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class mocha_cfg(C.Structure):
@@ -72,6 +72,9 @@ SIGNATURES = {
     "mocha_comm_init": (_i, [_vp, _vp, _i, _i]),
     "mocha_comm_destroy": (_i, [_vp]),
     "mocha_bank_broadcast": (_i, [_vp, _vp, _i, _i64, _i, _vp]),
+    "mocha_bcast_plan": (_i, [_i64, _i, _i, C.POINTER(_i64)]),
+    "mocha_build_info": (C.c_char_p, []),
+    "mocha_runtime_version": (_i, []),
     "mocha_profile_start": (_i, [_vp]),
     "mocha_profile_stop": (_i, [_vp, C.c_char_p, _i64]),
 }

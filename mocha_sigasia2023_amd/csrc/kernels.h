@@ -149,8 +149,9 @@ hipError_t launch_column_stats(const float* x, int64_t N, int cols, float* mean,
 hipError_t launch_rownorm2(const float* x, const float* sub /*or null*/, float* out, int64_t rows, int cols, hipStream_t s);
 hipError_t launch_sub_rows(const float* x, const float* sub, float* out, int64_t rows, int cols, hipStream_t s);
 // many-query matcher (match_mfma.hip): centred bf16 queries, one-plane bf16 coarse scores S[z][q][n] (K split z), and the
-// select kernel: top-8 coarse scores ||b-c||^2 - 2 S per query, exact re-rank in the direct form.  margin_rel < 0:
-// re-evaluate all 8 (bf16 coarse pass); >= 0: only candidates within margin_rel * (2||q-c||^2 + ||b-c||^2 + ||b0-c||^2) of the best.
+// select kernel: per query, EVERY row whose coarse score ||b-c||^2 - 2 S lies within margin_rel * (2||q-c||^2 + ||b-c||^2 +
+// ||b0-c||^2) of the best one (margin_rel >= 0 bounds the coarse pass's error; a negative value is rejected) is re-evaluated
+// exactly in the direct form; the smallest exact distance wins, ties to the lowest row.
 // bank = raw fp32 rows (exact distance sum (q - b)^2) or bank16 = centred bf16 rows (sum ((q - c) - b16)^2).
 hipError_t match_mfma_init();
 int match_bf16_ksplit(int Q, int64_t N);

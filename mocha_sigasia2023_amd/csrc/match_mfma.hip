@@ -236,7 +236,6 @@ hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S
 static constexpr int SEL_T = 1024, SEL_W = SEL_T / 64;
 static constexpr int SEL_CH = 4;                    // score chunks (of 4 * SEL_T rows) held in registers
 static constexpr int SEL_CAP = 128;                 // candidate list capacity per pass
-static constexpr int SEL_TOP = 8;                   // at most this many candidates of a list are re-evaluated
 
 
 __device__ __forceinline__ unsigned long long sel_key(float v, unsigned n) {          // order-preserving (value, index) key
@@ -431,20 +430,6 @@ __global__ __launch_bounds__(SEL_T) void mocha_match_select(const float* __restr
             __syncthreads();
             nc = ncand;
             if (nc == 0) continue;                               // uniform
-        }
-        // More than SEL_TOP rows inside the bound (it is a worst-case bound: the typical perturbation is ~sqrt(D) times
-        // smaller): the SEL_TOP best coarse scores of the list are re-evaluated, the others dropped.
-        if (nc > SEL_TOP) {                                      // uniform
-            int mine = 0, r = 0;
-            if (tid < nc) {
-                mine = cand[tid];
-                const float mv = candv[tid];
-                for (int i = 0; i < nc; ++i) r += candv[i] < mv || (candv[i] == mv && cand[i] < mine);
-            }
-            __syncthreads();
-            if (tid < nc && r < SEL_TOP) cand[r] = mine;
-            __syncthreads();
-            nc = SEL_TOP;
         }
         // rank sort by row index: the evaluation order (and with it every rounding) does not depend on the atomics' order
         if (tid < nc) {

@@ -138,7 +138,8 @@ struct mocha_ctx {
     float* center_scratch = nullptr;                        // fp64 partial column sums of launch_column_mean
     DevBuf match_qc[2];                                     // queries minus the centroid
     float* pair_norm = nullptr; size_t pair_norm_cap = 0;
-    float* pair_center = nullptr;                           // ... and its centroid      // row norms of the transient bank of mocha_characterize_pair
+    float* pair_center = nullptr;                           // row norms / centroid of the transient bank of mocha_characterize_pair
+    unsigned short* pair_x3 = nullptr; size_t pair_x3_cap = 0;     // ... and its packed plane image (never the user's bank_x3)
     int64_t bank_N = 0;
     // CVAE sampler (row N1): weights under "cvae.<reference key>", workspace for cvae_B conditions
     std::map<std::string, std::vector<int64_t>> cvae_expect;
@@ -406,7 +407,10 @@ int x3_image(mocha_ctx* c, hipStream_t s, const GemmParams& p, const unsigned sh
     return 0;
 }
 
+// A graph captured after warm-up has the image pointers baked into its mocha_gemm_x3 nodes: dropping them is a buffer
+// replacement like any other, so the generation moves and every holder re-captures.
 void x3_drop_images(mocha_ctx* c) {
+    if (!c->x3w.empty()) c->generation++;
     for (auto& kv : c->x3w) dev_free(c, reinterpret_cast<float*>(kv.second));
     c->x3w.clear();
 }
@@ -774,7 +778,17 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
 // =========================================================================================== C ABI
 extern "C" {
 
-int mocha_abi_version(void) { return 3; }
+int mocha_abi_version(void) { return 4; }
+
+#define MOCHA_STR2(x) #x
+#define MOCHA_STR(x) MOCHA_STR2(x)
+const char* mocha_build_info(void) {
+    return "hipcc HIP " MOCHA_STR(HIP_VERSION_MAJOR) "." MOCHA_STR(HIP_VERSION_MINOR) "." MOCHA_STR(HIP_VERSION_PATCH) "-" HIP_VERSION_GITHASH " gfx950";
+}
+int mocha_runtime_version(void) {
+    int v = 0;
+    return hipRuntimeGetVersion(&v) == hipSuccess ? v : -1;
+}
 
 int64_t mocha_generation(const mocha_ctx* c) { return c ? c->generation : 0; }
 
@@ -820,6 +834,7 @@ void mocha_destroy(mocha_ctx* c) {
     for (int set = 0; set < 2; ++set) { if (c->idx_ws[set]) (void)hipFree(c->idx_ws[set]); if (c->best_ws[set]) (void)hipFree(c->best_ws[set]); }
     if (c->bank_bf16) (void)hipFree(c->bank_bf16);
     if (c->bank_x3) (void)hipFree(c->bank_x3);
+    if (c->pair_x3) (void)hipFree(c->pair_x3);
     if (c->topk_keys) (void)hipFree(c->topk_keys);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1093,6 +1108,8 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
         c->bank_cnt = cnt_nm; c->bank_enc = encoded;
     } else {
         if (c->bank_cap < (size_t)N) {
+            if (c->bank_cnt == c->bank_cnt_own || c->bank_enc == c->bank_enc_own) { c->bank_cnt = nullptr; c->bank_enc = nullptr; c->bank_N = 0; c->generation++; }
+            c->bank_cap = 0;
             for (float** p : {&c->bank_cnt_own, &c->bank_enc_own})
                 if (*p) { dev_free(c, *p); *p = nullptr; }
             if ((rc = dev_alloc(c, &c->bank_cnt_own, (size_t)N * D))) return rc;
@@ -1269,9 +1286,14 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     if (cha_cnt_nm) HIPCHK(c, hipMemcpyAsync(cha_cnt_nm, WS(c, "qnm"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (B_src == 0) return 0;
     // transient bank: swap the context's bank state out, borrow the workspace rows, restore afterwards
-    struct Saved { const float *cnt, *enc; int64_t N; bool bf16; float* norm; size_t norm_cap; float* center; } sv{
-        c->bank_cnt, c->bank_enc, c->bank_N, c->bank_is_bf16, c->bank_norm, c->bank_norm_cap, c->bank_center};
+    // (everything bank_set_impl derives from a bank has a pair_* twin: norms, centroid, packed plane image - the user's
+    // current bank and what was derived from it are exactly as before when the call returns)
+    struct Saved { const float *cnt, *enc; int64_t N; bool bf16; float* norm; size_t norm_cap; float* center;
+                   unsigned short* x3; size_t x3_cap; bool x3_valid; } sv{
+        c->bank_cnt, c->bank_enc, c->bank_N, c->bank_is_bf16, c->bank_norm, c->bank_norm_cap, c->bank_center,
+        c->bank_x3, c->bank_x3_cap, c->bank_x3_valid};
     c->bank_norm = c->pair_norm; c->bank_norm_cap = c->pair_norm_cap; c->bank_center = c->pair_center;
+    c->bank_x3 = c->pair_x3; c->bank_x3_cap = c->pair_x3_cap; c->bank_x3_valid = false;
     rc = bank_set_impl(c, WS(c, "qnm"), WS(c, "enc_s"), B_cha, MOCHA_BANK_BORROW, stream, false);
     int32_t* ix = idx ? idx : c->idx_ws[0];
     if (!rc) rc = do_match(c, WS(c, "qnm") + (size_t)B_cha * T, B_src, ix, nullptr, s);
@@ -1280,6 +1302,8 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
         return 0;
     }();
     c->pair_norm = c->bank_norm; c->pair_norm_cap = c->bank_norm_cap; c->pair_center = c->bank_center;
+    c->pair_x3 = c->bank_x3; c->pair_x3_cap = c->bank_x3_cap;
+    c->bank_x3 = sv.x3; c->bank_x3_cap = sv.x3_cap; c->bank_x3_valid = sv.x3_valid;
     c->bank_cnt = sv.cnt; c->bank_enc = sv.enc; c->bank_N = sv.N; c->bank_is_bf16 = sv.bf16; c->bank_norm = sv.norm; c->bank_norm_cap = sv.norm_cap;
     c->bank_center = sv.center;
     if (rc) return rc;
@@ -1396,24 +1420,47 @@ int rccl_load(mocha_ctx* c) {
 // rank r (grouped point-to-point = scatter), then an in-place all-gather completes every rank's copy.  A flat
 // ncclBroadcast is a ring through the root's neighbours and bound by one link (~153 GB/s); scatter + all-gather moves
 // 1/world of the data per link and step.  The count % world tail (a few floats) goes through one small ncclBroadcast.
+// the plan of one chunked broadcast: rank r owns floats [r * chunk, (r + 1) * chunk), the last `tail` floats are broadcast whole
+struct BcastPlan { size_t chunk, tail, tail_off; };
+BcastPlan bcast_plan(size_t count, int world) {
+    BcastPlan p;
+    p.chunk = count / (size_t)world;
+    p.tail_off = p.chunk * (size_t)world;
+    p.tail = count - p.tail_off;
+    return p;
+}
+
 int bcast_chunked(mocha_ctx* c, ncclComm_t comm, int world, int rank, int root, float* buf, size_t count, hipStream_t s) {
     if (world == 1 || count == 0) return 0;
-    const size_t chunk = count / (size_t)world, tail = count - chunk * (size_t)world;
-    if (chunk > 0) {
+    const BcastPlan pl = bcast_plan(count, world);
+    if (pl.chunk > 0) {
+        // inside a group no call may return early: a group left open would swallow every later RCCL call of this thread.
+        // The first error is kept, the group is always closed.
+        ncclResult_t first = ncclSuccess;
+        const char* what = "";
+        auto keep = [&](ncclResult_t r, const char* w) { if (r != ncclSuccess && first == ncclSuccess) { first = r; what = w; } };
         NCCLCHK(c, g_rccl.GroupStart());
         if (rank == root) {
-            for (int r = 0; r < world; ++r)
-                if (r != root) NCCLCHK(c, g_rccl.Send(buf + chunk * (size_t)r, chunk, ncclFloat32, r, comm, s));
+            for (int r = 0; r < world && first == ncclSuccess; ++r)
+                if (r != root) keep(g_rccl.Send(buf + pl.chunk * (size_t)r, pl.chunk, ncclFloat32, r, comm, s), "ncclSend");
         } else {
-            NCCLCHK(c, g_rccl.Recv(buf + chunk * (size_t)rank, chunk, ncclFloat32, root, comm, s));
+            keep(g_rccl.Recv(buf + pl.chunk * (size_t)rank, pl.chunk, ncclFloat32, root, comm, s), "ncclRecv");
         }
-        NCCLCHK(c, g_rccl.GroupEnd());
-        NCCLCHK(c, g_rccl.AllGather(buf + chunk * (size_t)rank, buf, chunk, ncclFloat32, comm, s));
+        keep(g_rccl.GroupEnd(), "ncclGroupEnd");
+        if (first != ncclSuccess) return fail(c, MOCHA_ERR_HIP, "%s failed in the bank scatter: %s", what, g_rccl.GetErrorString(first));
+        NCCLCHK(c, g_rccl.AllGather(buf + pl.chunk * (size_t)rank, buf, pl.chunk, ncclFloat32, comm, s));
     }
-    if (tail > 0) NCCLCHK(c, g_rccl.Broadcast(buf + chunk * (size_t)world, buf + chunk * (size_t)world, tail, ncclFloat32, root, comm, s));
+    if (pl.tail > 0) NCCLCHK(c, g_rccl.Broadcast(buf + pl.tail_off, buf + pl.tail_off, pl.tail, ncclFloat32, root, comm, s));
     return 0;
 }
 }  // namespace
+
+int mocha_bcast_plan(int64_t count, int world, int rank, int64_t out[4]) {
+    if (count < 0 || world < 1 || rank < 0 || rank >= world || !out) return MOCHA_ERR_ARG;
+    const BcastPlan p = bcast_plan((size_t)count, world);
+    out[0] = (int64_t)(p.chunk * (size_t)rank); out[1] = (int64_t)p.chunk; out[2] = (int64_t)p.tail_off; out[3] = (int64_t)p.tail;
+    return 0;
+}
 
 int mocha_set_rccl_library(const char* path) {
     if (g_rccl.h) return MOCHA_ERR_STATE;              // already resolved: too late to switch
@@ -1468,6 +1515,9 @@ int mocha_bank_broadcast(mocha_ctx* c, void* comm_, int root, int64_t N, int fla
     } else {
         if (c->bank_cap < (size_t)N) {
             HIPCHK(c, hipDeviceSynchronize());
+            // the current bank may be the copy that is about to be freed: no dangling pointers if an allocation below fails
+            if (c->bank_cnt == c->bank_cnt_own || c->bank_enc == c->bank_enc_own) { c->bank_cnt = nullptr; c->bank_enc = nullptr; c->bank_N = 0; c->generation++; }
+            c->bank_cap = 0;
             for (float** p : {&c->bank_cnt_own, &c->bank_enc_own})
                 if (*p) { dev_free(c, *p); *p = nullptr; }
             if ((rc = dev_alloc(c, &c->bank_cnt_own, (size_t)N * D))) return rc;

@@ -84,3 +84,27 @@ def test_device_code_has_no_packed_fp32_op_sel_pattern():
     found = lint.scan(_C.LIB_PATH)
     bad = {k: v for k, v in found.items() if not any(a in k for a in lint.ALLOW)}
     assert not bad, bad
+
+
+def test_bcast_plan_covers_every_float_exactly_once():
+    """mocha_bank_broadcast's split (csrc/mocha_api.cpp: bcast_plan): `world` equal chunks, one per rank, contiguous from 0,
+    plus a count % world tail that is broadcast whole.  Pure host arithmetic, checked here for ragged counts."""
+    import ctypes as C
+    lib = _built()
+    out = (C.c_int64 * 4)()
+    for world in (1, 2, 3, 5, 8):
+        for count in (0, 1, 7, 23040, 23040 * 5, 23040 * 585, 23040 * 4096 + 3, (1 << 31) + 11):
+            cover = 0
+            for rank in range(world):
+                assert lib.mocha_bcast_plan(count, world, rank, out) == 0
+                off, chunk, toff, tail = list(out)
+                assert chunk == count // world and off == rank * chunk
+                assert toff == chunk * world and tail == count - toff and 0 <= tail < world
+                cover += chunk
+            assert cover + tail == count
+    assert lib.mocha_bcast_plan(10, 0, 0, out) != 0 and lib.mocha_bcast_plan(10, 2, 2, out) != 0 and lib.mocha_bcast_plan(-1, 2, 0, out) != 0
+
+
+def test_build_info_names_the_toolchain():
+    lib = _built()
+    assert lib.mocha_build_info().decode().startswith("hipcc HIP ")

@@ -2,9 +2,10 @@
 against the CPU oracle.
 
 * configs[1]  the demo pair, 585 source + 585 character windows (the workload bench.py times, same seeds), 22 and 24 joints,
-              through mocha_characterize_pair and through the three-call path: every large-batch GEMM instance
-              (<64,4,1,1,2> with residual / GELU / gathered epilogues, the matcher's <128,2,2,2,2>), both attention
-              instances and every pointwise kernel at the batch size the bench runs them at.  Reference call sites:
+              through mocha_characterize_pair and through the three-call path, on the DEFAULT engines: every instance of
+              the plane GEMM mocha_gemm_x3 (plain / gathered, residual / GELU / LeakyReLU epilogues, the matcher's K-split
+              coarse pass), both mocha_attention_x3 instances and every pointwise kernel at the batch size the bench runs
+              them at (the exact-f32 engines are compared with these in tests/test_gemm_engines.py).  Reference call sites:
               test_fullframework.py:188-194, 271-277, 293-298, 438-443, 465-467.
 * configs[2]  1024 source windows against a 4096-entry bf16 bank: indices against a float64 brute-force search over the
               bf16-rounded centred bank (the bank the kernel actually scans), agreement rate with the fp32 search reported.

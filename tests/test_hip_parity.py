@@ -225,6 +225,41 @@ def test_matcher_ranks_near_duplicate_rows_far_from_the_origin(Q):
     assert idx[0, 0].item() == N - 1
 
 
+@pytest.mark.parametrize("bf16", [False, True])
+def test_matcher_reevaluates_every_row_inside_the_error_bound(bf16):
+    """the select kernel used to keep only the 8 best coarse scores when more rows fell inside the coarse
+    pass's error bound.  A bank of 40 near-duplicates of each query (d^2 differing in the 4th digit, far below the bf16
+    pass's resolution) puts > 8 rows inside the bound; the answer must still be the exact search - float64 over the rows
+    the kernel scans (the bf16-rounded centred bank for bf16 banks), ties to the lowest index."""
+    _, _, model, _ = load(os.path.join(os.path.dirname(__file__), "golden"), "mocha24_g1")
+    r = np.random.Generator(np.random.PCG64(123))
+    D = 90 * 256
+    Q, dup = 24, 40
+    base = r.standard_normal((Q, D)).astype(np.float32)
+    rows = (base[:, None, :] + 0.01 * (1.0 + 0.001 * r.standard_normal((Q, dup, 1))) * r.standard_normal((Q, dup, D))).astype(np.float32)
+    bank = rows.reshape(Q * dup, D)
+    bank = bank[r.permutation(Q * dup)]
+    bank[5] = bank[700]                                       # an exact duplicate pair: the lower index must win
+    q = base
+    b = ContextBank(model, T(bank.reshape(-1, 90, 256)), T(bank.reshape(-1, 90, 256)), bf16=bf16)
+    dist, idx = b.query(T(q.reshape(Q, 90, 256)), k=1)
+    idx = idx[:, 0].cpu().numpy().astype(np.int64)
+    if bf16:
+        c = bank.astype(np.float64).mean(0).astype(np.float32)            # the library's centroid is the fp64 column mean, rounded once
+        scanned = torch.from_numpy(bank - c).to(torch.bfloat16).to(torch.float64).numpy()
+        qq = (q - c).astype(np.float64)
+    else:
+        scanned = bank.astype(np.float64); qq = q.astype(np.float64)
+    d2 = ((qq[:, None, :] - scanned[None, :, :]) ** 2).sum(-1) if Q * scanned.shape[0] * D < 3e8 else None
+    if d2 is None:
+        d2 = np.stack([((qq[i][None, :] - scanned) ** 2).sum(-1) for i in range(Q)])
+    ref = d2.argmin(1)
+    # fp32 evaluation of the exact distances: rows whose float64 distances agree to 1e-6 relative may legitimately swap
+    for i in range(Q):
+        assert idx[i] == ref[i] or abs(d2[i, idx[i]] - d2[i, ref[i]]) <= 2e-6 * d2[i, ref[i]], (i, idx[i], ref[i], d2[i, idx[i]], d2[i, ref[i]])
+    assert np.allclose(dist[:, 0].cpu().numpy() ** 2, d2[np.arange(Q), idx], rtol=1e-4)
+
+
 def test_bf16_bank_many_queries_agrees_with_fp32():
     """BASELINE configs[2] shape in small: bf16 bank, many queries; report-style agreement check."""
     sd = weights.synthetic_state_dict(9, 1.0)

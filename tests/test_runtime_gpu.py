@@ -243,3 +243,44 @@ def test_two_contexts_on_two_streams(planes, priority):
     runs after the streamer / sharded-bank tests of this file."""
     bad = _two_contexts(planes, priority)
     assert not bad, bad
+
+
+def test_pair_call_leaves_the_users_bank_image_alone(model):
+    """mocha_characterize_pair's transient bank used to repack the context's packed plane image of the
+    centred bank and leave it marked valid, so the next many-query match against the user's fp32 bank ranked the coarse
+    scores of the WRONG bank.  Interleaving: set a bank, run a pair call with another bank size, query with Q > 8."""
+    from oracle import mocha_oracle as O          # checker only
+    mean, std = _norm()
+    r = np.random.Generator(np.random.PCG64(5))
+    bank_nm = r.standard_normal((300, 90, 256)).astype(np.float32)
+    q = (bank_nm[r.integers(0, 300, 64)] + 0.05 * r.standard_normal((64, 90, 256))).astype(np.float32)
+    bank = ContextBank(model, torch.from_numpy(bank_nm), torch.from_numpy(bank_nm))
+    ref_idx, ref_dist = O.match_bruteforce(q, bank_nm)
+    d0, i0 = bank.query(torch.from_numpy(q))
+    assert np.array_equal(i0[:, 0].cpu().numpy().astype(np.int64), ref_idx)
+    g = model._ctx.generation()
+    model.characterize_pair(torch.from_numpy(synthetic.pose_windows(41, 40)), torch.from_numpy(synthetic.pose_windows(42, 77)), mean, std)
+    assert model._ctx.generation() == g
+    d1, i1 = bank.query(torch.from_numpy(q))                                                  # many-query path on the user's bank again
+    assert np.array_equal(i1[:, 0].cpu().numpy().astype(np.int64), ref_idx)
+    assert torch.equal(d0, d1)
+
+
+def test_reloading_weights_moves_the_generation_once_images_exist():
+    """finalising weights frees the packed plane images of the GEMM weights; a graph captured after
+    warm-up has those pointers baked in, so the generation must move."""
+    sd = weights.synthetic_state_dict(5, 1.0)
+    m = Generator(device="cuda:0").load_state_dict(sd).eval()
+    X = torch.from_numpy(synthetic.pose_windows(9, 64)).cuda()                                # large enough for the plane engine
+    m(X, X)
+    torch.cuda.synchronize()
+    g = m._ctx.generation()
+    m.load_state_dict(sd)
+    assert m._ctx.generation() > g
+
+
+def test_build_provenance_is_recorded(model):
+    lib = model._ctx.lib
+    info = lib.mocha_build_info().decode()
+    assert info.startswith("hipcc HIP ") and "gfx950" in info
+    assert lib.mocha_runtime_version() > 0
