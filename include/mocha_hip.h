@@ -158,7 +158,10 @@ int mocha_step_graph(mocha_ctx* ctx, const float* X1, const float* cnt_mean, con
  *                          ncclAllGather, so that every xGMI link of the root carries a share instead of one ring
  *                          neighbour carrying all of it; centroid, row norms and the optional bf16 copy (flags &
  *                          MOCHA_BANK_BF16) are recomputed locally.  `comm` = an ncclComm_t created by the same librccl,
- *                          or NULL for the context's own.  Collective; enqueued on `stream`.
+ *                          or NULL for the context's own.  Collective.  A 16-byte header {entries, bf16?} travels first
+ *                          and every rank checks it against its own N / flags (one stream synchronisation), so a root
+ *                          without that bank or a flags mismatch fails on ALL ranks instead of hanging the others; the
+ *                          payload is then enqueued on `stream`.
  *   mocha_set_rccl_library: which librccl to resolve (before the first mocha_comm_* call; process-wide).  A process that
  *                          already holds an RCCL - PyTorch wheels bundle their own copy - should name that file, so that one
  *                          RCCL instance serves the process; NULL / never called: "librccl.so.1" from the loader path. */
@@ -286,6 +289,13 @@ int mocha_runtime_version(void);
 int64_t mocha_generation(const mocha_ctx* ctx);
 int mocha_graph_constants(mocha_ctx* ctx, float* A_j /*3*V*V host*/, float* A_b /*2*6*6 host*/,
                           float* pool /*V*6 host*/, float* unpool /*6*V host*/);
+
+/* The current bank as the context holds it (device pointers, nothing is copied): the rows it matches against and gathers
+ * from, and what the library derived from them - the centroid (90*256), the squared norms of the centred rows (N), the
+ * centred bf16 copy (NULL for an fp32 bank).  Any out pointer may be NULL.  For tests that compare the ranks of a
+ * mocha_bank_broadcast bit for bit. */
+int mocha_bank_view(mocha_ctx* ctx, const float** cnt_nm, const float** encoded, const float** centroid, const float** row_norm2,
+                    const void** cnt_bf16, int64_t* N);
 
 /* Measurement support (bench.py roofline leg): between start and stop every kernel launch is
  * bracketed by a HIP event pair on its launch stream.  stop synchronises those events and

@@ -171,6 +171,7 @@ struct mocha_ctx {
     } step;
     hipStream_t cap_stream = nullptr;                 // capture happens on this internal stream (the caller's may be the null stream)
     ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 1;      // mocha_comm_init
+    long long* bcast_hdr = nullptr;                                     // device: {entries, bf16?} header of mocha_bank_broadcast
 
     // per-launch HIP-event profiling (mocha_profile_start/stop); off in normal operation
     struct ProfRec { std::string kernel, site; hipEvent_t e0, e1; double flops, bytes; };
@@ -835,6 +836,7 @@ void mocha_destroy(mocha_ctx* c) {
     if (c->bank_bf16) (void)hipFree(c->bank_bf16);
     if (c->bank_x3) (void)hipFree(c->bank_x3);
     if (c->pair_x3) (void)hipFree(c->pair_x3);
+    if (c->bcast_hdr) (void)hipFree(c->bcast_hdr);
     if (c->topk_keys) (void)hipFree(c->topk_keys);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -1507,12 +1509,27 @@ int mocha_bank_broadcast(mocha_ctx* c, void* comm_, int root, int64_t N, int fla
     if (root < 0 || root >= world || N < 1 || N > (int64_t)1 << 30) return fail(c, MOCHA_ERR_ARG, "bad bank_broadcast arguments");
     hipStream_t s = (hipStream_t)stream;
     const size_t D = 90 * 256;
+    const bool want_bf16 = (flags & MOCHA_BANK_BF16) != 0;
+    // Header first: the root announces {entries, bf16?} of the bank it is about to send (-1 entries: it has none of the size
+    // the call names), and EVERY rank checks it against its own arguments before any payload moves - a disagreement fails
+    // loudly on all ranks instead of leaving the others waiting in a collective the root never enters.
+    if (!c->bcast_hdr) HIPCHK(c, hipMalloc((void**)&c->bcast_hdr, 2 * sizeof(long long)));
+    long long hdr[2] = {-1, 0};
     if (rank == root) {
-        if (!c->bank_cnt || c->bank_N != N) return fail(c, MOCHA_ERR_STATE, "root has no current bank of %lld entries", (long long)N);
-        if (c->bank_is_bf16 != ((flags & MOCHA_BANK_BF16) != 0))
-            return fail(c, MOCHA_ERR_ARG, "root's bank was set %s MOCHA_BANK_BF16 but the broadcast asks for the opposite: every rank must match against the same bank",
-                        c->bank_is_bf16 ? "with" : "without");
-    } else {
+        hdr[0] = (c->bank_cnt && c->bank_N == N) ? (long long)N : -1;
+        hdr[1] = c->bank_is_bf16 ? 1 : 0;
+        HIPCHK(c, hipMemcpyAsync(c->bcast_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, s));
+    }
+    if (world > 1) NCCLCHK(c, g_rccl.Broadcast(c->bcast_hdr, c->bcast_hdr, 2, ncclInt64, root, comm, s));
+    HIPCHK(c, hipMemcpyAsync(hdr, c->bcast_hdr, sizeof hdr, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    if (hdr[0] != (long long)N)
+        return fail(c, MOCHA_ERR_STATE, "bank_broadcast: the root (rank %d) has no current bank of %lld entries (it announced %lld)", root,
+                    (long long)N, hdr[0]);
+    if ((hdr[1] != 0) != want_bf16)
+        return fail(c, MOCHA_ERR_ARG, "bank_broadcast: the root's bank was set %s MOCHA_BANK_BF16 but rank %d asks for the opposite: every "
+                    "rank must match against the same bank", hdr[1] ? "with" : "without", rank);
+    if (rank != root) {
         if (c->bank_cap < (size_t)N) {
             HIPCHK(c, hipDeviceSynchronize());
             // the current bank may be the copy that is about to be freed: no dangling pointers if an allocation below fails
@@ -1886,6 +1903,19 @@ int mocha_linear(mocha_ctx* c, const float* x, const float* w, const float* bias
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(img);
     if (e != hipSuccess) return fail(c, MOCHA_ERR_HIP, "mocha_linear: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int mocha_bank_view(mocha_ctx* c, const float** cnt_nm, const float** encoded, const float** centroid, const float** row_norm2,
+                    const void** cnt_bf16, int64_t* N) {
+    if (!c) return MOCHA_ERR_ARG;
+    if (!c->bank_cnt || c->bank_N <= 0) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
+    if (cnt_nm) *cnt_nm = c->bank_cnt;
+    if (encoded) *encoded = c->bank_enc;
+    if (centroid) *centroid = c->bank_center;
+    if (row_norm2) *row_norm2 = c->bank_norm;
+    if (cnt_bf16) *cnt_bf16 = c->bank_is_bf16 ? c->bank_bf16 : nullptr;
+    if (N) *N = c->bank_N;
     return 0;
 }
 

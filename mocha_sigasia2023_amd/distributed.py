@@ -46,11 +46,21 @@ def shard_bounds(n_items: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def _host_staged() -> bool:
+    """True when the default group cannot move device tensors (gloo): collectives then go through host copies."""
+    return dist.is_initialized() and dist.get_backend() == "gloo"
+
+
 def broadcast_(tensors: Iterable[torch.Tensor], src: int = 0) -> None:
     """In-place broadcast of the bank tensors (cnt_nm, encoded, cnt norm, or the raw character clip)."""
     if dist.is_initialized():
         for t in tensors:
-            dist.broadcast(t, src=src)
+            if _host_staged() and t.is_cuda:
+                h = t.cpu()
+                dist.broadcast(h, src=src)
+                t.copy_(h)
+            else:
+                dist.broadcast(t, src=src)
 
 
 def init_comm(model) -> None:
@@ -60,8 +70,12 @@ def init_comm(model) -> None:
     rank, _, world = env_rank()
     if getattr(model, "_comm_ready", False):
         return
-    # one RCCL per process: PyTorch bundles its own copy (the one torch.distributed's "nccl" backend drives); use it if present
-    bundled = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    # one RCCL per process: PyTorch bundles its own copy (the one torch.distributed's "nccl" backend drives); use it if present.
+    # MOCHA_RCCL_LIBRARY names another file (the tests load a shared-memory stand-in to run several ranks on one GPU).
+    override = os.environ.get("MOCHA_RCCL_LIBRARY")
+    bundled = override or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    if override and not os.path.exists(override):
+        raise RuntimeError(f"MOCHA_RCCL_LIBRARY={override}: no such file")
     if os.path.exists(bundled):
         model._ctx.lib.mocha_set_rccl_library(bundled.encode())        # status -3 = already resolved: keep what is loaded
     buf = (C.c_char * 128)()
@@ -94,7 +108,8 @@ def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
         return local
     world = dist.get_world_size()
     biggest = -(-n_total // world)
-    pad = torch.zeros((biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    cdev = torch.device("cpu") if _host_staged() else local.device
+    pad = torch.zeros((biggest,) + tuple(local.shape[1:]), dtype=local.dtype, device=cdev)
     pad[: local.shape[0]] = local
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad)
@@ -102,13 +117,13 @@ def all_gather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     for r, p in enumerate(parts):
         lo, hi = shard_bounds(n_total, world, r)
         out.append(p[: hi - lo])
-    return torch.cat(out)
+    return torch.cat(out).to(local.device)
 
 
 def max_over_ranks(value: float, device: torch.device) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=torch.device("cpu") if _host_staged() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

@@ -245,11 +245,12 @@ def test_two_contexts_on_two_streams(planes, priority):
     assert not bad, bad
 
 
-def test_pair_call_leaves_the_users_bank_image_alone(model):
+def test_pair_call_leaves_the_users_bank_image_alone():
     """mocha_characterize_pair's transient bank used to repack the context's packed plane image of the
     centred bank and leave it marked valid, so the next many-query match against the user's fp32 bank ranked the coarse
     scores of the WRONG bank.  Interleaving: set a bank, run a pair call with another bank size, query with Q > 8."""
     from oracle import mocha_oracle as O          # checker only
+    model = Generator(device="cuda:0").load_state_dict(weights.synthetic_state_dict(11, 1.0)).eval()
     mean, std = _norm()
     r = np.random.Generator(np.random.PCG64(5))
     bank_nm = r.standard_normal((300, 90, 256)).astype(np.float32)
@@ -258,6 +259,8 @@ def test_pair_call_leaves_the_users_bank_image_alone(model):
     ref_idx, ref_dist = O.match_bruteforce(q, bank_nm)
     d0, i0 = bank.query(torch.from_numpy(q))
     assert np.array_equal(i0[:, 0].cpu().numpy().astype(np.int64), ref_idx)
+    model.reserve(128)                                                                        # workspace for the pair below: no growth inside it
+    bank.query(torch.from_numpy(q))
     g = model._ctx.generation()
     model.characterize_pair(torch.from_numpy(synthetic.pose_windows(41, 40)), torch.from_numpy(synthetic.pose_windows(42, 77)), mean, std)
     assert model._ctx.generation() == g
