@@ -104,7 +104,7 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
 //   xad = (1+gamma)*IN(x)+beta ; qin = IN(xad) ; gb (B,512) = [gamma | beta]
 hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin, int B, int n, hipStream_t s);
 // u rows (b,t',p) x (dt*256+c) = 1/4 sum of the 4 reflect-indexed frames of tap dt (conv k=5 fused with AvgPool(4))
-hipError_t launch_window_sums(const float* ybar, float* u, int rows /*B*90*/, hipStream_t s);
+hipError_t launch_window_sums(const float* y, float* u, int rows, int channels /*256 or 192*/, hipStream_t s);
 // ---- CVAE sampler pieces (cvae.hip; model_CVAE.py)
 // y = LayerNorm(x) over 256 channels per row (eps 1e-5, biased variance), affine
 hipError_t launch_layernorm256(const float* x, const float* w, const float* b, float* y, int rows, hipStream_t s);

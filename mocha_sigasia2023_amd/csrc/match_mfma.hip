@@ -406,6 +406,8 @@ __global__ __launch_bounds__(SEL_T) void mocha_match_select(const float* __restr
     __syncthreads();
     total = ncand;
     const bool windowed = total > SEL_CAP;                       // uniform
+    int wpc = SEL_W;                                             // waves per candidate row: 16 / pow2(min(candidates, 16))
+    while (wpc > 1 && wpc * (total < SEL_W ? total : SEL_W) > SEL_W) wpc >>= 1;
     const long long nwin = windowed ? (N + SEL_CAP - 1) / SEL_CAP : 1;
 
     for (long long w = 0; w < nwin; ++w) {
@@ -439,11 +441,12 @@ __global__ __launch_bounds__(SEL_T) void mocha_match_select(const float* __restr
             csort[r] = mine;
         }
         __syncthreads();
-        // ---- 4. exact squared distances: passes of up to 16 candidates, 16 / pow2(candidates) waves each
-        for (int p0 = 0; p0 < nc; p0 += SEL_W) {
-            const int nb = nc - p0 < SEL_W ? nc - p0 : SEL_W;
-            int wpc = SEL_W;                                     // waves per candidate
-            while (wpc > 1 && wpc * nb > SEL_W) wpc >>= 1;
+        // ---- 4. exact squared distances: passes of up to 16 candidates.  The number of waves that share a row fixes the order
+        // its terms are summed in, so it is chosen ONCE per query (from the total candidate count): every candidate of the query is
+        // evaluated in the same order and identical rows get identical distances (ties then go to the lowest index).
+        for (int p0 = 0; p0 < nc; p0 += SEL_W / wpc) {
+            const int per = SEL_W / wpc;
+            const int nb = nc - p0 < per ? nc - p0 : per;
             const int ci = wave / wpc, sub = wave % wpc;
             float a = 0.f;
             if (ci < nb) {                                       // uniform per wave

@@ -153,6 +153,7 @@ struct mocha_ctx {
     bool attn_x3 = true;               // the Generator's attention as plane products on the bf16 pipe (attention_x3.hip)
     std::map<std::tuple<const float*, int, int>, unsigned short*> x3w;
     bool fold_decoder = true;          // decoder key / value projections folded into the query / output weights
+    bool fold_joint = true;            // embedding joint block: gcn 1x1 conv folded into the k=5 temporal conv (one K = 960 GEMM)
     bool gather_pool = false;          // AvgPool(4) folded into the k=5 temporal conv's A gather instead of mocha_window_sums
     bool fuse_tail = false; int fuse_tail_min_rows = 8192;      // out-proj + FF in one launch (xf_tail.hip) from this many token rows on
     int* bone_parents = nullptr;       // device: parents of the (V+1)-bone skeleton with the root bone in front
@@ -332,7 +333,7 @@ int ensure_ws(mocha_ctx* c, int B) {
         {"hbar", 360 * 192}, {"ybar", 360 * 256}, {"u", 90 * 1280}, {"x5", T}, {"xA", 90 * 512}, {"t1", T}, {"xa", T}, {"xb", T},
         {"qkv", 90 * 3072}, {"ao", 90 * 1024}, {"hff", 90 * 512}, {"kin", T}, {"xad", T}, {"qin", T},
         {"smean", 256}, {"s1", 512}, {"gb", 512}, {"g", 90 * 192}, {"y2c", (size_t)15 * V * 64},
-        {"z", (size_t)60 * V * 64}, {"enc_s", T}, {"enc_c", T}, {"cnt", T}, {"qnm", T}, {"sel", T}, {"dec", T},
+        {"z", (size_t)60 * V * 64}, {"enc_s", T}, {"enc_c", T}, {"qnm", T}, {"sel", T}, {"dec", T},
     };
     // free old workspaces
     for (int set = 0; set < 2; ++set) {
@@ -468,6 +469,15 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
                                   c->cfg.C_in, raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s, c->gemm_x3));
         b += b2;
     }
+    if (c->fold_joint && !c->gather_pool) {
+        // gcn conv folded into the temporal conv (mocha_finalize_weights: emb.Wc): the 4-frame sums of the five taps are taken on
+        // the 192 adjacency-mixed channels and ONE GEMM, K = 5 x 192, does both convolutions and the AvgPool
+        LAUNCH(c, s, "mocha_window_sums", "emb.window_sums", b * 90.0 * 960 * 4, b * 4.0 * (360.0 * 192 + 90.0 * 960),
+               launch_window_sums(WS(c, "hbar"), WS(c, "u"), b * 90, 192, s));
+        GemmParams gf = plain(WS(c, "u"), 960, DW(c, "emb.Wc"), WS(c, "x5"), 256, b * 90, 256, 960);
+        gf.rowbias = DW(c, "emb.rbc"); gf.rb_mod = 6;
+        GEMM(c, s, "emb.joint_block", gf);
+    } else {
     // gcn 1x1 conv on the pooled operand: (b*360, 192) x (256,192)^T + pooled bias
     GemmParams g1 = plain(WS(c, "hbar"), 192, DW(c, "emb.Wg"), WS(c, "ybar"), 256, b * 360, 256, 192);
     g1.rowbias = DW(c, "emb.rbg"); g1.rb_mod = 6;
@@ -482,9 +492,10 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
         g2.tshift = 0; g2.Cc = 256; g2.T_src = 60; g2.ascale = 0.25f;
     } else {
         LAUNCH(c, s, "mocha_window_sums", "emb.window_sums", b * 90.0 * 1280 * 4, b * 4.0 * (360.0 * 256 + 90.0 * 1280),
-               launch_window_sums(WS(c, "ybar"), WS(c, "u"), b * 90, s));
+               launch_window_sums(WS(c, "ybar"), WS(c, "u"), b * 90, 256, s));
     }
     GEMM(c, s, "emb.tcn_joint_pool", g2);
+    }
     // body block                                                               model.py:48,137-162
     LAUNCH(c, s, "mocha_body_front", "emb.body_front", b * 90.0 * 512 * 12, b * 90.0 * (256 + 512) * 4, launch_body_front(WS(c, "x5"), DW(c, "A_b"), WS(c, "xA"), b * 15, s));
     GemmParams g3 = plain(WS(c, "xA"), 512, DW(c, "emb.Wgb"), WS(c, "t1"), 256, b * 90, 256, 512);
@@ -917,6 +928,33 @@ int mocha_finalize_weights(mocha_ctx* c) {
     }
     up("emb.Wt", repack_tcn(W(c, "mot_embedding.2.blk.tcn.weight"), 256, 256, 5));
     up("emb.bt", W(c, "mot_embedding.2.blk.tcn.bias"));
+    {
+        // The joint block applies its 1x1 gcn conv and its k=5 temporal conv back to back (net/blocks.py:126-134: norm and
+        // activation act on the block's INPUT, nothing sits between gcn and tcn), so the two compose into one linear map on the
+        // pooled, adjacency-mixed 3 x 64 channels: per tap  Wc_tap = Wt_tap (256 x 256) · Wg (256 x 192),  K = 5 x 192 = 960
+        // instead of a K = 192 GEMM at 4x the rows plus a K = 1280 one.  fp64, rounded once.
+        //   Wc[co][tap*192 + j] = sum_c Wt[co][tap*256 + c] Wg[c][j];   rbc[p][co] = bt[co] + sum_tap sum_c Wt[co][tap*256 + c] rbg[p][c]
+        // (the gcn bias is constant over frames, so reflect padding and the 4-frame mean leave it a per-part constant)
+        const std::vector<float> Wt = repack_tcn(W(c, "mot_embedding.2.blk.tcn.weight"), 256, 256, 5);
+        const std::vector<float> Wg = repack_gcn_adjfirst(W(c, "mot_embedding.2.blk.gcn.conv.weight"), 3, 256, 64);
+        const auto& bg = W(c, "mot_embedding.2.blk.gcn.conv.bias");
+        const auto& bt = W(c, "mot_embedding.2.blk.tcn.bias");
+        std::vector<double> Wc((size_t)256 * 960, 0.0), rbc(6 * 256, 0.0), rbg(6 * 256, 0.0);
+        for (int p = 0; p < 6; ++p)
+            for (int cc = 0; cc < 256; ++cc) { double a = 0; for (int k = 0; k < 3; ++k) a += (double)bg[k * 256 + cc] * APsum[k * 6 + p]; rbg[p * 256 + cc] = a; }
+        for (int co = 0; co < 256; ++co)
+            for (int tap = 0; tap < 5; ++tap) {
+                double* row = &Wc[(size_t)co * 960 + tap * 192];
+                for (int cc = 0; cc < 256; ++cc) {
+                    const double wt = Wt[(size_t)co * 1280 + tap * 256 + cc];
+                    const float* g = &Wg[(size_t)cc * 192];
+                    for (int j = 0; j < 192; ++j) row[j] += wt * (double)g[j];
+                    for (int p = 0; p < 6; ++p) rbc[p * 256 + co] += wt * rbg[p * 256 + cc];
+                }
+            }
+        for (int p = 0; p < 6; ++p) for (int co = 0; co < 256; ++co) rbc[p * 256 + co] += (double)bt[co];
+        up("emb.Wc", f32(Wc)); up("emb.rbc", f32(rbc));
+    }
     for (int which = 0; which < 2; ++which) {
         const std::string src = which ? "to_mot.1.blk." : "mot_embedding.5.blk.";
         const std::string dst = which ? "mot." : "emb.";
@@ -1242,7 +1280,7 @@ static int characterize_impl(mocha_ctx* c, const float* src_X, int B, const floa
         int32_t* ix = idx ? idx + b0 : c->idx_ws[c->cur];
         if ((r = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s, raw))) return r;
         if ((r = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return r;
-        LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * 3, launch_instnorm(WS(c, "enc_s"), WS(c, "cnt"), nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s));
+        LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * 2, launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s));
         if ((r = do_match(c, WS(c, "qnm"), b, ix, nullptr, s))) return r;
         LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, b * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), b, 90 * 256, c->bank_N, s));
         if ((r = run_decoder(c, WS(c, "enc_s"), WS(c, "sel"), b, WS(c, "dec"), s))) return r;
@@ -1282,8 +1320,8 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     // character windows first: rows [0, B_cha) of every buffer are the bank, rows [B_cha, B) the queries
     if ((rc = run_embed(c, cha_X, B_cha, WS(c, "x5"), true, s, raw, src_X, B_src))) return rc;
     if ((rc = run_encoder(c, WS(c, "x5"), B, WS(c, "enc_s"), s))) return rc;
-    LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * 3,
-           launch_instnorm(WS(c, "enc_s"), WS(c, "cnt"), nullptr, cnt_mean, cnt_std, WS(c, "qnm"), B, 90, s));
+    LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * 2,
+           launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), B, 90, s));
     if (cha_encoded) HIPCHK(c, hipMemcpyAsync(cha_encoded, WS(c, "enc_s"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (cha_cnt_nm) HIPCHK(c, hipMemcpyAsync(cha_cnt_nm, WS(c, "qnm"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (B_src == 0) return 0;
@@ -1870,6 +1908,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     }
     if (n == "dual_min") { c->dual_min = value < 2 ? 2 : value; return 0; }
     if (n == "fold_decoder") { c->fold_decoder = value != 0; return 0; }
+    if (n == "fold_joint") { c->fold_joint = value != 0; return 0; }
     if (n == "fuse_tail") { c->fuse_tail = value != 0; return 0; }
     if (n == "gather_pool") { c->gather_pool = value != 0; return 0; }
     if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; return 0; }

@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64 * IN_NG) void mocha_instnorm(const float* __rest
         if (i < cnt) {
             const int t = g + IN_NG * i;
             const f32x4 v = (xv[i] - mean) / den;
-            ob[(size_t)t * 64] = v;
+            if (out) ob[(size_t)t * 64] = v;                   // out == nullptr: only the z-scored copy is wanted (characterize: cnt itself is not an output)
             if (zn) {
                 const f32x4 m = reinterpret_cast<const f32x4*>(gm)[t * 64 + q], sd = reinterpret_cast<const f32x4*>(gs)[t * 64 + q];
                 (reinterpret_cast<f32x4*>(zn + (size_t)b * n * 256) + q)[(size_t)t * 64] = (v - m) / sd;
@@ -495,23 +495,26 @@ hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin,
 
 // ---------------------------------------------------------------------------------------
 // window_sums: operand of the joint temporal conv fused with AvgPool2d((4,1)) (blocks.py:112-118, model.py:47):
-//   u[(b,t',p)][dt*256 + c] = 1/4 * sum_{j<4} y[(b, refl(4t'+j+dt-2, 60), p)][c],   dt = 0..4
+//   u[(b,t',p)][dt*C + c] = 1/4 * sum_{j<4} y[(b, refl(4t'+j+dt-2, 60), p)][c],   dt = 0..4
+// on the C = 256 gcn outputs, or - with the gcn conv folded into the temporal conv's weights (mocha_api.cpp: emb.Wc) - on the
+// C = 192 adjacency-mixed inputs of the gcn conv.
 // The five overlapping 4-frame windows of one output row share 8 input frames, and consecutive output rows share 4.
 // One thread owns a (window, body part, channel quad) and walks the 15 output frames with a sliding register window of 8
 // input frames (4 new ones per step), so every input frame is fetched once (PMC had shown 2x the input bytes from HBM when
 // each output row fetched its own 8 frames).
 // ---------------------------------------------------------------------------------------
+template <int CQ /* channel quads per row: 64 (256 channels) or 48 (192) */>
 __global__ __launch_bounds__(256) void mocha_window_sums(const float* __restrict__ y, float* __restrict__ u, int rows /*B*15*6*/) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int bp = gid >> 6, q = gid & 63;              // bp = b * 6 + pp
+    const int bp = gid / CQ, q = gid - bp * CQ;         // bp = b * 6 + pp
     if (bp * 15 >= rows) return;
     const int b = bp / 6, pp = bp - b * 6;
-    const f32x4* yb = reinterpret_cast<const f32x4*>(y) + ((size_t)b * 60 * 6 + pp) * 64 + q;
-    f32x4* ub = reinterpret_cast<f32x4*>(u) + ((size_t)b * 15 * 6 + pp) * 5 * 64 + q;
+    const f32x4* yb = reinterpret_cast<const f32x4*>(y) + ((size_t)b * 60 * 6 + pp) * CQ + q;
+    f32x4* ub = reinterpret_cast<f32x4*>(u) + ((size_t)b * 15 * 6 + pp) * 5 * CQ + q;
     auto frame = [&](int t) __attribute__((always_inline)) {
         t = t < 0 ? -t : t;
         t = t > 59 ? 118 - t : t;                        // reflect padding (blocks.py:112-118)
-        return yb[(size_t)t * 6 * 64];
+        return yb[(size_t)t * 6 * CQ];
     };
     f32x4 f[8];
 #pragma unroll
@@ -520,17 +523,19 @@ __global__ __launch_bounds__(256) void mocha_window_sums(const float* __restrict
     for (int t15 = 0; t15 < 15; ++t15) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { f[i] = f[4 + i]; f[4 + i] = frame(4 * t15 + 2 + i); }
-        f32x4* ur = ub + (size_t)t15 * 6 * 5 * 64;
+        f32x4* ur = ub + (size_t)t15 * 6 * 5 * CQ;
 #pragma unroll
-        for (int dt = 0; dt < 5; ++dt) ur[dt * 64] = (((f[dt] + f[dt + 1]) + f[dt + 2]) + f[dt + 3]) * 0.25f;
+        for (int dt = 0; dt < 5; ++dt) ur[dt * CQ] = (((f[dt] + f[dt + 1]) + f[dt + 2]) + f[dt + 3]) * 0.25f;
     }
 }
 
-hipError_t launch_window_sums(const float* y, float* u, int rows, hipStream_t s) {
+hipError_t launch_window_sums(const float* y, float* u, int rows, int channels, hipStream_t s) {
     if (rows <= 0) return hipSuccess;
-    if (rows % 90) return hipErrorInvalidValue;          // whole windows: 15 frames x 6 parts
-    const long long threads = (long long)(rows / 15) * 64;
-    hipLaunchKernelGGL(mocha_window_sums, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, y, u, rows);
+    if (rows % 90 || (channels != 256 && channels != 192)) return hipErrorInvalidValue;          // whole windows: 15 frames x 6 parts
+    const long long threads = (long long)(rows / 15) * (channels / 4);
+    const dim3 grid((unsigned)((threads + 255) / 256));
+    if (channels == 256) hipLaunchKernelGGL(mocha_window_sums<64>, grid, dim3(256), 0, s, y, u, rows);
+    else hipLaunchKernelGGL(mocha_window_sums<48>, grid, dim3(256), 0, s, y, u, rows);
     return hipGetLastError();
 }
 

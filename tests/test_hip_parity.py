@@ -361,6 +361,28 @@ def test_decoder_projection_folding_is_only_rounding(golden_dir, name):
     assert float((folded - literal).abs().max()) < 1e-5 * float(literal.abs().max())
 
 
+@pytest.mark.parametrize("name", VARIANTS)
+def test_joint_block_folding_is_only_rounding(golden_dir, name):
+    """Default path: the embedding joint block's 1x1 gcn conv folded into its k=5 temporal conv (net/blocks.py:126-134 applies
+    them back to back; mocha_set_option "fold_joint").  Folded and literal two-GEMM forms both meet the fixture tolerance and
+    agree with each other to fp32 rounding, at fixture size and on a batch large enough for the plane engine."""
+    z, meta, model, _ = load(golden_dir, name)
+    X = T(z["src_X"])
+    folded = model.mot_embedding(X)
+    model.set_option("fold_joint", 0)
+    literal = model.mot_embedding(X)
+    model.set_option("fold_joint", 1)
+    assert rel(folded, z["src_tokens"]) < RTOL and rel(literal, z["src_tokens"]) < RTOL
+    assert not torch.equal(folded, literal)
+    assert float((folded - literal).abs().max()) < 1e-5 * float(literal.abs().max())
+    big = T(synthetic.pose_windows(17, 96, X.shape[2]))
+    f2 = model.mot_embedding(big)
+    model.set_option("fold_joint", 0)
+    l2 = model.mot_embedding(big)
+    model.set_option("fold_joint", 1)
+    assert float((f2 - l2).abs().max()) < 1e-5 * float(l2.abs().max())
+
+
 def test_characterize_pair_matches_the_three_call_path():
     """mocha_characterize_pair = encode(cha) + bank_set + characterize(src) with shared launches: same indices, outputs equal
     up to the kernel choice of a larger batch (<= 2e-6 relative), the context's own bank untouched, oracle parity."""
