@@ -28,8 +28,14 @@
  *   - a platform hazard found in round 2, for applications that run THEIR OWN kernels on another stream while this library works:
  *     a kernel that issues ordinary VALU instructions between bf16 MFMAs (the plane engines do) was observed to corrupt the results
  *     of `v_pk_fma_f32 ... op_sel` (low result from a high VGPR) in OTHER kernels sharing its CU - lanes 48-63, value 0
- *     (tools/body_front_repro.hip reproduces it without this library's pipeline).  The library's own device code is kept free of
- *     that instruction pattern (tools/isa_lint.py).  If foreign kernels must overlap with the library's calls and may contain it,
+ *     (tools/body_front_repro.hip reproduces it without this library's pipeline).  What is established by test, not by guess
+ *     (tests/test_concurrency_stress.py, run on every GPU test pass): under that aggressor - large-batch plane GEMMs and plane
+ *     attention streaming from a second context - the round-2 build of the affected kernel (kept as a test-only canary) differs
+ *     from its solo result in more than half of 3 000 repetitions, while EVERY kernel class of this library, each repeated 1 000
+ *     times on same- and different-priority streams, reproduces its solo result bit for bit - including the kernels that use
+ *     packed fp32 arithmetic by design (mocha_match_stream) or by the compiler's choice (GEMM epilogues, window sums, norms).
+ *     tools/isa_lint.py additionally keeps the one pattern that failed (low result from the HIGH register of a VGPR pair) out
+ *     of the library's device code.  If foreign kernels must overlap with the library's calls and may contain that pattern,
  *     order them after the library's stream, or run with mocha_set_option "gemm_bf16x3" = 0 and "attention_bf16x3" = 0.
  */
 #ifndef MOCHA_HIP_H

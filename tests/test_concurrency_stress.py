@@ -106,6 +106,67 @@ def victims():
     return out
 
 
+def _run_beside(agg, fn, solo, reps, prios=(0, -1), burst=6, per_burst=20):
+    """Repeat `fn` on a victim stream while the aggressor's work is in flight on another; count repetitions that differ from `solo`."""
+    s_agg = torch.cuda.Stream()
+    bad = {}
+    for prio in prios:
+        s_vic = torch.cuda.Stream(priority=prio)
+        n_bad = done = 0
+        while done < reps:
+            agg.enqueue(s_agg, burst)                    # ~2 ms of plane GEMMs / attention per call in flight
+            batch = []
+            with torch.cuda.stream(s_vic):
+                for _ in range(per_burst):
+                    batch.append(_clone(fn()))
+            torch.cuda.synchronize()
+            n_bad += sum(0 if _bitwise(b, solo) else 1 for b in batch)
+            done += len(batch)
+        bad[prio] = (n_bad, done)
+    return bad
+
+
+def test_harness_detects_the_round2_canary():
+    """Sensitivity of this harness: the round-2 build of mocha_body_front (tests/canary/canary.hip: LDS-fed coefficients, packed
+    fp32 with op_sel on a high register) must FAIL under it, exactly as it did in the pipeline; the shipped kernel, same input and
+    same harness, must not.  Without this the test below would prove nothing."""
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "canary")
+    lib_path = os.path.join(here, "libmocha_canary.so")
+    if not os.path.exists(lib_path) or os.path.getmtime(lib_path) < os.path.getmtime(os.path.join(here, "canary.hip")):
+        subprocess.run(["make", "-C", here], check=True)
+    lib = C.CDLL(lib_path)
+    lib.canary_body_front_launch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    agg = Aggressor()
+    frames = 300 * 15                                           # 300 windows, the size of the round-2 reproduction
+    x = torch.from_numpy(synthetic.token_features(5, 300)).cuda()
+    Ab = torch.from_numpy(weights.synthetic_state_dict(5, 1.0)["mot_embedding.5.A_b"]).cuda().contiguous()
+    out = torch.empty((frames * 6, 512), dtype=torch.float32, device="cuda:0")
+
+    def canary():
+        rc = lib.canary_body_front_launch(x.data_ptr(), Ab.data_ptr(), out.data_ptr(), frames, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        return out
+    canary(); torch.cuda.synchronize()
+    solo = out.clone()
+    for _ in range(50):                                         # alone on the chip it is deterministic
+        canary(); torch.cuda.synchronize()
+        assert _bitwise(out, solo)
+    bad = _run_beside(agg, canary, solo, 1500)
+    total_bad = sum(b for b, _ in bad.values())
+    print(f"canary: repetitions differing from the solo result by victim-stream priority: {bad}")
+    assert total_bad > 0, f"the harness no longer reproduces the round-2 failure with the canary kernel: {bad}"
+    # the shipped kernel on the same input, through the library (to_mot's first stage is mocha_body_front on the tokens)
+    m = Generator(device="cuda:0").load_state_dict(weights.synthetic_state_dict(5, 1.0)).eval()
+    fn = lambda: m.to_mot(x)
+    fn(); torch.cuda.synchronize()
+    solo2 = fn().clone(); torch.cuda.synchronize()
+    bad2 = _run_beside(agg, fn, solo2, 400)
+    assert sum(b for b, _ in bad2.values()) == 0, bad2
+
+
 def test_every_kernel_is_bit_stable_beside_the_plane_gemm_aggressor():
     agg = Aggressor()
     vic = victims()
@@ -117,21 +178,8 @@ def test_every_kernel_is_bit_stable_beside_the_plane_gemm_aggressor():
         again = fn(); torch.cuda.synchronize()
         assert _bitwise(again, solo[name]), f"{name}: not even run-to-run deterministic on an idle chip"
     failures = {}
-    s_agg = torch.cuda.Stream()
-    for prio in (0, -1):
-        s_vic = torch.cuda.Stream(priority=prio)
-        for name, fn in vic.items():
-            bad = 0
-            done = 0
-            while done < REPS // 2:
-                agg.enqueue(s_agg, 6)                    # ~12 ms of plane GEMMs / attention in flight
-                batch = []
-                with torch.cuda.stream(s_vic):
-                    for _ in range(20):
-                        batch.append(_clone(fn()))
-                torch.cuda.synchronize()
-                bad += sum(0 if _bitwise(b, solo[name]) else 1 for b in batch)
-                done += len(batch)
+    for name, fn in vic.items():
+        for prio, (bad, done) in _run_beside(agg, fn, solo[name], REPS // 2).items():
             if bad:
                 failures[f"{name} (victim stream priority {prio})"] = f"{bad} of {done} repetitions differ from the solo result"
     assert not failures, failures
