@@ -152,6 +152,14 @@ int mocha_characterize(mocha_ctx* ctx, const float* src_X, int B, const float* c
  * that stays valid between calls.  `stream` may be the null stream (capture runs on an internal stream). */
 int mocha_step_graph(mocha_ctx* ctx, const float* X1, const float* cnt_mean, const float* cnt_std, float* Y1, int32_t* idx,
                      int raw, void* stream);
+/* The same step on one of the context's LANES (mocha_set_option "lanes" = 1..3; lane 0 is mocha_step_graph).  Every lane has
+ * its own workspace set, match scratch and captured graph, so the steps of up to three consecutive windows can be in flight
+ * at once, each on its own stream: windows are independent (test_fullframework.py:148-158) and the step alternates a
+ * latency-bound chain of small kernels (encode, decode) with an HBM-bound bank scan, so window i + 1's chains run under
+ * window i's scan.  The caller gives every lane its own X1 / Y1 / idx buffers and stream; results of one lane are ordered by
+ * that stream as usual.  Weights and the bank are shared and read-only. */
+int mocha_step_graph_lane(mocha_ctx* ctx, int lane, const float* X1, const float* cnt_mean, const float* cnt_std, float* Y1,
+                          int32_t* idx, int raw, void* stream);
 
 /* Multi-GPU set-up: one process per GPU, windows sharded across ranks, the character bank replicated.
  * The reference has no counterpart (trainer.py:45-47 is nn.DataParallel); the only exchange on the path is this one-time

@@ -67,6 +67,7 @@ SIGNATURES = {
     "mocha_graph_constants": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "mocha_generation": (_i64, [_vp]),
     "mocha_step_graph": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mocha_step_graph_lane": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mocha_set_rccl_library": (_i, [C.c_char_p]),
     "mocha_comm_unique_id": (_i, [_vp, _vp]),
     "mocha_comm_init": (_i, [_vp, _vp, _i, _i]),

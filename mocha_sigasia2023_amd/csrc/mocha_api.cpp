@@ -122,12 +122,17 @@ struct mocha_ctx {
     // Two workspace sets: large batches are split in two halves that run on two HIP streams (the caller's and
     // `aux`), so that the prologue / epilogue / tail of one half's kernels overlaps the other half's MFMA phases
     // (+5..10 % measured); `cur` selects the set the pipelines below write to.
-    std::map<std::string, DevBuf> wss[2];
+    static constexpr int MAX_SETS = 3;
+    std::map<std::string, DevBuf> wss[MAX_SETS];
     int cur = 0;
+    // Lanes: up to three per-window steps in flight at once (mocha_step_graph_lane; BASELINE configs[4] pipelined).  Lane k
+    // owns workspace set k (sets beyond the first are sized for a handful of windows unless dual_stream needs set 1 whole) and
+    // its own captured graph; `lane` is the set the single-stream pipelines below write to.
+    int lanes = 1, lane = 0;
     bool dual_stream = false; int dual_min = 128;     // opt-in: mocha_set_option(ctx, "dual_stream", 1) or MOCHA_DUAL_STREAM=1
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    DevBuf match_S[2];
-    int32_t* idx_ws[2] = {nullptr, nullptr}; size_t idx_ws_n = 0;
+    DevBuf match_S[MAX_SETS];
+    int32_t* idx_ws[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t idx_ws_n = 0;
 
     // bank
     const float* bank_cnt = nullptr;
@@ -136,7 +141,7 @@ struct mocha_ctx {
     float* bank_norm = nullptr; size_t bank_norm_cap = 0;
     float* bank_center = nullptr;                           // centroid of the matching bank (90*256), see do_match
     float* center_scratch = nullptr;                        // fp64 partial column sums of launch_column_mean
-    DevBuf match_qc[2];                                     // queries minus the centroid
+    DevBuf match_qc[MAX_SETS];                                     // queries minus the centroid
     float* pair_norm = nullptr; size_t pair_norm_cap = 0;
     float* pair_center = nullptr;                           // row norms / centroid of the transient bank of mocha_characterize_pair
     unsigned short* pair_x3 = nullptr; size_t pair_x3_cap = 0;     // ... and its packed plane image (never the user's bank_x3)
@@ -161,7 +166,7 @@ struct mocha_ctx {
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
     // fp32 banks of up to X3_BANK_MAX rows also keep the plane engine's packed image of the centred bank (many-query matching)
     unsigned short* bank_x3 = nullptr; size_t bank_x3_cap = 0; bool bank_x3_valid = false;
-    unsigned long long* best_ws[2] = {nullptr, nullptr}; size_t best_ws_n[2] = {0, 0};
+    unsigned long long* best_ws[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t best_ws_n[MAX_SETS] = {0, 0, 0};
     unsigned long long* topk_keys = nullptr; size_t topk_keys_n = 0;       // every row's key of up to 8 queries (mocha_match_topk)
 
     // captured per-window step (mocha_step_graph): one executable graph, re-captured when its key changes
@@ -169,7 +174,7 @@ struct mocha_ctx {
         hipGraphExec_t exec = nullptr; hipGraph_t graph = nullptr;
         const void *x = nullptr, *mean = nullptr, *sd = nullptr; void *y = nullptr, *idx = nullptr;
         int64_t generation = -1; bool raw = false;
-    } step;
+    } step[MAX_SETS];
     hipStream_t cap_stream = nullptr;                 // capture happens on this internal stream (the caller's may be the null stream)
     ncclComm_t comm = nullptr; int comm_rank = 0, comm_size = 1;      // mocha_comm_init
     long long* bcast_hdr = nullptr;                                     // device: {entries, bf16?} header of mocha_bank_broadcast
@@ -336,23 +341,26 @@ int ensure_ws(mocha_ctx* c, int B) {
         {"z", (size_t)60 * V * 64}, {"enc_s", T}, {"enc_c", T}, {"qnm", T}, {"sel", T}, {"dec", T},
     };
     // free old workspaces
-    for (int set = 0; set < 2; ++set) {
+    for (int set = 0; set < mocha_ctx::MAX_SETS; ++set) {
         for (auto& kv : c->wss[set]) {
             dev_free(c, kv.second.p);
         }
         c->wss[set].clear();
         if (c->idx_ws[set]) { (void)hipFree(c->idx_ws[set]); c->idx_ws[set] = nullptr; }
     }
-    const int nsets = (c->dual_stream && want >= c->dual_min / 2) ? 2 : 1;
+    const bool dual_sets = c->dual_stream && want >= c->dual_min / 2;
+    const int nsets = std::max(dual_sets ? 2 : 1, c->lanes);
     for (int set = 0; set < nsets; ++set) {
+        // a lane's set serves per-window steps: a handful of windows; dual_stream's second set takes half of every large batch
+        const int wset = (set == 0 || (set == 1 && dual_sets)) ? want : std::min(want, 8);
         for (auto& pl : plan) {
-            DevBuf b; b.n = pl.second * (size_t)want;
+            DevBuf b; b.n = pl.second * (size_t)wset;
             int rc = dev_alloc(c, &b.p, b.n);
             if (rc) return rc;
             c->wss[set][pl.first] = b;
         }
         void* ip = nullptr;
-        HIPCHK(c, hipMalloc(&ip, sizeof(int32_t) * (size_t)want));
+        HIPCHK(c, hipMalloc(&ip, sizeof(int32_t) * (size_t)wset));
         c->idx_ws[set] = (int32_t*)ip;
     }
     c->idx_ws_n = want;
@@ -638,7 +646,7 @@ template <class F>
 int for_chunks(mocha_ctx* c, int B, hipStream_t s, F&& fn) {
     const bool dual = c->dual_stream && B >= c->dual_min && !c->wss[1].empty();
     if (!dual) {
-        c->cur = 0;
+        c->cur = c->lane;
         for (int b0 = 0; b0 < B; b0 += c->chunk) { int rc = fn(b0, std::min(c->chunk, B - b0), s); if (rc) return rc; }
         return 0;
     }
@@ -692,6 +700,12 @@ static constexpr int64_t X3_BANK_MAX = 4096;       // rows: the packed image of 
 int match_ksplit(int Q, int64_t N) {
     const long long tiles = (long long)((Q + 127) / 128) * ((N + 127) / 128);
     return (int)std::min<long long>(16, std::max<long long>(1, (768 + tiles - 1) / tiles));
+}
+
+// windows workspace set `set` holds (ensure_ws): the chunk for set 0 and dual_stream's set 1, a handful for a lane's set
+int set_windows(const mocha_ctx* c, int set) {
+    const bool dual_sets = c->dual_stream && c->chunk >= c->dual_min / 2;
+    return (set == 0 || (set == 1 && dual_sets)) ? std::max(c->chunk, 8) : 8;
 }
 
 // Scratch of do_match for up to Q queries against N bank rows, in workspace set `set`: centred queries, the streaming
@@ -843,7 +857,7 @@ void mocha_destroy(mocha_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (float* p : c->owned) (void)hipFree(p);
-    for (int set = 0; set < 2; ++set) { if (c->idx_ws[set]) (void)hipFree(c->idx_ws[set]); if (c->best_ws[set]) (void)hipFree(c->best_ws[set]); }
+    for (int set = 0; set < mocha_ctx::MAX_SETS; ++set) { if (c->idx_ws[set]) (void)hipFree(c->idx_ws[set]); if (c->best_ws[set]) (void)hipFree(c->best_ws[set]); }
     if (c->bank_bf16) (void)hipFree(c->bank_bf16);
     if (c->bank_x3) (void)hipFree(c->bank_x3);
     if (c->pair_x3) (void)hipFree(c->pair_x3);
@@ -853,8 +867,10 @@ void mocha_destroy(mocha_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->bone_parents) (void)hipFree(c->bone_parents);
-    if (c->step.exec) (void)hipGraphExecDestroy(c->step.exec);
-    if (c->step.graph) (void)hipGraphDestroy(c->step.graph);
+    for (auto& g : c->step) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
     if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     (void)mocha_comm_destroy(c);
     delete c;
@@ -1033,8 +1049,8 @@ int mocha_reserve(mocha_ctx* c, int max_batch) {
     int rc = ensure_ws(c, max_batch);
     if (rc) return rc;
     if (c->bank_N > 0)                                    // ... and the match scratch of the current bank for that many queries
-        for (int set = 0; set < ((c->dual_stream && !c->wss[1].empty()) ? 2 : 1); ++set)
-            if ((rc = ensure_match_scratch(c, set, std::max(c->chunk, 8), c->bank_N, true))) return rc;
+        for (int set = 0; set < mocha_ctx::MAX_SETS; ++set)
+            if (!c->wss[set].empty() && (rc = ensure_match_scratch(c, set, set_windows(c, set), c->bank_N, true))) return rc;
     return 0;
 }
 
@@ -1168,8 +1184,8 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
     c->bank_N = N;
     if (current) c->generation++;                         // a captured step has the previous bank's pointers and row count baked in
     // match scratch for every query count the workspace admits: a later match never allocates (capture-safe)
-    for (int set = 0; set < ((c->dual_stream && !c->wss[1].empty()) ? 2 : 1); ++set)
-        if ((rc = ensure_match_scratch(c, set, std::max(c->chunk, 8), N, true))) return rc;
+    for (int set = 0; set < mocha_ctx::MAX_SETS; ++set)
+        if ((set == 0 || !c->wss[set].empty()) && (rc = ensure_match_scratch(c, set, set_windows(c, set), N, true))) return rc;
     c->bank_is_bf16 = (flags & MOCHA_BANK_BF16) != 0;
     // centroid of the bank: the many-query GEMM and the bf16 copy work on b - centroid (see do_match)
     if (!c->bank_center && (rc = dev_alloc(c, &c->bank_center, D))) return rc;
@@ -1365,25 +1381,30 @@ int mocha_characterize_pair_raw(mocha_ctx* c, const float* src_X_raw, int B_src,
 // BASELINE configs[4]: a clip streamed one 60-frame window per step.  The whole step (mot_embedding, +pos_emb, encoder, cnt,
 // z-score, bank scan, gather, decoder, to_mot: test_fullframework.py:438-443, 465-467) is captured once into a HIP graph and
 // replayed; the graph is keyed on the buffer pointers and on the context generation, and re-captured when either changes.
-int mocha_step_graph(mocha_ctx* c, const float* X1, const float* cnt_mean, const float* cnt_std, float* Y1, int32_t* idx,
-                     int raw, void* stream) {
+int mocha_step_graph_lane(mocha_ctx* c, int lane, const float* X1, const float* cnt_mean, const float* cnt_std, float* Y1, int32_t* idx,
+                          int raw, void* stream) {
+    if (!c) return MOCHA_ERR_ARG;
+    if (lane < 0 || lane >= c->lanes) return fail(c, MOCHA_ERR_ARG, "lane %d: the context has %d lane(s) (mocha_set_option \"lanes\")", lane, c->lanes);
     int rc = ready(c, 1); if (rc) return rc;
     if (!X1 || !cnt_mean || !cnt_std || !Y1 || !idx) return fail(c, MOCHA_ERR_ARG, "null argument");
     if (!c->bank_cnt) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
+    if (c->wss[lane].empty()) return fail(c, MOCHA_ERR_STATE, "lane %d has no workspace", lane);
     hipStream_t s = (hipStream_t)stream;
-    auto& g = c->step;
+    auto& g = c->step[lane];
     const bool hit = g.exec && g.x == X1 && g.mean == cnt_mean && g.sd == cnt_std && g.y == Y1 && g.idx == idx &&
                      g.generation == c->generation && g.raw == (raw != 0);
     if (!hit) {
         if (c->prof_on) return fail(c, MOCHA_ERR_STATE, "mocha_step_graph: stop profiling before capturing");
         // make sure nothing inside the captured region allocates (scratch for one query against the current bank)
-        if ((rc = ensure_match_scratch(c, 0, 8, c->bank_N, true))) return rc;
+        if ((rc = ensure_match_scratch(c, lane, 8, c->bank_N, true))) return rc;
         if (!c->cap_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
         if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
         if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
         const int64_t gen0 = c->generation;
         HIPCHK(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeRelaxed));
+        c->lane = lane;                                   // the step's kernels use this lane's workspace set and match scratch
         rc = characterize_impl(c, X1, 1, cnt_mean, cnt_std, Y1, idx, c->cap_stream, raw != 0);
+        c->lane = 0; c->cur = 0;
         hipGraph_t graph = nullptr;
         const hipError_t ee = hipStreamEndCapture(c->cap_stream, &graph);
         if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
@@ -1397,6 +1418,11 @@ int mocha_step_graph(mocha_ctx* c, const float* X1, const float* cnt_mean, const
     }
     HIPCHK(c, hipGraphLaunch(g.exec, s));
     return 0;
+}
+
+int mocha_step_graph(mocha_ctx* c, const float* X1, const float* cnt_mean, const float* cnt_std, float* Y1, int32_t* idx,
+                     int raw, void* stream) {
+    return mocha_step_graph_lane(c, 0, X1, cnt_mean, cnt_std, Y1, idx, raw, stream);
 }
 
 // ------------------------------------------------------------------------------------------- RCCL (multi-GPU set-up)
@@ -1904,6 +1930,14 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
         HIPCHK(c, hipDeviceSynchronize());
         c->dual_stream = value != 0;
         c->chunk = 0;                              // workspaces are re-planned (one or two sets) on the next call
+        return 0;
+    }
+    if (n == "lanes") {
+        if (value < 1 || value > mocha_ctx::MAX_SETS) return fail(c, MOCHA_ERR_ARG, "lanes must be 1..%d", mocha_ctx::MAX_SETS);
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipDeviceSynchronize());
+        c->lanes = value;
+        c->chunk = 0;                              // workspace sets are re-planned on the next call (generation moves)
         return 0;
     }
     if (n == "dual_min") { c->dual_min = value < 2 ? 2 : value; return 0; }

@@ -471,23 +471,33 @@ class StreamingCharacterizer:
     graph launch.  The library re-captures by itself when the bank or a workspace it baked in has changed; this class
     re-activates its bank when another bank was made current in between."""
 
-    def __init__(self, bank: ContextBank, cnt_mean, cnt_std, use_graph: bool = True):
+    def __init__(self, bank: ContextBank, cnt_mean, cnt_std, use_graph: bool = True, lanes: int = 1):
         self.bank, self.model = bank, bank.model
         m = self.model
+        if not 1 <= lanes <= 3:
+            raise ValueError("lanes must be 1..3")
+        if lanes > 1 and not use_graph:
+            raise ValueError("lanes > 1 needs the captured step (use_graph=True)")
+        self.lanes = lanes
         self.mean = _dev_f32(cnt_mean, m.device, (NTOK, DIM), "cnt_mean")
         self.std = _dev_f32(cnt_std, m.device, (NTOK, DIM), "cnt_std")
-        self.x = torch.zeros((1, m.cfg["nframes"], m.V, m.cfg["mot_in_dim"]), dtype=torch.float32, device=m.device)
-        self.y = torch.empty_like(self.x)
-        self.idx = torch.zeros((1,), dtype=torch.int32, device=m.device)
+        shape = (1, m.cfg["nframes"], m.V, m.cfg["mot_in_dim"])
+        self.xs = [torch.zeros(shape, dtype=torch.float32, device=m.device) for _ in range(lanes)]
+        self.ys = [torch.empty(shape, dtype=torch.float32, device=m.device) for _ in range(lanes)]
+        self.idxs = [torch.zeros((1,), dtype=torch.int32, device=m.device) for _ in range(lanes)]
+        self.x, self.y, self.idx = self.xs[0], self.ys[0], self.idxs[0]
         self.use_graph = use_graph
+        self._lane_streams = None
+        if lanes > 1:
+            m.set_option("lanes", lanes)                   # re-plans the workspace sets (generation moves)
         bank.activate()
 
-    def _enqueue(self):
+    def _enqueue(self, lane: int = 0):
         if getattr(self.model, "_bank", None) is not self.bank:
             self.bank.activate()                           # another bank was made current: ours again (bumps the generation)
         if self.use_graph:
-            self.model._ctx.call("mocha_step_graph", _ptr(self.x), _ptr(self.mean), _ptr(self.std), _ptr(self.y),
-                                 _ptr(self.idx), 0, _stream())
+            self.model._ctx.call("mocha_step_graph_lane", lane, _ptr(self.xs[lane]), _ptr(self.mean), _ptr(self.std), _ptr(self.ys[lane]),
+                                 _ptr(self.idxs[lane]), 0, _stream())
         else:
             self.model._ctx.call("mocha_characterize", _ptr(self.x), 1, _ptr(self.mean), _ptr(self.std), _ptr(self.y),
                                  _ptr(self.idx), _stream())
@@ -498,6 +508,38 @@ class StreamingCharacterizer:
         self.x.copy_(window.reshape(self.x.shape), non_blocking=True)
         self._enqueue()
         return self.y[0], self.idx
+
+    def run_clip(self, windows: torch.Tensor):
+        """All W windows of a clip, one captured per-window step each, with up to ``lanes`` steps in flight: window i runs on
+        lane i % lanes and that lane's stream, so window i + 1's encode chain overlaps window i's bank scan (the windows of a
+        clip are known up front and independent: test_fullframework.py:128, 148-158, 438).  Same kernels and the same
+        arithmetic per window as ``step``: results are bit-identical to it.  -> (Y (W,60,V,15), idx (W,)), ordered on the
+        caller's stream when the call returns (no host synchronisation)."""
+        m = self.model
+        W = windows.shape[0]
+        wins = _dev_f32(windows, m.device, tuple(self.x.shape[1:]), "windows")
+        Y = torch.empty((W,) + tuple(self.x.shape[1:]), dtype=torch.float32, device=m.device)
+        idx = torch.empty((W,), dtype=torch.int32, device=m.device)
+        if self._lane_streams is None:
+            self._lane_streams = [torch.cuda.Stream(device=m.device) for _ in range(self.lanes)]
+        cur = torch.cuda.current_stream(m.device)
+        ready = torch.cuda.Event(); ready.record(cur)
+        for st in self._lane_streams:
+            st.wait_event(ready)                           # inputs (and the outputs' allocations) are ordered before the lanes start
+        for i in range(W):
+            k = i % self.lanes
+            with torch.cuda.stream(self._lane_streams[k]):
+                self.xs[k].copy_(wins[i:i + 1], non_blocking=True)
+                self._enqueue(k)
+                Y[i:i + 1].copy_(self.ys[k], non_blocking=True)
+                idx[i:i + 1].copy_(self.idxs[k], non_blocking=True)
+        for st in self._lane_streams:
+            done = torch.cuda.Event(); done.record(st)
+            cur.wait_event(done)
+        for t in (wins, Y, idx):
+            for st in self._lane_streams:
+                t.record_stream(st)
+        return Y, idx
 
 
 class CVAE:

@@ -273,6 +273,35 @@ def test_bf16_bank_many_queries_agrees_with_fp32():
     assert (i32 == i16).mean() >= 0.95                    # random N(0,1) banks: gaps >> bf16 rounding
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 3])
+def test_streaming_lanes_reproduce_the_synchronous_steps(lanes):
+    """BASELINE configs[4] pipelined: run_clip keeps up to three captured per-window steps in flight on their own lanes (workspace
+    set, match scratch, graph, stream each).  Same kernels per window as step(): outputs and indices bit for bit, for every lane
+    count, twice in a row (buffers are reused across the clip), and step() still works afterwards."""
+    from mocha_sigasia2023_amd import StreamingCharacterizer
+    sd = weights.synthetic_state_dict(56, 1.2)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    mean, std = synthetic.cnt_norm(8)
+    cha = T(synthetic.pose_windows(72, 41))
+    src = T(synthetic.pose_windows(73, 17))
+    enc_c, cnt_c, nm_c = model.encode(cha, mean, std)
+    bank = ContextBank(model, nm_c, enc_c)
+    ref = StreamingCharacterizer(bank, mean, std)
+    Ys, Is = [], []
+    for i in range(17):
+        y, ix = ref.step(src[i])
+        Ys.append(y.clone()); Is.append(int(ix.item()))
+    sc = StreamingCharacterizer(bank, mean, std, lanes=lanes)
+    for _ in range(2):
+        Y, idx = sc.run_clip(src)
+        torch.cuda.synchronize()
+        assert idx.cpu().tolist() == Is
+        assert torch.equal(Y, torch.stack(Ys))
+    y, ix = sc.step(src[3])
+    assert torch.equal(y, Ys[3]) and int(ix.item()) == Is[3]
+    model.set_option("lanes", 1)
+
+
 def test_streaming_graph_replay_matches_batched():
     """BASELINE configs[4] in small: windows streamed one per step through a captured HIP graph must
     reproduce the batched NN-branch result bit for bit (same kernels, same order per window)."""
