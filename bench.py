@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--dual-stream", action="store_true",
                     help="add a second timing of the same step with the opt-in two-stream overlap (reported beside the headline, "
                          "never as it; off by default so that a rocprofv3 run of the default command sees only the headline kernels)")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="windows per clip for the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=585, help="windows per clip for the CPU baseline leg (default: the full 585 + 585 of the GPU workload)")
+    ap.add_argument("--sustained-s", type=float, default=2.5, help="seconds of the extra back-to-back timing of the same step (0 = skip)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra records of the default N=1 line (matcher roofline, bank4k, streaming)")
     return ap.parse_args()
@@ -104,21 +105,44 @@ def spawn_ranks(a):
     raise SystemExit(max(abs(rc) for rc in rcs))
 
 
+def kernel_source_sha16():
+    """Hash of the device sources (csrc/*.hip, *.h): tools/pmc_traffic.sh writes it into the traffic summary it produces, and
+    the bench quotes PMC traffic only from a summary whose hash matches the sources of the library it is running."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "mocha_sigasia2023_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mocha_sigasia2023_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic_for(kernel_name):
     """HBM-side bytes per launch of `kernel_name` from the committed rocprofv3 PMC summary (separate
-    --pmc FETCH_SIZE / WRITE_SIZE passes, read side x2 on gfx950; tools/pmc_traffic.sh).  None if absent."""
+    --pmc FETCH_SIZE / WRITE_SIZE passes, read side x2 on gfx950; tools/pmc_traffic.sh).  (None, reason) if there is no
+    summary, or if the newest one was measured on other kernel sources than the ones in the tree (its `# kernel_source_sha16`
+    line): a kernel change must not keep quoting the old counters."""
     import glob, re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "*pmc_traffic_summary.txt")))
     if not files:
-        return None, None
+        return None, "no committed PMC traffic summary"
+    rel = os.path.relpath(files[-1], ROOT)
+    text = open(files[-1]).read()
+    m = re.search(r"^# kernel_source_sha16: (\w+)", text, re.M)
+    now = kernel_source_sha16()
+    if not m or m.group(1) != now:
+        return None, (f"stale: {rel} was measured on kernel sources {m.group(1) if m else '(unrecorded)'}, the tree is {now}; "
+                      "re-run tools/pmc_traffic.sh")
     key = re.sub(r"[ ,]", "", kernel_name.split("<")[0] + "<" + kernel_name.split("<")[1]) if "<" in kernel_name else kernel_name
-    for line in open(files[-1]):
+    tot, n = 0.0, 0
+    for line in text.splitlines():
         flat = re.sub(r"[ ,]", "", line)
         if key in flat:
-            m = re.search(r"\)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
-            if m:
-                return (float(m.group(2)) + float(m.group(3))) * 1e6, os.path.relpath(files[-1], ROOT)
-    return None, None
+            mm = re.search(r"\)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s*$", line)
+            if mm:                                      # every template instance of the kernel, weighted by its launches
+                tot += int(mm.group(1)) * (float(mm.group(2)) + float(mm.group(3))) * 1e6
+                n += int(mm.group(1))
+    if n:
+        return tot / n, f"from profile: {rel} (rocprofv3 --pmc passes of this command on these kernel sources, committed; PMC counters cannot be read inside this process)"
+    return None, f"{rel} has no line for {kernel_name}"
 
 
 def dist_device_and_backend(local):
@@ -288,6 +312,69 @@ def stream_record(model, dev, V):
     return out
 
 
+def ours_record(model, dev):
+    """Row N1 (test_fullframework.py:446-457): the CVAE ("Ours") branch per frame - condition, CVAE.sample, de-normalise, decoder,
+    to_mot through OursSession with graph replay - for 1 clip and for 8 clips advanced in lock step; host-timed per step with a
+    one-element read-back as the synchronisation (the demo's loop consumes every frame's pose on the host)."""
+    from mocha_sigasia2023_amd import CVAE, OursSession, synthetic
+    from mocha_sigasia2023_amd import weights as Wt
+    cvae = CVAE(device=dev).load_state_dict(Wt.synthetic_cvae_state_dict(99, 1.0)).eval()
+    rng = np.random.Generator(np.random.PCG64(0))
+    stats = [(0.1 * rng.standard_normal((90, 256))).astype(np.float32), rng.uniform(0.5, 1.5, (90, 256)).astype(np.float32),
+             (0.1 * rng.standard_normal((90, 256))).astype(np.float32), rng.uniform(0.5, 1.5, (90, 256)).astype(np.float32)]
+    out = {}
+    for B in (1, 8):
+        enc, cnt = model.encode(torch.from_numpy(synthetic.pose_windows(3, B, model.V)).to(dev))
+        s = OursSession(model, cvae, *stats, use_graph=True).reset(enc)
+        for _ in range(5):
+            s.step(enc, cnt)
+        torch.cuda.synchronize()
+        lat = []
+        for _ in range(200):
+            t0 = time.perf_counter(); y, c = s.step(enc, cnt); y[0, 0, 0, 0].item(); lat.append(time.perf_counter() - t0)
+        lat = np.sort(np.asarray(lat)) * 1e3
+        out[f"clips{B}"] = {"ms_per_frame_p50": float(lat[100]), "ms_per_frame_p99": float(lat[197]), "frames_per_s": B / float(lat[100]) * 1e3}
+    return out
+
+
+def post_record(model, dev, W):
+    """Rows N2 / N3 around the step, HIP events over 20 repetitions each: featurisation of W windows (mocha_featurize), last-frame
+    pose heads of W decoded windows (mocha_pose_heads), and the sequential frame loop of one W-frame clip and of 64 such clips in
+    one launch (mocha_post_clip: root integration, blending, foot-lock IK, BVH channels; one lane per clip)."""
+    from mocha_sigasia2023_amd import postprocess as P
+    r = np.random.Generator(np.random.PCG64(11))
+    V, J = model.V, model.V + 1
+
+    def ev(fn, reps=20):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+    rot = torch.from_numpy(r.standard_normal((W, 60, J, 4)).astype(np.float32)).to(dev)
+    rot = rot / rot.norm(dim=-1, keepdim=True)
+    pos, vel, ang = (torch.from_numpy(r.standard_normal((W, 60, J, 3)).astype(np.float32)).to(dev) for _ in range(3))
+    Y = torch.from_numpy(r.standard_normal((W, 60, V, 15)).astype(np.float32)).to(dev)
+    out = {"featurize_us_per_window": ev(lambda: model.featurize(rot, pos, vel, ang)) / W,
+           "pose_heads_us_per_window": ev(lambda: P.pose_heads(model, Y)) / W}
+    heads, speed = P.pose_heads(model, Y)
+    # toe bones in the (V+1)-bone skeleton: 5 / 24 for the shipped 24-joint layout (test_fullframework.py:104), the 'mixamo'
+    # tables' toes (joints 17 and 21, net/graph.py:18-31) for the 22-joint one
+    pp = P.PostProcessor(model, contact_bones=(5, 24) if V == 24 else (18, 22))
+    for clips in (1, 64):
+        h = heads[None].expand(clips, -1, -1, -1).contiguous()
+        sp = speed[None].expand(clips, -1).contiguous()
+        rv = torch.from_numpy((0.01 * r.standard_normal((clips, W, 3))).astype(np.float32)).to(dev)
+        ra = torch.from_numpy((0.01 * r.standard_normal((clips, W, 3))).astype(np.float32)).to(dev)
+        ss = torch.from_numpy(np.abs(r.standard_normal((clips, W))).astype(np.float32)).to(dev)
+        ct = torch.from_numpy((r.uniform(size=(clips, W, 2)) > 0.5).astype(np.uint8)).to(dev)
+        us = ev(lambda: pp.run(h, sp, rv, ra, ss, ct, bvh=True), reps=5)
+        out[f"post_clip_us_per_frame_{clips}_clip{'s' if clips > 1 else ''}"] = us / (clips * W)
+    return out
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -392,6 +479,20 @@ def main():
         torch.distributed.all_gather_object(vals, per_rank[0])
         per_rank = [float(v) for v in vals]
 
+    # extra (not the headline): the same step back to back for >= --sustained-s seconds (the plane GEMMs run at the board's
+    # power limit: the clock a 0.1 s burst holds is not the one a long run holds)
+    sustained = None
+    if a.sustained_s > 0 and world == 1:
+        n_sus = max(a.steps, int(a.sustained_s / (ms_per_step * 1e-3)) + 1)
+        with torch.no_grad():
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(n_sus):
+                step()
+            sync_all()
+            e_s = time.perf_counter() - t0
+        sustained = {"value": W * n_sus / e_s, "ms_per_step": e_s / n_sus * 1e3, "steps": n_sus, "seconds": e_s}
+
     # extra (not the headline): the same step with the library's two-stream overlap enabled
     dual = None
     if a.dual_stream:
@@ -456,8 +557,7 @@ def main():
                      "product; 'achieved' counts the executed bf16 FLOPs") if on_bf16 else "f32 MFMA (v_mfma_f32_32x32x2_f32)",
             "fp32_equivalent": {"achieved": ach, "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac": ach / PEAK_F32_MFMA_TFLOPS},
             "traffic": traffic,
-            "traffic_source": (f"from profile: {traffic_src} (rocprofv3 --pmc passes of this command, committed; PMC counters cannot "
-                               "be read inside this process)") if traffic_src else None,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
             "launches_per_step": d["launches"] // 3, "avg_launch_us": d["ms"] / d["launches"] * 1e3,
             "algorithmic_flops_per_launch": d["flops"] / d["launches"],
@@ -483,15 +583,33 @@ def main():
             "match_sites": {k: {"ms_per_step": v["ms"] / 3} for k, v in mk.items()},
             "bank_broadcast_ms": bcast_ms, "bank_broadcast_error": bcast_err, "clip_broadcast_ms": clip_bcast_ms,
             "per_rank_frames_per_s": per_rank,
+            "sustained": sustained,
             "dual_stream": dual,
             "exact_f32_engine": exact_f32,
         }
         if world == 1 and not a.no_extras:
             # extra records measured in the same process (not the headline): the matcher's own roofline on the shapes the
-            # north star's ">= 50 % HBM in the context-matching kernel" is evaluated on, and the streamed configs[4] step
+            # north star's ">= 50 % HBM in the context-matching kernel" is evaluated on, the streamed configs[4] step, the
+            # shipped model's 24-joint layout, and the (f) rows around the step (CVAE branch, featurisation, post-processing)
             with torch.no_grad():
                 out["match"] = match_records(model, dev)
                 out["stream_16k"] = stream_record(model, dev, V)
+                out["ours"] = ours_record(model, dev)
+                out["post"] = post_record(model, dev, W)
+                if V != 24:
+                    sd24 = synthetic_state_dict(seed=1777, gain=1.0, layout="mocha")
+                    m24 = Generator(layout="mocha", device=dev).load_state_dict(sd24).eval()
+                    s24 = torch.from_numpy(synthetic.pose_windows(1777, W, 24)).to(dev)
+                    c24 = torch.from_numpy(synthetic.pose_windows(4242, W, 24)).to(dev)
+                    for _ in range(a.warmup):
+                        m24.characterize_pair(s24, c24, mean, std)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    for _ in range(a.steps):
+                        m24.characterize_pair(s24, c24, mean, std)
+                    torch.cuda.synchronize(); e24 = time.perf_counter() - t0
+                    out["joints24"] = {"value": W * a.steps / e24, "ms_per_step": e24 / a.steps * 1e3,
+                                       "note": "the same step on the shipped model's 24-joint 'mocha' layout (configs/config.yaml:8-10,17)"}
+                    del m24, s24, c24
         if not a.no_cpu_baseline and world == 1:         # the CPU leg runs at N=1 only (the other ranks would idle through it)
             m_, s_ = synthetic.cnt_norm(7)
             out["cpu_baseline"] = cpu_baseline(sd, V, a.cpu_sample, m_, s_)

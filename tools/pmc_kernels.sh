@@ -3,7 +3,7 @@
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/pmc_kernels; rm -rf $out; mkdir -p $out
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out -o k -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/stdout.txt 2> $out/stderr.txt
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out -o k -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --sustained-s 0 > $out/stdout.txt 2> $out/stderr.txt
 python3 - $out <<'PY'
 import csv, sys, glob, collections
 out = sys.argv[1]

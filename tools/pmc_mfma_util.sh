@@ -7,7 +7,7 @@ tag=${1:-r01}
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/pmc_mfma_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out -o m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/stdout.txt 2> $out/stderr.txt
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out -o m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --sustained-s 0 > $out/stdout.txt 2> $out/stderr.txt
 python3 - $out <<'PY'
 import csv, sys, glob, collections
 out = sys.argv[1]

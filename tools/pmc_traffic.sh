@@ -8,7 +8,7 @@ cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/pmc_traffic_$tag; rm -rf $out; mkdir -p $out
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/$ctr.stdout 2> $out/$ctr.stderr
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/$ctr -o t -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --sustained-s 0 > $out/$ctr.stdout 2> $out/$ctr.stderr
 done
 python3 - $out <<'PY'
 import csv, sys, glob, collections
@@ -26,6 +26,10 @@ lines = [f"{'kernel':70s} {'launches':>8s} {'read_MB/launch(2x FETCH)':>26s} {'w
 for k, v in sorted(agg.items(), key=lambda kv: -(kv[1]['FETCH_SIZE'] + kv[1]['WRITE_SIZE'])):
     n = max(v["n"], 1)
     lines.append(f"{k[:70]:70s} {n:8d} {2*v['FETCH_SIZE']*1024/n/1e6:26.2f} {v['WRITE_SIZE']*1024/n/1e6:16.2f}")
+import os
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+lines.append(f"# kernel_source_sha16: {bench.kernel_source_sha16()}")
 open(out + "/traffic_summary.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY

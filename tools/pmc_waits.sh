@@ -5,7 +5,7 @@ tag=${1:-r02}
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/pmc_waits_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/stdout.txt 2> $out/stderr.txt
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $out -o w -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --sustained-s 0 > $out/stdout.txt 2> $out/stderr.txt
 python3 - $out <<'PY'
 import csv, sys, glob, collections
 out = sys.argv[1]

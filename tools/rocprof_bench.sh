@@ -7,7 +7,7 @@ cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
 out=gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline ${BENCH_EXTRA:---no-extras} > "$out/bench_stdout.json" 2> "$out/bench_stderr.txt"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --sustained-s 0 ${BENCH_EXTRA:---no-extras} > "$out/bench_stdout.json" 2> "$out/bench_stderr.txt"
 f=$(find "$out" -name '*kernel_stats.csv' | head -1)
 echo "stats file: $f"
 python3 - "$f" "$out" <<'PY'
