@@ -251,6 +251,9 @@ typedef struct mocha_post_cfg {
     double dt, ik_max_length_buffer, ik_foot_height, ik_unlock_radius, ik_blending_halflife;
     int ik_enabled, n_contact;
     int contact_bones[4];      /* toe bones, indices in the (V+1)-bone skeleton with the root bone in front */
+    int blend_enabled;         /* 1 (default): positions blended with the previous frame's (:537, 627).  0 together with
+                                * ik_enabled = 0 is the demo's context-matching "cm_" stream: decoded poses as they are, only
+                                * the root integrated (test_fullframework.py:512-527, 637-641) */
 } mocha_post_cfg;
 void mocha_post_cfg_default(mocha_post_cfg* cfg);
 int mocha_pose_heads(mocha_ctx* ctx, const float* Y, int B, float* heads, float* speed, void* stream);

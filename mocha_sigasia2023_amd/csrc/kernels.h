@@ -134,7 +134,7 @@ struct PostParams {
     const unsigned char* contact;   // (clips, frames, n_contact)
     double *pos, *rot, *ik_rot;     // (clips, frames, V+1, 3|4|4)
     double *bvh_pos, *bvh_euler;    // (clips, frames, V, 3) or null
-    int n_clips, n_frames, V, n_contact, ik_enabled;
+    int n_clips, n_frames, V, n_contact, ik_enabled, blend_enabled;
     int parents[MOCHA_MAX_BONES];
     int contact_bones[MOCHA_MAX_CONTACT];
     double dt, max_length_buffer, foot_height, unlock_radius, halflife;

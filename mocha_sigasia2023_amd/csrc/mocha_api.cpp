@@ -1873,6 +1873,7 @@ void mocha_post_cfg_default(mocha_post_cfg* cfg) {
     cfg->ik_unlock_radius = 0.2;
     cfg->ik_blending_halflife = 0.1;
     cfg->ik_enabled = 1;
+    cfg->blend_enabled = 1;
     cfg->n_contact = 2;                     // :104
     cfg->contact_bones[0] = 5;
     cfg->contact_bones[1] = 24;
@@ -1895,6 +1896,7 @@ int mocha_postprocess(mocha_ctx* c, const mocha_post_cfg* cfg, const float* head
     p.heads = heads; p.speed = speed; p.src_rvel = src_rvel; p.src_rang = src_rang; p.src_speed = src_speed; p.contact = contact;
     p.pos = pos; p.rot = rot; p.ik_rot = ik_rot; p.bvh_pos = bvh_pos; p.bvh_euler = bvh_euler;
     p.n_clips = n_clips; p.n_frames = n_frames; p.V = c->cfg.V; p.n_contact = cfg->n_contact; p.ik_enabled = cfg->ik_enabled;
+    p.blend_enabled = cfg->blend_enabled;
     p.parents[0] = -1;                       // parents = [-1] + (joint parents + 1), test_fullframework.py:101-102
     for (int i = 0; i < c->cfg.V; ++i) p.parents[i + 1] = c->sk.parents[i] + 1;
     for (int i = 0; i < cfg->n_contact; ++i) {

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void mocha_post_clip(PostParams p) {
                 rj = {(double)hj[3], (double)hj[4], (double)hj[5], (double)hj[6]};
                 vj = {(double)hj[7], (double)hj[8], (double)hj[9]};
             }
-            if (prev) pj = (ld3(prev + j * 3) + vj * dt) * 0.5 + pj * 0.5;
+            if (prev && p.blend_enabled) pj = (ld3(prev + j * 3) + vj * dt) * 0.5 + pj * 0.5;
             st3(pos + j * 3, pj);
             stq(rot + j * 4, rj);
             stq(ikr + j * 4, rj);

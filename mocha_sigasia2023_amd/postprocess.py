@@ -18,7 +18,7 @@ class PostCfg(C.Structure):
     """``mocha_post_cfg`` of include/mocha_hip.h; defaults are the demo's constants (test_fullframework.py:104-114)."""
     _fields_ = [("dt", C.c_double), ("ik_max_length_buffer", C.c_double), ("ik_foot_height", C.c_double),
                 ("ik_unlock_radius", C.c_double), ("ik_blending_halflife", C.c_double),
-                ("ik_enabled", C.c_int), ("n_contact", C.c_int), ("contact_bones", C.c_int * 4)]
+                ("ik_enabled", C.c_int), ("n_contact", C.c_int), ("contact_bones", C.c_int * 4), ("blend_enabled", C.c_int)]
 
 
 def pose_heads(model: Generator, Y):
@@ -34,7 +34,7 @@ def pose_heads(model: Generator, Y):
 class PostProcessor:
     """Root integration + blending + foot-lock IK of whole clips on the device, one lane per clip."""
 
-    def __init__(self, model: Generator, contact_bones: Optional[Sequence[int]] = None, ik_enabled: bool = True, **ik):
+    def __init__(self, model: Generator, contact_bones: Optional[Sequence[int]] = None, ik_enabled: bool = True, blend: bool = True, **ik):
         self.model = model
         self.cfg = PostCfg()
         model._ctx.lib.mocha_post_cfg_default(C.byref(self.cfg))
@@ -45,6 +45,7 @@ class PostProcessor:
             for i, b in enumerate(contact_bones):
                 self.cfg.contact_bones[i] = int(b)
         self.cfg.ik_enabled = int(ik_enabled)
+        self.cfg.blend_enabled = int(blend)     # blend=False, ik_enabled=False: the demo's "cm_" stream (test_fullframework.py:512-527, 637-641)
         for k, v in ik.items():
             if k not in ("dt", "ik_max_length_buffer", "ik_foot_height", "ik_unlock_radius", "ik_blending_halflife"):
                 raise TypeError(f"unknown post-processing option {k!r}")

@@ -197,10 +197,11 @@ class PostProcess:
     root-local velocities / hip speed / contact labels of the same frame and returns the frame's pose:
     (pos (V+1,3), rot (V+1,4), ik_rot (V+1,4)), all float64; pos is shared by the plain and the IK stream."""
 
-    def __init__(self, parents, contact_bones=CONTACT_BONES, dt=DT, ik=IK, ik_enabled=True):
+    def __init__(self, parents, contact_bones=CONTACT_BONES, dt=DT, ik=IK, ik_enabled=True, blend=True):
         self.parents = [int(p) for p in parents]
         self.contact_bones = tuple(int(b) for b in contact_bones)
         self.dt, self.ik, self.ik_enabled = dt, dict(ik), ik_enabled
+        self.blend = blend            # False + ik_enabled=False: the demo's context-matching "cm_" stream (:512-527, 637-641)
         self.prev_pos = None
 
     def _root(self, heads, speed, src_rvel, src_rang, src_speed, root_pos, root_rot):
@@ -227,7 +228,7 @@ class PostProcess:
             self.prev_pos, self.prev_root_rot = pos, rot[0]
             return pos.copy(), rot.copy(), rot.copy()
         pos, rot, vel, ang = self._root(heads, speed, src_rvel, src_rang, src_speed, self.prev_pos[0], self.prev_root_rot)
-        blended = (self.prev_pos + vel * dt) * 0.5 + pos * 0.5                         # :537-540, 627
+        blended = (self.prev_pos + vel * dt) * 0.5 + pos * 0.5 if self.blend else pos  # :537-540, 627; cm_ stream: :524, 637
         ik_rot = rot.copy()
         if self.ik_enabled:
             for ci, toe in enumerate(self.contact_bones):

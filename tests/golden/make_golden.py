@@ -16,6 +16,7 @@ No reference source or bytecode is written anywhere; the fixtures are data only.
 """
 import os
 import sys
+import textwrap
 
 import numpy as np
 import torch
@@ -258,8 +259,14 @@ def run_database():
 
 
 def run_postprocess():
-    """The demo's per-frame post-processing (test_fullframework.py:303-437 for the first frame, :457-632 after it)
-    driven through the reference's own motion/quat.py and motion/Inertialization.py on synthetic decoded windows."""
+    """The demo's per-frame post-processing, produced by EXECUTING THE REFERENCE'S OWN LINES: test_fullframework.py:289-641 (the body
+    of its `with torch.no_grad():` block - frame 0 at :289-437, the frame loop at :438-641) and :643-694 (stacking, root merge),
+    taken from its source text and run in a prepared namespace, as run_database does for collect_CVAE_feature_action.py.
+    Nothing of the loop is re-written here: the namespace only supplies what the script computed earlier in main() -
+    stand-ins for the network (model.decoder / model.to_mot hand out the seeded synthetic decoded windows, CVAE branch and NN
+    branch separately; network_cvae.sample returns its input's second half), the source clip's arrays, constants - and the
+    reference's quat / Inertialization modules.  Both branches are stored: "Ours" (blend + foot-lock IK, :529-631) and the
+    context-matching "cm_" branch (no blend, no IK, :512-527, 637-641)."""
     cwd = os.getcwd(); os.chdir(REF)
     try:
         sys.path.insert(0, os.path.join(REF, "motion"))
@@ -267,63 +274,75 @@ def run_postprocess():
         import Inertialization as inert
     finally:
         os.chdir(cwd)
+    from sklearn.neighbors import BallTree
     from mocha_sigasia2023_amd.skeleton import LAYOUTS
-    par = np.concatenate([[-1], np.asarray(LAYOUTS["mocha"]["parents"]) + 1])
-    feet = np.array([5, 24]); dt = 1.0 / 60.0
-    buf, foot_h, radius, half = 0.015, 0.02, 0.2, 0.1
     N = 120
-    Y, rvel, rang, hipvel, contact = synthetic.postprocess_inputs(77, N)
-    ident = np.array([1, 0, 0, 0])
-    P, R, RIK = [], [], []
-    heads_rot, speeds = [], []
-    for i in range(N):
-        W = Y[i]
-        jp, jv, ja = W[-1, :, :3], W[..., 9:12], W[-1, :, 12:15]
-        jr = quat.from_xform_xy(W[-1, :, 3:9].reshape(jp.shape[0], 3, 2))
-        heads_rot.append(jr)
-        ratio = np.linalg.norm(jv[:, 0], axis=1).mean() / np.linalg.norm(hipvel[i], axis=1).mean()
-        speeds.append(np.linalg.norm(jv[:, 0], axis=1).mean())
-        if ratio > 3.0 or ratio < 0.33:
-            ratio = 1.0
-        q0, p0 = (ident, np.array([0, 0, 0])) if i == 0 else (R[-1][0], P[-1][0])
-        wv = quat.mul_vec(q0, rvel[i] * ratio); wa = quat.mul_vec(q0, rang[i])
-        pos = np.concatenate([(p0 + wv * dt)[None], jp]); vel = np.concatenate([wv[None], jv[-1]])
-        rot = np.concatenate([quat.mul(q0, quat.from_scaled_angle_axis(wa * dt))[None], jr]); ang = np.concatenate([wa[None], ja])
-        if i == 0:
-            nc = feet.size
-            st = dict(state=np.zeros(nc, bool), lock=np.zeros(nc, bool), pos=np.zeros((nc, 3)), vel=np.zeros((nc, 3)),
-                      point=np.zeros((nc, 3)), target=np.zeros((nc, 3)), ox=np.zeros((nc, 3)), ov=np.zeros((nc, 3)))
-            for b in range(nc):
-                bp, bv, _, _ = quat.fk_vel_bone(pos, vel, rot, ang, par, feet[b])
-                st["pos"][b] = bp; st["vel"][b] = bv; st["point"][b] = bp; st["target"][b] = bp
-            gpos, grot, done = np.zeros((len(par), 3)), np.zeros((len(par), 4)), np.zeros(len(par), bool)
-            P.append(pos); R.append(rot); RIK.append(rot)
-            continue
-        lpos = ((P[-1] + vel * dt) * 0.5 + pos * 0.5).copy()
-        arot = rot.copy()
-        for b in range(feet.size):
-            toe = feet[b]; heel = par[toe]; knee = par[heel]; hip = par[knee]; up = par[hip]
-            done[:] = False
-            quat.fk_partial(gpos, grot, done, lpos, rot, par, toe)
-            (st["state"][b], st["lock"][b], st["pos"][b], st["vel"][b], st["point"][b], st["target"][b], st["ox"][b], st["ov"][b]) = \
-                inert.contact_update(st["state"][b], st["lock"][b], st["pos"][b], st["vel"][b], st["point"][b], st["target"][b],
-                                     st["ox"][b], st["ov"][b], gpos[toe], bool(contact[i, b]), radius, foot_h, half, dt)
-            clamp = st["pos"][b]
-            clamp[1] = np.max([clamp[1], foot_h])
-            arot[hip], arot[knee] = quat.ik_two_bone(arot[hip], arot[knee], gpos[hip], gpos[knee], gpos[heel],
-                                                     clamp + (gpos[heel] - gpos[toe]),
-                                                     quat.mul_vec(grot[knee], np.array([0.0, 1.0, 0.0], dtype=np.float32)),
-                                                     grot[hip], grot[knee], grot[up], buf)
-        P.append(lpos); R.append(rot); RIK.append(arot)
-    P, R, RIK = np.stack(P), np.stack(R), np.stack(RIK)
-    grot_all, gpos_all = quat.fk(RIK, P, par)                           # root merge of :677-681 and Euler channels of :697
-    bp = P[:, 1:].copy(); bp[:, 0] = gpos_all[:, 1]
-    br = RIK[:, 1:].copy(); br[:, 0] = grot_all[:, 1]
-    np.savez(os.path.join(HERE, "postprocess.npz"), seed=np.array([77, N]), pos=P, rot=R, ik_rot=RIK,
-             heads_rot=np.stack(heads_rot).astype(np.float32), speed=np.asarray(speeds, np.float32),
-             bvh_pos=bp, bvh_euler=np.degrees(quat.to_euler(br)))
-    print("postprocess", P.shape, float(np.abs(P).max()), "ik changed rotations on",
-          int((np.abs(RIK - R).max(axis=(1, 2)) > 1e-9).sum()), "frames")
+    Y, rvel, rang, hipvel, contact = synthetic.postprocess_inputs(77, N)         # "Ours" branch windows + the source's signals
+    Ycm = synthetic.postprocess_inputs(78, N)[0]                                 # NN ("cm_") branch windows
+    r = np.random.Generator(np.random.PCG64(123))
+
+    class _Tokens:                                        # what model.decoder returns: which window to_mot must hand out
+        def __init__(self, frame, branch): self.frame, self.branch = frame, branch
+
+    class _Model:
+        """decoder is called twice per frame, CVAE branch first, NN branch second (test_fullframework.py:301,311 / 455,465)."""
+        calls = 0
+        def decoder(self, src, cha):
+            t = _Tokens(self.calls // 2, self.calls % 2); self.calls += 1
+            return t
+        def to_mot(self, t):
+            return torch.from_numpy((Ycm if t.branch else Y)[t.frame][None])
+
+    class _CVAE:
+        def sample(self, condition, deterministic=False):
+            return condition[:, condition.shape[1] // 2:]
+
+    par0 = np.asarray(LAYOUTS["mocha"]["parents"])
+    J = len(par0) + 1
+    src_Yrvel = r.standard_normal((N, 60, 3)).astype(np.float32); src_Yrvel[:, -1] = rvel
+    src_Yrang = r.standard_normal((N, 60, 3)).astype(np.float32); src_Yrang[:, -1] = rang
+    src_Yvel = r.standard_normal((N, 60, J, 3)).astype(np.float32); src_Yvel[:, :, 1] = hipvel
+    src_contact = (r.uniform(size=(N, 60, 2)) > 0.5).astype(np.uint8); src_contact[:, -1] = contact
+    ns = {
+        "np": np, "torch": torch, "quat": quat, "inert": inert, "BallTree": BallTree, "device": torch.device("cpu"),
+        "model": _Model(), "network_cvae": _CVAE(),
+        # the matching inputs only steer which bank row the NN branch names; the stand-in decoder ignores it
+        "src_encoded": torch.zeros((N, 2, 3)), "src_cnt": r.standard_normal((N, 2, 3)).astype(np.float32),
+        "cha_cnt": r.standard_normal((7, 2, 3)).astype(np.float32), "cha_encoded": torch.zeros((7, 2, 3)),
+        "cnt_mean": np.zeros((2, 3), np.float32), "cnt_std": np.ones((2, 3), np.float32),
+        "src_cnt_mean": torch.zeros((2, 3)), "src_cnt_std": torch.ones((2, 3)),
+        "cha_encoded_mean": torch.zeros((2, 3)), "cha_encoded_std": torch.ones((2, 3)),
+        "Y_mean": np.zeros((1, 1, J, 15), np.float32), "Y_std": np.ones((1, 1, J, 15), np.float32),      # windows are de-normalised already
+        "src_Ypos": r.standard_normal((N, 60, J, 3)).astype(np.float32), "src_Yvel": src_Yvel,
+        "src_Yrot": np.tile(np.array([1, 0, 0, 0], np.float32), (N, 60, J, 1)), "src_Yang": r.standard_normal((N, 60, J, 3)).astype(np.float32),
+        "src_Yrvel": src_Yrvel, "src_Yrang": src_Yrang, "src_contact": src_contact,
+        "parents": np.concatenate([[-1], par0 + 1]), "contact_bones": np.array([5, 24]), "dt": 1.0 / 60.0,
+        "ik_enabled": True, "ik_max_length_buffer": 0.015, "ik_foot_height": 0.02, "ik_toe_length": 0.15,
+        "ik_unlock_radius": 0.2, "ik_blending_halflife": 0.1,
+        "animation_plot": lambda *a, **k: None,
+    }
+    src = open(os.path.join(REF, "test_fullframework.py")).read().splitlines()
+    assert src[287].strip() == "with torch.no_grad():" and src[642].startswith("    src_Ypos = np.stack(src_Ypos_list")
+    loop = textwrap.dedent("\n".join(src[288:641]))       # lines 289-641
+    with torch.no_grad():
+        exec(compile(loop, "test_fullframework.py[289:641]", "exec"), ns)
+    pre = {k: np.stack(ns[k + "_list"]) for k in ("trans_Ypos", "trans_Yrot", "ik_trans_Ypos", "ik_trans_Yrot", "cm_trans_Ypos", "cm_trans_Yrot")}
+    tail = textwrap.dedent("\n".join(src[642:694]))       # lines 643-694: np.stack of every list, quat.fk, root merge
+    exec(compile(tail, "test_fullframework.py[643:694]", "exec"), ns)
+    assert ns["model"].calls == 2 * N
+    assert np.array_equal(pre["trans_Ypos"], pre["ik_trans_Ypos"])      # IK never moves positions: one list serves both (:627, :633)
+    # what the library computes per window before the loop (:457-462 and the ratio's numerator :492): reference functions on the windows
+    heads_rot = np.stack([quat.from_xform_xy(Y[i][-1, :, 3:9].reshape(-1, 3, 2)) for i in range(N)])
+    speed = np.array([np.linalg.norm(Y[i][..., 9:12][:, 0], axis=1).mean() for i in range(N)], np.float32)
+    cm_speed = np.array([np.linalg.norm(Ycm[i][..., 9:12][:, 0], axis=1).mean() for i in range(N)], np.float32)
+    np.savez(os.path.join(HERE, "postprocess.npz"), seed=np.array([77, N]), cm_seed=np.array([78, N]),
+             pos=pre["ik_trans_Ypos"], rot=pre["trans_Yrot"], ik_rot=pre["ik_trans_Yrot"],
+             cm_pos=pre["cm_trans_Ypos"], cm_rot=pre["cm_trans_Yrot"],
+             heads_rot=heads_rot.astype(np.float32), speed=speed, cm_speed=cm_speed,
+             bvh_pos=ns["ik_trans_Ypos"], bvh_euler=np.degrees(quat.to_euler(ns["ik_trans_Yrot"])),          # :706-707
+             cm_bvh_pos=ns["cm_trans_Ypos"], cm_bvh_euler=np.degrees(quat.to_euler(ns["cm_trans_Yrot"])))
+    print("postprocess", pre["ik_trans_Ypos"].shape, float(np.abs(pre["ik_trans_Ypos"]).max()), "ik changed rotations on",
+          int((np.abs(pre["ik_trans_Yrot"] - pre["trans_Yrot"]).max(axis=(1, 2)) > 1e-9).sum()), "frames")
 
 
 def run_bvh():

@@ -1,7 +1,8 @@
 """Row N3: decoded windows -> root integration / blending / foot-lock IK -> BVH.
 
-CPU: the oracle against outputs of the reference's own quat / Inertialization / bvh modules (tests/golden/postprocess.npz,
-bvh_writer.npz, generated by tests/golden/make_golden.py).  GPU: the HIP kernels against the oracle and the fixtures.
+CPU: the oracle against what the REFERENCE'S OWN FRAME LOOP produced - tests/golden/postprocess.npz holds the results of executing
+test_fullframework.py:289-641 and :643-694 from the reference's source text (tests/golden/make_golden.py: run_postprocess), for the
+"Ours" stream (blend + foot-lock IK) and the context-matching "cm_" stream (neither); bvh_writer.npz is the reference writer's text.  GPU: the HIP kernels against the oracle and the fixtures.
 Tolerances: heads are float32 (1e-6 absolute on unit quaternions, compared up to sign-free equality because the kernel
 takes the same branch as NumPy on these inputs); the float64 clip state must agree to 1e-9."""
 import os
@@ -39,6 +40,21 @@ def test_oracle_matches_reference_modules():
     bp, be = P.bvh_channels(pos, ik)
     assert np.abs(bp - z["bvh_pos"]).max() < 1e-12
     assert np.abs(be - z["bvh_euler"]).max() < 1e-6
+
+
+def test_oracle_matches_the_reference_loops_cm_stream():
+    """The "cm_" stream of the same executed reference loop (test_fullframework.py:512-527, 637-641, 689-694): the decoded poses as
+    they are - no blending with the previous frame, no IK - with the root integrated from the stream's own previous root."""
+    z, Y, rvel, rang, src_speed, contact = _inputs()
+    Ycm = synthetic.postprocess_inputs(int(z["cm_seed"][0]), int(z["cm_seed"][1]))[0]
+    heads, speed = P.pose_heads(Ycm)
+    assert np.array_equal(speed, z["cm_speed"])
+    pos, rot, ik = P.run_clip(heads, speed, rvel, rang, src_speed, contact, PARENTS, ik_enabled=False, blend=False)
+    assert np.abs(pos - z["cm_pos"]).max() < 1e-12 and np.abs(rot - z["cm_rot"]).max() < 1e-12
+    assert np.array_equal(ik, rot)
+    bp, be = P.bvh_channels(pos, rot)
+    assert np.abs(bp - z["cm_bvh_pos"]).max() < 1e-12 and np.abs(be - z["cm_bvh_euler"]).max() < 1e-6
+    assert np.abs(z["cm_pos"][1:, 1:] - heads[1:, :, 0:3]).max() == 0           # really unblended: the joints are the decoded ones
 
 
 def test_oracle_exercises_every_contact_transition():
@@ -100,6 +116,14 @@ def test_postprocess_clip_parity(model):
     for k in ("pos", "rot", "ik_rot", "bvh_pos"):
         assert np.abs(out[k].cpu().numpy() - z[k]).max() < 1e-9, k
     assert np.abs(out["bvh_euler"].cpu().numpy() - z["bvh_euler"]).max() < 1e-6
+    # the "cm_" stream (no blend, no IK) against the same executed reference loop
+    Ycm = synthetic.postprocess_inputs(int(z["cm_seed"][0]), int(z["cm_seed"][1]))[0]
+    hc, sc = P.pose_heads(Ycm)
+    cm = PostProcessor(model, ik_enabled=False, blend=False).run(hc, sc, rvel, rang, src_speed, contact)
+    assert np.abs(cm["pos"].cpu().numpy() - z["cm_pos"]).max() < 1e-9 and np.abs(cm["rot"].cpu().numpy() - z["cm_rot"]).max() < 1e-9
+    assert torch.equal(cm["ik_rot"], cm["rot"])
+    assert np.abs(cm["bvh_pos"].cpu().numpy() - z["cm_bvh_pos"]).max() < 1e-9
+    assert np.abs(cm["bvh_euler"].cpu().numpy() - z["cm_bvh_euler"]).max() < 1e-6
     # device heads feeding the device loop, end to end
     dh, ds = pose_heads(model, torch.from_numpy(Y))
     out2 = PostProcessor(model).run(dh, ds, rvel, rang, src_speed, contact, bvh=False)
