@@ -451,6 +451,116 @@ bool gemm_is_skinny(const GemmParams& p) {
     return wide_tiles < 96;
 }
 
+// ---------------------------------------------------------------------------------------
+// One or two windows (M <= 192: the streamed per-window step, the single-clip CVAE branch).  The 32 x 32 variant above puts such a
+// GEMM on 24 ... 144 workgroups - a tenth of the chip's SIMDs - and a wave walks its K quarter in rounds of 64 (load round trip,
+// 32 dependent 64-cycle MFMAs, repeat): 8-16 us per launch, 30 launches per window.  Here a workgroup owns a 16 x 16 tile
+// (v_mfma_f32_16x16x4_f32, 32 cycles), so the same GEMM spreads over 4x the workgroups, and a wave issues EVERY load of its K
+// quarter (up to 16 + 16 sixteen-byte loads per lane) before the first MFMA: one memory round trip, then at most 64 MFMAs on two
+// alternating accumulators.  Same operands-in-MFMA-layout loads, fixed-order reduction of the four K quarters through LDS
+// (deterministic) and fused epilogue as above.
+//   lane l: A row m0 + (l & 15), W row n0 + (l & 15), k sub-block l >> 4 (4 consecutive k per 16-byte load: element i feeds MFMA i of
+//   the group, the same k permutation on both operands);  acc[r] = C[m0 + (l & 15)][n0 + 4 (l >> 4) + r]  (W as the "A" operand).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_gemm_skinny16(GemmParams p) {
+    __shared__ f32x4 red[3][64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int n_tiles = (p.N + 15) / 16;
+    const int mt = blockIdx.x / n_tiles, nt = blockIdx.x - mt * n_tiles;
+    const int m0 = mt * 16, n0 = nt * 16;
+
+    int m = m0 + l15;
+    m = m < p.M ? m : p.M - 1;
+    int a_rb = m, a_t = 0;
+    if (p.gather) {
+        const int v = m % p.V;
+        const int bt = m / p.V;
+        a_t = bt % p.T_out;
+        a_rb = (bt / p.T_out) * p.T_src * p.V + v;
+    }
+    int n = n0 + l15;
+    n = n < p.N ? n : p.N - 1;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.gather ? p.A : p.A + (size_t)(m0 < p.M ? m0 : 0) * p.lda);
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.W + (size_t)n0 * p.K);
+    const unsigned a_off = p.gather ? 0u : ((unsigned)(m - m0) * (unsigned)p.lda + 4u * kq) * 4u;
+    const unsigned w_off = ((unsigned)(n - n0) * (unsigned)p.K + 4u * kq) * 4u;
+
+    const int groups = p.K / 16;                    // k groups of 16 (4 per lane quarter)
+    const int gper = (groups + 3) / 4;
+    const int g_begin = wave * gper;
+    const int g_end = (g_begin + gper) < groups ? (g_begin + gper) : groups;
+
+    // epilogue operands of the wave that will use them, fetched before the K loop (their round trip hides under it)
+    const int row = m0 + l15, col = n0 + 4 * kq;
+    f32x4 ebias = {0.f, 0.f, 0.f, 0.f}, eres = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0 && row < p.M && col < p.N) {
+        if (p.bias) ebias = *reinterpret_cast<const f32x4*>(p.bias + col);
+        if (p.rowbias) ebias += *reinterpret_cast<const f32x4*>(p.rowbias + (size_t)(row % p.rb_mod) * p.N + col);
+        if (p.residual) eres = *reinterpret_cast<const f32x4*>(p.residual + (size_t)row * p.ldr + col);
+    }
+
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int GMAX = 16;                        // groups in flight per round: 2 x 16 x 16 B per lane (128 VGPRs)
+    for (int g0 = g_begin; g0 < g_end; g0 += GMAX) {
+        f32x4 a4[GMAX], b4[GMAX];
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            const int kb = (g0 + g) * 16;            // wave-uniform
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            a4[g] = z; b4[g] = z;
+            if (g0 + g < g_end) {
+                if (!p.gather) {
+                    a4[g] = bload(rsA, a_off, (unsigned)kb * 4u);
+                } else {
+                    const int k = kb + 4 * kq;
+                    const int tap = k / p.Cc;
+                    const int cc = k - tap * p.Cc;
+                    int tf = a_t * p.stride + tap - p.pad;
+                    tf = tf < 0 ? -tf : tf;
+                    tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
+                    a4[g] = bload(rsA, ((unsigned)(a_rb + (tf >> p.tshift) * p.V) * (unsigned)p.lda + (unsigned)cc) * 4u, 0u);
+                }
+                b4[g] = bload(rsW, w_off, (unsigned)kb * 4u);
+            }
+        }
+        if (p.a_lrelu) {
+#pragma unroll
+            for (int g = 0; g < GMAX; ++g) {
+                a4[g][0] = lrelu02(a4[g][0]); a4[g][1] = lrelu02(a4[g][1]);
+                a4[g][2] = lrelu02(a4[g][2]); a4[g][3] = lrelu02(a4[g][3]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < GMAX; ++g) {
+            if (g0 + g < g_end) {                   // wave-uniform
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b4[g][0], a4[g][0], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b4[g][1], a4[g][1], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(b4[g][2], a4[g][2], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b4[g][3], a4[g][3], acc1, 0, 0, 0);
+            }
+        }
+    }
+    f32x4 acc = acc0 + acc1;
+    if (wave > 0) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave > 0) return;
+    acc = ((acc + red[0][lane]) + red[1][lane]) + red[2][lane];
+    if (row >= p.M || col >= p.N) return;           // N % 4 == 0 is checked on the host for this kernel
+    f32x4 v = acc + ebias;
+    if (p.act == 1) { v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]); }
+    else if (p.act == 2) { v[0] = lrelu02(v[0]); v[1] = lrelu02(v[1]); v[2] = lrelu02(v[2]); v[3] = lrelu02(v[3]); }
+    else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    v += eres;
+    *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
+}
+
+// the 16 x 16 variant serves one or two windows (and the style MLP's single rows); K in whole groups of 16
+bool gemm_is_skinny16(const GemmParams& p) {
+    return gemm_is_skinny(p) && p.M <= 192 && p.K % 16 == 0;
+}
+
 template <int BN>
 static constexpr size_t lds_bytes() { return (size_t)(BM + BN) * LDSK * sizeof(float); }
 
@@ -495,6 +605,11 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t s) {
     // 32-bit buffer offsets: a gathered source is addressed from its base, a tile of plain A / W from the tile's first row
     if (p.gather && (long long)p.M / p.T_out * p.T_src * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     if (128ll * p.lda * 4 >= (1ll << 31) || 128ll * p.K * 4 >= (1ll << 31)) return hipErrorInvalidValue;
+    if (gemm_is_skinny16(p)) {
+        dim3 grid(((p.M + 15) / 16) * ((p.N + 15) / 16));
+        hipLaunchKernelGGL(mocha_gemm_skinny16, grid, dim3(256), 0, s, p);
+        return hipGetLastError();
+    }
     if (gemm_is_skinny(p)) {
         dim3 grid(((p.M + 31) / 32) * ((p.N + 31) / 32));
         hipLaunchKernelGGL(mocha_gemm_skinny, grid, dim3(256), 0, s, p);

@@ -40,7 +40,8 @@ struct GemmParams {
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 bool gemm_is_narrow(const GemmParams& p);
 bool gemm_is_small(const GemmParams& p);    // true: mid-size launch -> 64 x 64 tiles
-bool gemm_is_skinny(const GemmParams& p);   // true: a handful of windows -> mocha_gemm_skinny (32x32 tile per workgroup, 4-way in-workgroup split-K)
+bool gemm_is_skinny(const GemmParams& p);
+bool gemm_is_skinny16(const GemmParams& p); // true: one or two windows -> mocha_gemm_skinny16 (16x16 tile per workgroup, every load of a wave's K quarter in flight at once)   // true: a handful of windows -> mocha_gemm_skinny (32x32 tile per workgroup, 4-way in-workgroup split-K)
 hipError_t gemm_init();           // one-time function attributes (dynamic LDS size)
 // fp32 GEMM on the bf16 matrix pipe (gemm_x3.hip): both operands as three bf16 planes, six MFMA passes, fp32-accurate.
 // p.Wsplit = the packed image of W made by launch_pack_x3 (gemm_x3_packed_elems(N, K) bf16).

@@ -393,6 +393,7 @@ int prof_begin(mocha_ctx* c, hipStream_t s, const char* kernel, const char* site
     } while (0)
 
 const char* gemm_kernel_name(const GemmParams& p) {
+    if (gemm_is_skinny16(p)) return "mocha_gemm_skinny16";
     if (gemm_is_skinny(p)) return "mocha_gemm_skinny";
     if (gemm_is_small(p)) return "mocha_gemm_f32<64,2,2,1,1>";
     return gemm_is_narrow(p) ? "mocha_gemm_f32<64,4,1,1,2>" : "mocha_gemm_f32<128,2,2,2,2>";
