@@ -15,6 +15,7 @@
 //      ds_read_b64_tr_b16, which hands lane (dim, h) the four consecutive keys of its column: two reads give the A operand in the
 //      same key order.  No transposing stores, P never leaves the register file.
 #include "kernels.h"
+#include <type_traits>
 #include "device_utils.h"
 
 namespace mocha {
@@ -33,8 +34,12 @@ static constexpr int AX_OPER = 3 * AX_PLANE;             // K or Q chunk, three 
 static constexpr int AX_VPLANE = AX_ROWS * 64;           // V pass plane: [key][64 dims]
 static constexpr int AX_LDS = 2 * AX_OPER > 3 * AX_VPLANE ? 2 * AX_OPER : 3 * AX_VPLANE;     // 18 816 bf16 = 37 632 B
 
-template <int DH>
-__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) void mocha_attention_x3(AttnParams p) {
+// PF2 (a handful of windows: fewer workgroups than CUs, so the kernel is a chain of memory round trips - one per 32-dim K/Q chunk and
+// per 64-dim V pass): chunks are fetched TWO steps ahead into alternating register sets, and the first two V passes are already in
+// flight while the softmax runs.  Same arithmetic in the same order: results are bit-identical to the one-step-ahead variant, which
+// keeps its 3 waves per SIMD for full batches.
+template <int DH, bool PF2>
+__global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(PF2 ? 2 : 3, PF2 ? 2 : 3))) void mocha_attention_x3(AttnParams p) {
     constexpr int NTHR = 192, NKT = 3;
     __shared__ __attribute__((aligned(16))) unsigned short sm[AX_LDS];
     unsigned short* Ks = sm;
@@ -65,7 +70,7 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
     // a chunk of K (96 x 32) and of Q (96 x 32): 768 16-byte pieces each, four per thread; rows beyond nk / nq are clamped to the last
     // valid row (the scores of padded keys are masked below, padded queries are never stored)
-    f32x4 kr[4], qr[4];
+    f32x4 kr[PF2 ? 2 : 1][4], qr[PF2 ? 2 : 1][4];
     unsigned k_off[4], q_off[4];
     int st_off[4];                                       // bf16 offset of this piece inside a plane of the chunk image
 #pragma unroll
@@ -77,19 +82,21 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         q_off[i] = (unsigned)(rq * p.ldq + c * 4) * 4u;
         st_off[i] = (c >> 1) * AX_BLK + row * 8 + (c & 1) * 4;
     }
-    auto fetch_kq = [&](int c) __attribute__((always_inline)) {
+    auto fetch_kq = [&](int c, auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            kr[i] = bload(rsk, k_off[i], (unsigned)c * 128u);
-            qr[i] = bload(rsq, q_off[i], (unsigned)c * 128u);
+            kr[S][i] = bload(rsk, k_off[i], (unsigned)c * 128u);
+            qr[S][i] = bload(rsq, q_off[i], (unsigned)c * 128u);
         }
     };
-    auto stage_kq = [&]() __attribute__((always_inline)) {
+    auto stage_kq = [&](auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             u32x2 pk[3], pq[3];
-            plane_split4(kr[i], pk);
-            plane_split4(qr[i], pq);
+            plane_split4(kr[S][i], pk);
+            plane_split4(qr[S][i], pq);
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 *reinterpret_cast<u32x2*>(Ks + q * AX_PLANE + st_off[i]) = pk[q];
@@ -97,11 +104,17 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             }
         }
     };
-    fetch_kq(0);
-    stage_kq();
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, PF2 ? 1 : 0>;
+    constexpr int NC = DH / 32, NP = DH / 64;
+    fetch_kq(0, S0{});
+    if (PF2) fetch_kq(1, S1{});
+    stage_kq(S0{});
     __syncthreads();
-    for (int c = 0; c < DH / 32; ++c) {
-        if (c + 1 < DH / 32) fetch_kq(c + 1);
+    auto s_chunk = [&](int c, auto cur_set, auto nxt_set) __attribute__((always_inline)) {
+        // PF2: the set chunk c was staged from is free - chunk c + 2 goes there; otherwise chunk c + 1 into the only set
+        if (PF2) { if (c + 2 < NC) fetch_kq(c + 2, cur_set); }
+        else if (c + 1 < NC) fetch_kq(c + 1, S0{});
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             s16x8 a[3][NKT], bq[3];
@@ -119,9 +132,42 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PLANE_PA[pr]][t], bq[PLANE_PB[pr]], st[t], 0, 0, 0);
         }
         __syncthreads();
-        if (c + 1 < DH / 32) stage_kq();
+        if (c + 1 < NC) stage_kq(nxt_set);
         __syncthreads();
+    };
+    for (int c = 0; c < NC; c += 2) {                   // NC is even: the register sets alternate statically
+        s_chunk(c, S0{}, S1{});
+        s_chunk(c + 1, S1{}, S0{});
     }
+
+    // a V pass (96 keys x 64 dims): 1536 pieces, eight per thread; 16 lanes cover a key's 256 bytes
+    f32x4 vr[PF2 ? 2 : 1][8];
+    unsigned v_off[8];
+    int vs_off[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int f = tid + NTHR * i;
+        const int row = f >> 4, c4 = (f & 15) * 4;
+        const int rv = row < nk ? row : nk - 1;          // padded keys carry P = 0
+        v_off[i] = (unsigned)(rv * p.ldv + c4) * 4u;
+        vs_off[i] = row * 64 + c4;
+    }
+    auto fetch_v = [&](int dp, auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vr[S][i] = bload(rsv, v_off[i], (unsigned)dp * 256u);
+    };
+    auto stage_v = [&](auto set) __attribute__((always_inline)) {
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            u32x2 pv[3];
+            plane_split4(vr[S][i], pv);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(Vs + q * AX_VPLANE + vs_off[i]) = pv[q];
+        }
+    };
+    if (PF2) { fetch_v(0, S0{}); if (NP > 1) fetch_v(1, S1{}); }      // in flight under the softmax
 
     // ---------------- phase 2: softmax over keys for this lane's query (fp32, as attention.hip)
     // st[t][r] = S[query = 32*wave + l31][key = 32t + (r&3) + 8(r>>2) + 4hh]
@@ -169,39 +215,15 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     // ---------------- phase 3: O^T[d][query] = sum_key V[key][d] * P^T[key][query], 64 head dims per pass
     const int query = wave * 32 + l31;
     float* og = p.out + ((size_t)b * nq + query) * p.ldo + head * DH;
-    // a V pass (96 keys x 64 dims): 1536 pieces, eight per thread; 16 lanes cover a key's 256 bytes
-    f32x4 vr[8];
-    unsigned v_off[8];
-    int vs_off[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int f = tid + NTHR * i;
-        const int row = f >> 4, c4 = (f & 15) * 4;
-        const int rv = row < nk ? row : nk - 1;          // padded keys carry P = 0
-        v_off[i] = (unsigned)(rv * p.ldv + c4) * 4u;
-        vs_off[i] = row * 64 + c4;
-    }
-    auto fetch_v = [&](int dp) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) vr[i] = bload(rsv, v_off[i], (unsigned)dp * 256u);
-    };
-    auto stage_v = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            u32x2 pv[3];
-            plane_split4(vr[i], pv);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(Vs + q * AX_VPLANE + vs_off[i]) = pv[q];
-        }
-    };
     // transposed read: lane L of a 16-lane group supplies the address of row (L & 15) >> 2, columns 4 (L & 3) ..; it receives
     // column L & 15 of the four rows.  Group g = lane >> 4: dims 16 (g & 1) .. + 15 of the 32-dim block, key half h = g >> 1.
     const int tr_base = ((4 * hh + ((lane & 15) >> 2)) * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3));
-    fetch_v(0);
-    stage_v();                                           // the chunk stages are free: every wave passed the last barrier of phase 1
+    if (!PF2) fetch_v(0, S0{});                          // PF2: passes 0 and 1 were fetched before the softmax (below)
+    stage_v(S0{});                                       // the chunk stages are free: every wave passed the last barrier of phase 1
     __syncthreads();
-    for (int dp = 0; dp < DH / 64; ++dp) {
-        if (dp + 1 < DH / 64) fetch_v(dp + 1);
+    auto v_pass = [&](int dp, auto cur_set, auto nxt_set) __attribute__((always_inline)) {
+        if (PF2) { if (dp + 2 < NP) fetch_v(dp + 2, cur_set); }
+        else if (dp + 1 < NP) fetch_v(dp + 1, S0{});
         f32x16 o[2];
 #pragma unroll
         for (int d = 0; d < 2; ++d)
@@ -236,8 +258,12 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 }
         }
         __syncthreads();
-        if (dp + 1 < DH / 64) stage_v();
+        if (dp + 1 < NP) stage_v(nxt_set);
         __syncthreads();
+    };
+    for (int dp = 0; dp < NP; dp += 2) {                 // NP is even
+        v_pass(dp, S0{}, S1{});
+        v_pass(dp + 1, S1{}, S0{});
     }
 }
 
@@ -245,8 +271,14 @@ hipError_t launch_attention_x3(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     if (p.nq < 1 || p.nk < 1 || p.nq > 96 || p.nk > 96 || (p.dh != 128 && p.dh != 256)) return hipErrorInvalidValue;
     dim3 grid((unsigned)(((p.B + 7) / 8) * 8 * p.heads));
-    if (p.dh == 128) hipLaunchKernelGGL((mocha_attention_x3<128>), grid, dim3(192), 0, s, p);
-    else hipLaunchKernelGGL((mocha_attention_x3<256>), grid, dim3(192), 0, s, p);
+    const bool pf2 = (long long)p.B * p.heads <= 256;    // fewer (window, head) workgroups than CUs: latency-bound, prefetch two steps ahead
+    if (p.dh == 128) {
+        if (pf2) hipLaunchKernelGGL((mocha_attention_x3<128, true>), grid, dim3(192), 0, s, p);
+        else hipLaunchKernelGGL((mocha_attention_x3<128, false>), grid, dim3(192), 0, s, p);
+    } else {
+        if (pf2) hipLaunchKernelGGL((mocha_attention_x3<256, true>), grid, dim3(192), 0, s, p);
+        else hipLaunchKernelGGL((mocha_attention_x3<256, false>), grid, dim3(192), 0, s, p);
+    }
     return hipGetLastError();
 }
 

@@ -395,43 +395,62 @@ hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, f
 static constexpr int IN_NG = 8;             // token groups per window
 static constexpr int IN_MAXT = 12;          // tokens per thread (n <= 96)
 
+// QW = channel quads per workgroup: 64 (one workgroup per window; large batches) or 16 (a window's 256 channels over four workgroups:
+// a handful of windows would otherwise sit on a handful of CUs, each moving a window's 0.3-0.5 MB alone).  A channel's tokens are
+// partitioned and summed in the same order either way: results are bit-identical.
+template <int QW>
 __device__ __forceinline__ f32x4 group_sum4(f32x4 v, f32x4* red, int q, int g) {
     __syncthreads();                         // red[] may still be read from the previous reduction
-    red[g * 64 + q] = v;
+    red[g * QW + q] = v;
     __syncthreads();
     f32x4 a = red[q];
 #pragma unroll
-    for (int k = 1; k < IN_NG; ++k) a += red[k * 64 + q];      // fixed order: deterministic
+    for (int k = 1; k < IN_NG; ++k) a += red[k * QW + q];      // fixed order: deterministic
     return a;
 }
 
+template <int QW>
 __device__ __forceinline__ void inorm_stats(const f32x4* xv, int cnt, int n, f32x4* red, int q, int g, f32x4& mean, f32x4& den) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) s += xv[i];
-    mean = group_sum4(s, red, q, g) / (float)n;
+    mean = group_sum4<QW>(s, red, q, g) / (float)n;
     f32x4 qq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) { const f32x4 d = xv[i] - mean; qq += d * d; }
-    qq = group_sum4(qq, red, q, g) / (float)(n - 1);
+    qq = group_sum4<QW>(qq, red, q, g) / (float)(n - 1);
     den[0] = sqrtf(qq[0]) + 1e-5f; den[1] = sqrtf(qq[1]) + 1e-5f; den[2] = sqrtf(qq[2]) + 1e-5f; den[3] = sqrtf(qq[3]) + 1e-5f;
 }
 
-__global__ __launch_bounds__(64 * IN_NG) void mocha_instnorm(const float* __restrict__ x, float* __restrict__ out,
+template <int QW>
+__global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __restrict__ x, float* __restrict__ out,
                                                              float* __restrict__ mean_out, const float* __restrict__ gm,
                                                              const float* __restrict__ gs, float* __restrict__ zn, int n) {
-    __shared__ f32x4 red[64 * IN_NG];
-    const int b = blockIdx.x, q = threadIdx.x & 63, g = threadIdx.x >> 6;
+    __shared__ f32x4 red[QW * IN_NG];
+    const int b = blockIdx.x, ql = threadIdx.x % QW, g = threadIdx.x / QW;
+    const int q = blockIdx.y * QW + ql;                     // channel quad 0..63
     const int cnt = (n - g + IN_NG - 1) / IN_NG;           // tokens g, g + NG, ...
     const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * n * 256) + q;
     f32x4 xv[IN_MAXT];
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) xv[i] = xb[(size_t)(g + IN_NG * i) * 64];
+    // the z-score's operands do not depend on the statistics: the small-batch variant (latency-bound) fetches them now, under the
+    // two reductions; the large-batch one (bandwidth-bound, register-lean for occupancy) where they are used
+    constexpr bool EARLY = QW < 64;
+    f32x4 zm[EARLY ? IN_MAXT : 1], zs[EARLY ? IN_MAXT : 1];
+    if (EARLY && zn) {
+#pragma unroll
+        for (int i = 0; i < IN_MAXT; ++i)
+            if (i < cnt) {
+                const int t = g + IN_NG * i;
+                zm[EARLY ? i : 0] = reinterpret_cast<const f32x4*>(gm)[t * 64 + q]; zs[EARLY ? i : 0] = reinterpret_cast<const f32x4*>(gs)[t * 64 + q];
+            }
+    }
     f32x4 mean, den;
-    inorm_stats(xv, cnt, n, red, q, g, mean, den);
+    inorm_stats<QW>(xv, cnt, n, red, ql, g, mean, den);
     if (mean_out && g == 0) reinterpret_cast<f32x4*>(mean_out + (size_t)b * 256)[q] = mean;
     f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * n * 256) + q;
 #pragma unroll
@@ -441,26 +460,33 @@ __global__ __launch_bounds__(64 * IN_NG) void mocha_instnorm(const float* __rest
             const f32x4 v = (xv[i] - mean) / den;
             if (out) ob[(size_t)t * 64] = v;                   // out == nullptr: only the z-scored copy is wanted (characterize: cnt itself is not an output)
             if (zn) {
-                const f32x4 m = reinterpret_cast<const f32x4*>(gm)[t * 64 + q], sd = reinterpret_cast<const f32x4*>(gs)[t * 64 + q];
+                const f32x4 m = EARLY ? zm[EARLY ? i : 0] : reinterpret_cast<const f32x4*>(gm)[t * 64 + q];
+                const f32x4 sd = EARLY ? zs[EARLY ? i : 0] : reinterpret_cast<const f32x4*>(gs)[t * 64 + q];
                 (reinterpret_cast<f32x4*>(zn + (size_t)b * n * 256) + q)[(size_t)t * 64] = (v - m) / sd;
             }
         }
 }
 
+// a handful of windows: four workgroups per window
+static inline bool inorm_split(int B) { return B <= 32; }
+
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
                            int B, int n, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (n > IN_NG * IN_MAXT || n < 2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_instnorm, dim3(B), dim3(64 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n);
+    if (inorm_split(B)) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n);
+    else hipLaunchKernelGGL(mocha_instnorm<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n);
     return hipGetLastError();
 }
 
 // AdaIN followed by the attention's own mapping norm (net/transformer.py:108-113 then :49-56):
 //   xad = (1+gamma) * IN(x) + beta ;  qin = IN(xad)
-__global__ __launch_bounds__(64 * IN_NG) void mocha_adain(const float* __restrict__ x, const float* __restrict__ gb,
+template <int QW>
+__global__ __launch_bounds__(QW * IN_NG) void mocha_adain(const float* __restrict__ x, const float* __restrict__ gb,
                                                           float* __restrict__ xad, float* __restrict__ qin, int n) {
-    __shared__ f32x4 red[64 * IN_NG];
-    const int b = blockIdx.x, q = threadIdx.x & 63, g = threadIdx.x >> 6;
+    __shared__ f32x4 red[QW * IN_NG];
+    const int b = blockIdx.x, ql = threadIdx.x % QW, g = threadIdx.x / QW;
+    const int q = blockIdx.y * QW + ql;
     const int cnt = (n - g + IN_NG - 1) / IN_NG;
     const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * n * 256) + q;
     f32x4 xv[IN_MAXT];
@@ -471,7 +497,7 @@ __global__ __launch_bounds__(64 * IN_NG) void mocha_adain(const float* __restric
     const f32x4 beta = reinterpret_cast<const f32x4*>(gb + (size_t)b * 512 + 256)[q];
     gamma1 += 1.f;
     f32x4 mean, den;
-    inorm_stats(xv, cnt, n, red, q, g, mean, den);
+    inorm_stats<QW>(xv, cnt, n, red, ql, g, mean, den);
     f32x4* ab = reinterpret_cast<f32x4*>(xad + (size_t)b * n * 256) + q;
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
@@ -479,7 +505,7 @@ __global__ __launch_bounds__(64 * IN_NG) void mocha_adain(const float* __restric
             xv[i] = gamma1 * ((xv[i] - mean) / den) + beta;
             ab[(size_t)(g + IN_NG * i) * 64] = xv[i];
         }
-    inorm_stats(xv, cnt, n, red, q, g, mean, den);
+    inorm_stats<QW>(xv, cnt, n, red, ql, g, mean, den);
     f32x4* qb = reinterpret_cast<f32x4*>(qin + (size_t)b * n * 256) + q;
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
@@ -489,7 +515,8 @@ __global__ __launch_bounds__(64 * IN_NG) void mocha_adain(const float* __restric
 hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin, int B, int n, hipStream_t s) {
     if (B <= 0) return hipSuccess;
     if (n > IN_NG * IN_MAXT || n < 2) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_adain, dim3(B), dim3(64 * IN_NG), 0, s, x, gb, xad, qin, n);
+    if (inorm_split(B)) hipLaunchKernelGGL(mocha_adain<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, gb, xad, qin, n);
+    else hipLaunchKernelGGL(mocha_adain<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, gb, xad, qin, n);
     return hipGetLastError();
 }
 

@@ -121,3 +121,18 @@ def test_attention_on_either_engine(B):
     for a, b in zip(outs[1], outs[0]):
         scale = max(1.0, float(np.abs(b).max()))
         assert np.abs(a - b).max() < 2e-5 * scale, (np.abs(a - b).max(), scale)
+
+
+def test_attention_prefetch_variants_are_bit_identical():
+    """mocha_attention_x3 has a two-steps-ahead prefetch variant for launches with fewer (window, head) workgroups than CUs
+    (B * heads <= 256) and the one-step-ahead variant for full batches: same arithmetic in the same order.  64 windows take the
+    first, 65 the second; every GEMM of both calls is the same kernel with per-row arithmetic, so the shared windows must agree
+    bit for bit through the encoder (head dim 128) and the decoder (head dim 256)."""
+    sd = weights.synthetic_state_dict(31, 1.2)
+    model = Generator(device="cuda:0").load_state_dict(sd).eval()
+    tok = torch.from_numpy(synthetic.token_features(7, 65)).cuda()
+    cha = torch.from_numpy(synthetic.token_features(8, 65)).cuda()
+    e65, e64 = model.encoder(tok), model.encoder(tok[:64].contiguous())
+    assert torch.equal(e65[:64], e64)
+    d65, d64 = model.decoder(tok, cha), model.decoder(tok[:64].contiguous(), cha[:64].contiguous())
+    assert torch.equal(d65[:64], d64)
