@@ -51,18 +51,6 @@ size_t gemm_x3_packed_elems(int N, int K);
 hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s, const float* wsub = nullptr);   // wsub: K values subtracted from every row
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s);
 
-// ---------------------------------------------------------------------------------------
-// Fused transformer-layer tail (xf_tail.hip; net/transformer.py:91-94):
-//   x1 = ao[M,Kin] · Wo[256,Kin]^T + bo + resid[M,256];   out[M,256] = GELU(x1 · W1[512,256]^T + b1) · W2[256,512]^T + b2 + x1
-// ---------------------------------------------------------------------------------------
-struct XfTailParams {
-    const float* ao; int Kin;
-    const float* Wo; const float* bo; const float* resid;
-    const float* W1; const float* b1; const float* W2; const float* b2;
-    float* out; int M;
-};
-hipError_t xf_tail_init();
-hipError_t launch_xf_tail(const XfTailParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Multi-head attention, nq queries x nk keys (<= 192), one workgroup per (window, head)

@@ -159,8 +159,6 @@ struct mocha_ctx {
     std::map<std::tuple<const float*, int, int>, unsigned short*> x3w;
     bool fold_decoder = true;          // decoder key / value projections folded into the query / output weights
     bool fold_joint = true;            // embedding joint block: gcn 1x1 conv folded into the k=5 temporal conv (one K = 960 GEMM)
-    bool gather_pool = false;          // AvgPool(4) folded into the k=5 temporal conv's A gather instead of mocha_window_sums
-    bool fuse_tail = false; int fuse_tail_min_rows = 8192;      // out-proj + FF in one launch (xf_tail.hip) from this many token rows on
     int* bone_parents = nullptr;       // device: parents of the (V+1)-bone skeleton with the root bone in front
     float* pose_norm = nullptr;        // [x_mean | x_std | y_mean | y_std], (V+1)*C_in each (norm.npz of the reference)
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
@@ -478,7 +476,7 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
                                   c->cfg.C_in, raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s, c->gemm_x3));
         b += b2;
     }
-    if (c->fold_joint && !c->gather_pool) {
+    if (c->fold_joint) {
         // gcn conv folded into the temporal conv (mocha_finalize_weights: emb.Wc): the 4-frame sums of the five taps are taken on
         // the 192 adjacency-mixed channels and ONE GEMM, K = 5 x 192, does both convolutions and the AvgPool
         LAUNCH(c, s, "mocha_window_sums", "emb.window_sums", b * 90.0 * 960 * 4, b * 4.0 * (360.0 * 192 + 90.0 * 960),
@@ -494,12 +492,7 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     // temporal conv k=5 (reflect) fused with AvgPool2d((4,1)):  (b*90, 5*256) x (256, 1280)^T   blocks.py:112-118, model.py:47
     GemmParams g2 = plain(WS(c, "u"), 1280, DW(c, "emb.Wt"), WS(c, "x5"), 256, b * 90, 256, 1280);
     g2.bias = DW(c, "emb.bt");
-    if (c->gather_pool) {
-        // the four averaged frames of every tap are summed by the GEMM's A loader (R = 4 gather): no 5x-wide operand in HBM
-        g2.A = WS(c, "ybar"); g2.lda = 256;
-        g2.gather = 1; g2.T_out = 15; g2.V = 6; g2.ntaps = 5; g2.pad = 2; g2.stride = 4; g2.R = 4; g2.T_full = 60;
-        g2.tshift = 0; g2.Cc = 256; g2.T_src = 60; g2.ascale = 0.25f;
-    } else {
+    {
         LAUNCH(c, s, "mocha_window_sums", "emb.window_sums", b * 90.0 * 1280 * 4, b * 4.0 * (360.0 * 256 + 90.0 * 1280),
                launch_window_sums(WS(c, "ybar"), WS(c, "u"), b * 90, 256, s));
     }
@@ -521,14 +514,6 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
 // one transformer layer's attention output projection + FF (net/transformer.py:91-94), shared by enc/dec
 int run_out_ff(mocha_ctx* c, const std::string& p, const float* ao, int inner, const float* resid, int M, int mlp,
                float* out, hipStream_t s, const char* wo = ".Wo") {
-    if (c->fuse_tail && M >= c->fuse_tail_min_rows && mlp == 512) {
-        // one launch for the whole tail: x1 and the hidden activation stay in registers (xf_tail.hip)
-        XfTailParams t{ao, inner, DW(c, p + wo), DW(c, p + ".bo"), resid, DW(c, p + ".W1"), DW(c, p + ".b1"), DW(c, p + ".W2"), DW(c, p + ".b2"), out, M};
-        const double flops = 2.0 * M * (256.0 * inner + 2.0 * 256 * 512);
-        const double bytes = 4.0 * M * (inner + 256.0 + 256.0) + 4.0 * (256.0 * inner + 2.0 * 256 * 512);
-        LAUNCH(c, s, "mocha_xf_tail", "xf.tail", flops, bytes, launch_xf_tail(t, s));
-        return 0;
-    }
     GemmParams o = plain(ao, inner, DW(c, p + wo), WS(c, "xb"), 256, M, 256, inner);
     o.bias = DW(c, p + ".bo"); o.residual = resid; o.ldr = 256;
     GEMM(c, s, "xf.out_proj", o);
@@ -844,7 +829,6 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     if (e == hipSuccess) e = gemm_init();
     if (e == hipSuccess) e = gemm_x3_init();
     if (e == hipSuccess) e = match_mfma_init();
-    if (e == hipSuccess) e = xf_tail_init();
     if (e == hipSuccess) e = featurize_init();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
@@ -1946,11 +1930,8 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "dual_min") { c->dual_min = value < 2 ? 2 : value; return 0; }
     if (n == "fold_decoder") { c->fold_decoder = value != 0; return 0; }
     if (n == "fold_joint") { c->fold_joint = value != 0; return 0; }
-    if (n == "fuse_tail") { c->fuse_tail = value != 0; return 0; }
-    if (n == "gather_pool") { c->gather_pool = value != 0; return 0; }
     if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; return 0; }
     if (n == "attention_bf16x3") { c->attn_x3 = value != 0; return 0; }
-    if (n == "fuse_tail_min_rows") { c->fuse_tail_min_rows = value < 1 ? 1 : value; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);
 }
 

@@ -452,27 +452,3 @@ def test_characterize_pair_matches_the_three_call_path():
     assert absmax(Y2[torch.from_numpy(same).to(Y2.device)], Yo.numpy()[same]) < TOL
     with pytest.raises(RuntimeError, match="workspace limit"):
         model.characterize_pair(T(synthetic.pose_windows(7, 700)), T(synthetic.pose_windows(8, 700)), mean, std)
-
-
-def test_fused_transformer_tail_matches_the_three_gemm_tail():
-    """mocha_xf_tail (out-projection + residual + FF1 + GELU + FF2 + residual in one launch, activations kept in MFMA
-    accumulators) against the three-launch tail ("fuse_tail" = 0) on encoder and decoder, full and ragged row blocks, and
-    against the oracle."""
-    sd = weights.synthetic_state_dict(41, 1.4)
-    model = Generator(device=dev()).load_state_dict(sd).eval()
-    model.set_option("fuse_tail_min_rows", 1)
-    ost = O.to_torch_state(sd)
-    for B in (1, 7, 100):                                          # 90, 630 (ragged last 64-row block), 9000 token rows
-        tok = T(synthetic.token_features(500 + B, B))
-        cha = T(synthetic.token_features(600 + B, B))
-        model.set_option("fuse_tail", 1)
-        e1, d1 = model.encoder(tok), model.decoder(tok, cha)
-        model.set_option("fuse_tail", 0)
-        e0, d0 = model.encoder(tok), model.decoder(tok, cha)
-        model.set_option("fuse_tail", 1)
-        assert not torch.equal(e1, e0)                               # the option really switches the kernel chain
-        assert float((e1 - e0).abs().max()) < 2e-5 * float(e0.abs().max())
-        assert float((d1 - d0).abs().max()) < 2e-5 * float(d0.abs().max())
-        with torch.no_grad():
-            eo = O.encoder(ost, tok.cpu()).numpy(); do = O.decoder(ost, tok.cpu(), cha.cpu()).numpy()
-        assert rel(e1, eo) < RTOL and rel(d1, do) < RTOL

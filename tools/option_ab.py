@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of a context option on the demo step (585 + 585 windows, 22 joints): python tools/option_ab.py gather_pool fuse_tail ..."""
+"""A/B of a context option on the demo step (585 + 585 windows, 22 joints): python tools/option_ab.py fold_joint fold_decoder ..."""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
