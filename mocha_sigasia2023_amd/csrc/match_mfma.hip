@@ -228,6 +228,9 @@ hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S
 //                 2 |sum dq_i b_i| <= 2^-8 ||q|| ||b|| <= 2^-9 (||q||^2 + ||b||^2) - rigorous, rel = 2^-9 plus slack for the fp32
 //                 accumulation; exact-f32 MFMA pass: ~4e-7 (||q||^2 + ||b||^2) observed, rel = 4e-6.
 //   candidates    v_n <= v_min + rel (2 ||q-c||^2 + ||b_n-c||^2 + ||b_min-c||^2)  -> the true nearest row is always among them.
+//                 bf16 bank (round 3): the rounding part is priced with the query's MEASURED ||dq|| instead of its worst case:
+//                 v_n <= v_min + 2 ||dq|| (||b_n-c|| + ||b_min-c||) + slack (...), ~0.4 of the margin above, about half the candidates.
+//                 EVERY candidate is re-evaluated (no cap): the result is the exact search over the rows the kernel scans.
 // One 1024-thread workgroup per query (a few hundred queries would not fill the chip with less).  The kernel is a chain of
 // memory round trips, so every phase issues all of its loads before it uses any: score row (all K slices in flight) and
 // the query row -> one block reduction (min score, ||q-c||^2) -> candidate list -> the candidates' bank rows, 16 waves
@@ -251,9 +254,9 @@ __global__ __launch_bounds__(SEL_T) void mocha_match_select(const float* __restr
                                                             float margin_rel, int32_t* __restrict__ idx, float* __restrict__ dist) {
     extern __shared__ __attribute__((aligned(16))) float sel_q[];      // [D]: q - c (bf16 bank) or q (fp32 bank)
     __shared__ unsigned long long rk[SEL_W];
-    __shared__ float rs[SEL_W];
+    __shared__ float rs[SEL_W], rs2[SEL_W];
     __shared__ unsigned long long r_key;
-    __shared__ float r_qn;
+    __shared__ float r_qn, r_dq;
     __shared__ int cand[SEL_CAP], csort[SEL_CAP];
     __shared__ float candv[SEL_CAP];
     __shared__ int ncand;
@@ -338,14 +341,23 @@ __global__ __launch_bounds__(SEL_T) void mocha_match_select(const float* __restr
     // ---- 2. the centred query into LDS, ||q - c||^2, and the block reduction (best score, its row; the norm)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's pieces of the query row have landed ...
     __syncthreads();                                             // ... and everyone else's
-    float qn = 0.f;
+    // bf16 bank: also ||dq||^2, dq = (q - c) - bf16(q - c) - exactly the rounding the coarse pass's query plane carries
+    // (mocha_center_bf16 forms q - c with the same fp32 subtraction and the same round-to-nearest-even conversion)
+    float qn = 0.f, dqn = 0.f;
 #pragma unroll
     for (int i = 0; i < QN; ++i) {
         const int e = (i * SEL_T + tid) * 4;
         if (e < D) {
             const f32x4 qc = *reinterpret_cast<const f32x4*>(sel_q + e) - cv[i];
             qn = fmaf(qc[0], qc[0], qn); qn = fmaf(qc[1], qc[1], qn); qn = fmaf(qc[2], qc[2], qn); qn = fmaf(qc[3], qc[3], qn);
-            if (bank16) *reinterpret_cast<f32x4*>(sel_q + e) = qc;
+            if (bank16) {
+                *reinterpret_cast<f32x4*>(sel_q + e) = qc;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = qc[k] - __uint_as_float(bf16_bits(qc[k]) << 16);
+                    dqn = fmaf(d, d, dqn);
+                }
+            }
         }
     }
 #pragma unroll
@@ -353,30 +365,38 @@ __global__ __launch_bounds__(SEL_T) void mocha_match_select(const float* __restr
         const unsigned long long k2 = __shfl_xor(key, o);
         key = k2 < key ? k2 : key;
         qn += __shfl_xor(qn, o);
+        dqn += __shfl_xor(dqn, o);
     }
-    if (lane == 0) { rk[wave] = key; rs[wave] = qn; }
+    if (lane == 0) { rk[wave] = key; rs[wave] = qn; rs2[wave] = dqn; }
     __syncthreads();
     if (wave == 0) {
         unsigned long long k = lane < SEL_W ? rk[lane] : ~0ull;
-        float sq = lane < SEL_W ? rs[lane] : 0.f;
+        float sq = lane < SEL_W ? rs[lane] : 0.f, sd = lane < SEL_W ? rs2[lane] : 0.f;
 #pragma unroll
         for (int o = SEL_W / 2; o > 0; o >>= 1) {
             const unsigned long long k2 = __shfl_xor(k, o);
             k = k2 < k ? k2 : k;
             sq += __shfl_xor(sq, o);
+            sd += __shfl_xor(sd, o);
         }
-        if (lane == 0) { r_key = k; r_qn = sq; }
+        if (lane == 0) { r_key = k; r_qn = sq; r_dq = sd; }
     }
     __syncthreads();
     const unsigned nmin = (unsigned)(r_key & 0xffffffffull);
     const unsigned umin = (unsigned)(r_key >> 32);
     const float vmin = __uint_as_float((umin & 0x80000000u) ? (umin & 0x7fffffffu) : ~umin);
     const bool none = !(vmin < INFINITY);                        // no finite score at all (NaN / inf inputs): row 0, distance NaN / inf
-    const float base = 2.f * r_qn + (none ? 0.f : bnorm[nmin]);
+    const float bmin = none ? 0.f : bnorm[nmin];
+    const float base = 2.f * r_qn + bmin;
+    // bf16 bank: the coarse score of row n differs from the exact one by 2 |sum dq_i b_ni| <= 2 ||dq|| ||b_n - c|| (Cauchy-Schwarz with the
+    // MEASURED ||dq|| of this query: about 0.4 of the worst case 2^-9 ||q - c|| the first version priced), plus margin_rel (...) for the
+    // fp32 accumulation of the pass.  fp32 bank: margin_rel (...) alone, as before.
+    const float dq2 = bank16 ? 2.000002f * sqrtf(r_dq) : 0.f;
+    const float sbmin = sqrtf(bmin);
 
     // ---- 3. candidates; passes over index windows only when more than SEL_CAP rows qualify (each window then holds <= SEL_CAP)
     auto qualifies = [&](float sc, float b, unsigned n) -> bool {
-        return n == nmin || sc <= vmin + margin_rel * (base + b);
+        return n == nmin || sc <= vmin + dq2 * (sqrtf(b) + sbmin) + margin_rel * (base + b);
     };
     int total = 0;
     if (!none) {

@@ -747,14 +747,14 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     DevBuf& mS = c->match_S[set];
     if (c->bank_is_bf16) {
         // bf16 bank: one bf16 plane of the centred queries against the centred bf16 bank; the select kernel re-evaluates every
-        // row whose coarse score is within the query rounding's error bound (2^-9 (2||q||^2 + ||b||^2 + ||b0||^2), plus slack for the
-        // fp32 accumulation: 0.002) of the best exactly - fp32 centred query against the bf16 rows - so the result is the exact
-        // search over the rounded bank
+        // row whose coarse score is within the query rounding's error bound of the best one - 2 ||dq|| (||b|| + ||b0||) with the query's
+        // measured rounding residual dq, plus 5e-5 (2||q||^2 + ||b||^2 + ||b0||^2) of slack for the pass's fp32 accumulation - exactly
+        // (fp32 centred query against the bf16 rows), so the result is the exact search over the rounded bank
         const int ksplit = match_bf16_ksplit(Q, N);
         LAUNCH(c, s, "mocha_match_gemm_bf16", "match.qk_bf16", 2.0 * Q * (double)N * D, 2.0 * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
                launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s));
         LAUNCH(c, s, "mocha_match_select", "match.select", 0.0, 4.0 * ksplit * Q * N + Q * (8.0 * D + 8 * 2.0 * D),
-               launch_match_select(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, nullptr, c->bank_bf16, 0.002f,
+               launch_match_select(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, nullptr, c->bank_bf16, 5e-5f,
                                    Q, N, D, idx, dist, s));
         return 0;
     }
