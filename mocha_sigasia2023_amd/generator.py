@@ -492,8 +492,8 @@ class StreamingCharacterizer:
             m.set_option("lanes", lanes)                   # re-plans the workspace sets (generation moves)
         bank.activate()
 
-    def _enqueue(self, lane: int = 0):
-        if getattr(self.model, "_bank", None) is not self.bank:
+    def _enqueue(self, lane: int = 0, check_bank: bool = True):
+        if check_bank and getattr(self.model, "_bank", None) is not self.bank:
             self.bank.activate()                           # another bank was made current: ours again (bumps the generation)
         if self.use_graph:
             self.model._ctx.call("mocha_step_graph_lane", lane, _ptr(self.xs[lane]), _ptr(self.mean), _ptr(self.std), _ptr(self.ys[lane]),
@@ -516,10 +516,14 @@ class StreamingCharacterizer:
         arithmetic per window as ``step``: results are bit-identical to it.  -> (Y (W,60,V,15), idx (W,)), ordered on the
         caller's stream when the call returns (no host synchronisation)."""
         m = self.model
-        W = windows.shape[0]
         wins = _dev_f32(windows, m.device, tuple(self.x.shape[1:]), "windows")
+        W = wins.shape[0]
         Y = torch.empty((W,) + tuple(self.x.shape[1:]), dtype=torch.float32, device=m.device)
         idx = torch.empty((W,), dtype=torch.int32, device=m.device)
+        if W == 0:
+            return Y, idx
+        if getattr(m, "_bank", None) is not self.bank:
+            self.bank.activate()                           # once, on the caller's stream, before the lanes fork
         if self._lane_streams is None:
             self._lane_streams = [torch.cuda.Stream(device=m.device) for _ in range(self.lanes)]
         cur = torch.cuda.current_stream(m.device)
@@ -530,7 +534,7 @@ class StreamingCharacterizer:
             k = i % self.lanes
             with torch.cuda.stream(self._lane_streams[k]):
                 self.xs[k].copy_(wins[i:i + 1], non_blocking=True)
-                self._enqueue(k)
+                self._enqueue(k, check_bank=False)
                 Y[i:i + 1].copy_(self.ys[k], non_blocking=True)
                 idx[i:i + 1].copy_(self.idxs[k], non_blocking=True)
         for st in self._lane_streams:

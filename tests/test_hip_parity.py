@@ -299,6 +299,16 @@ def test_streaming_lanes_reproduce_the_synchronous_steps(lanes):
         assert torch.equal(Y, torch.stack(Ys))
     y, ix = sc.step(src[3])
     assert torch.equal(y, Ys[3]) and int(ix.item()) == Is[3]
+    # fewer windows than lanes, no windows at all, and a bank switch between two clips (the lanes' graphs are re-captured)
+    Y1, i1 = sc.run_clip(src[:1])
+    assert torch.equal(Y1[0], Ys[0]) and i1.cpu().tolist() == Is[:1]
+    Y0, i0 = sc.run_clip(src[:0])
+    assert Y0.shape[0] == 0 and i0.shape[0] == 0
+    other = ContextBank(model, nm_c[:7].clone(), enc_c[:7].clone())          # becomes the context's current bank
+    assert other.query(nm_c[:3], return_distance=False)[:, 0].cpu().tolist() == [0, 1, 2]
+    Y2, i2 = sc.run_clip(src)                                                # ours again: re-activated once, before the lanes fork
+    torch.cuda.synchronize()
+    assert i2.cpu().tolist() == Is and torch.equal(Y2, torch.stack(Ys))
     model.set_option("lanes", 1)
 
 
