@@ -218,6 +218,9 @@ def bank4k(a):
     import zlib
     idx_all = D.all_gather_rows(idx, W).cpu().numpy().astype(np.int32)
     y_abs = D.max_over_ranks(float(Y.abs().max()), dev)
+    # ... and a per-window fingerprint of the poses (sum |Y| of 16 windows spread over all shards): a split that mixed windows up
+    # would keep the index CRC when the indices happen to coincide, not this
+    fp_all = D.all_gather_rows(Y.abs().sum(dim=(1, 2, 3)), W).cpu().numpy()
     if rank == 0:
         print(json.dumps({
             "metric": METRIC[V], "value": W * a.steps / elapsed, "unit": "frames/s",
@@ -227,7 +230,8 @@ def bank4k(a):
             "config": {"workload": f"BASELINE configs[2]/[3]: 1024 windows x 4096-entry bank (bf16 cnt), V={V}, {W // world} windows per GPU",
                        "parallelism": f"dp{world}, bank broadcast from rank 0"},
             "bank_broadcast_ms": bcast_ms, "bank_bytes": 2 * NB * 90 * 256 * 4,
-            "idx_crc32": zlib.crc32(idx_all.tobytes()), "idx_head": idx_all[:8].tolist(), "max_abs_Y": y_abs}), flush=True)
+            "idx_crc32": zlib.crc32(idx_all.tobytes()), "idx_head": idx_all[:8].tolist(), "idx_distinct": int(len(np.unique(idx_all))),
+            "max_abs_Y": y_abs, "y_fingerprint": [float(v) for v in fp_all[:: W // 16][:16]]}), flush=True)
     if torch.distributed.is_initialized():
         D.barrier(); torch.distributed.destroy_process_group()
 

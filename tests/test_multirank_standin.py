@@ -144,6 +144,10 @@ def test_bench_bank4k_split_two_ways_reproduces_the_one_rank_indices(standin):
     assert two["bank_broadcast_ms"] is not None and two["bank_broadcast_ms"] > 0
     assert two["idx_crc32"] == one["idx_crc32"] and two["idx_head"] == one["idx_head"]
     assert abs(two["max_abs_Y"] - one["max_abs_Y"]) < 1e-4
+    # per-window fingerprints of 16 windows spread over both shards: the right window in the right place (the two runs batch
+    # 1024 and 512 windows, so GEMM tile choices and with them the last bits may differ)
+    assert len(one["y_fingerprint"]) == 16 and np.allclose(two["y_fingerprint"], one["y_fingerprint"], rtol=1e-5)
+    assert len(set(np.round(one["y_fingerprint"], 3))) > 8                      # the windows really differ from each other
 
 
 @pytest.mark.timeout(3000)
