@@ -55,7 +55,11 @@ cha_X = model.featurize(*cha_bones)
 # ---- NN branch for the whole clip                                                            :188-194, 271-302, 438-443, 465-467
 Y, idx, cha_enc, cha_nm = model.characterize_pair(src_X, cha_X, cnt_mean, cnt_std, return_index=True, return_bank=True, raw=True)
 bank = ContextBank(model, cha_nm, cha_enc)
-nn = retarget_clip(bank, src_X, cnt_mean, cnt_std, rvel, rang, src_speed, contact, raw=True)
+# the reference's "cm_" stream takes the decoded poses as they are: no blending with the previous frame, no foot-lock IK
+# (test_fullframework.py:512-527, 637-641)
+from mocha_sigasia2023_amd import PostProcessor  # noqa: E402
+nn = retarget_clip(bank, src_X, cnt_mean, cnt_std, rvel, rang, src_speed, contact, raw=True,
+                   post=PostProcessor(model, ik_enabled=False, blend=False))
 # ---- Ours branch: CVAE frame loop seeded with the first matched character feature            :298, 436, 446-457
 src_enc, src_cnt = model.encode(src_X, raw=True)
 sess = OursSession(model, cvae, *stats).reset(cha_enc[int(idx[0])])
