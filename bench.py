@@ -246,9 +246,11 @@ def match_records(model, dev):
     out = {}
     g = torch.Generator(device=dev); g.manual_seed(16384)
     big = torch.randn((16384, D), device=dev, generator=g)
-    for name, N, Q, bf16 in (("q1_x_16k_f32", 16384, 1, False), ("q1_x_16k_bf16", 16384, 1, True), ("q128_x_4k_bf16", 4096, 128, True),
-                             ("q128_x_4k_f32", 4096, 128, False)):
+    for name, N, Q, bf16, scan16 in (("q1_x_16k_f32", 16384, 1, False, 1), ("q1_x_16k_f32_scan32", 16384, 1, False, 0),
+                                     ("q1_x_16k_bf16", 16384, 1, True, 1), ("q128_x_4k_bf16", 4096, 128, True, 1),
+                                     ("q128_x_4k_f32", 4096, 128, False, 1)):
         nm = big[:N]
+        model.set_option("scan16", scan16)         # fp32 banks >= 4096 rows, <= 8 queries: scan of the centred bf16 copy + exact re-rank
         bank = ContextBank(model, nm, nm.view(N, 90, 256), bf16=bf16)
         q = torch.randn((Q, D), device=dev, generator=g)
         for _ in range(3):
@@ -270,8 +272,18 @@ def match_records(model, dev):
         elt = 2 if bf16 else 4
         by = (N * elt + Q * 4) * D + 4 * Q
         fl = 2.0 * Q * N * D
-        out[name] = {"us": us, "algorithmic_bytes": by, "GB/s": by / us / 1e3, "frac_of_hbm_peak": by / us / 1e3 / PEAK_HBM_GBS,
-                     "TFLOP/s": fl / us / 1e6, "kernels": {k: v["ms"] / reps * 1e3 for k, v in prof["kernels"].items()}}
+        rec = {"us": us, "algorithmic_bytes": by, "GB/s": by / us / 1e3, "frac_of_hbm_peak": by / us / 1e3 / PEAK_HBM_GBS,
+               "TFLOP/s": fl / us / 1e6, "kernels": {k: v["ms"] / reps * 1e3 for k, v in prof["kernels"].items()}}
+        if not bf16 and Q <= 8 and scan16 and N >= 4096:
+            # the fp32 search answered from the bf16 copy: the roofline is priced on the bytes the kernels move (2 B per bank value,
+            # the queries twice, 16 B of key per row written and read), not on the fp32 bank's size
+            moved = (N * 2 + Q * 8) * D + 16 * Q * N
+            rec.update({"bytes_moved": moved, "GB/s": moved / us / 1e3, "frac_of_hbm_peak": moved / us / 1e3 / PEAK_HBM_GBS,
+                        "fp32_bank_bytes_per_s_equivalent_GB/s": by / us / 1e3,
+                        "note": "exact fp32 search through the bank's centred bf16 copy + exact re-rank (mocha_match_refine); "
+                                "q1_x_16k_f32_scan32 is the scan of the fp32 rows themselves"})
+        out[name] = rec
+    model.set_option("scan16", 1)
     del big
     return out
 
@@ -286,7 +298,8 @@ def stream_record(model, dev, V):
     m_, s_ = synthetic.cnt_norm(7)
     src = torch.from_numpy(synthetic.pose_windows(5, 285, V)).to(dev)
     out = {}
-    for bf16 in (False, True):
+    for bf16, scan16 in ((False, 1), (False, 0), (True, 1)):
+        model.set_option("scan16", scan16)
         bank = ContextBank(model, nm, nm.view(-1, 90, 256), bf16=bf16)
         sc = StreamingCharacterizer(bank, m_, s_, use_graph=True)
         for i in range(5):
@@ -312,7 +325,8 @@ def stream_record(model, dev, V):
             torch.cuda.synchronize()
             rec[f"pipelined_lanes{lanes}_windows_per_s"] = 285 / (time.perf_counter() - t0)
         model.set_option("lanes", 1)
-        out["bf16_bank" if bf16 else "f32_bank"] = rec
+        out["bf16_bank" if bf16 else ("f32_bank" if scan16 else "f32_bank_scan32")] = rec
+    model.set_option("scan16", 1)
     return out
 
 

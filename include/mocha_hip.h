@@ -119,7 +119,11 @@ int mocha_forward_features(mocha_ctx* ctx, const float* src_X, const float* cha_
  * (half the HBM bytes per bank scan; BASELINE configs[2]); indices then agree with the fp32 search
  * except where the two nearest distances differ by less than the bf16 rounding of the bank.
  * fp32 banks of up to 4096 rows additionally keep the packed three-plane image of the centred bank (6 bytes per value, made by
- * mocha_bank_set) that many-query matching multiplies on the bf16 pipe when "gemm_bf16x3" is on - exact planes, the same indices. */
+ * mocha_bank_set) that many-query matching multiplies on the bf16 pipe when "gemm_bf16x3" is on - exact planes, the same indices.
+ * fp32 banks of at least 4096 rows additionally keep a centred bf16 copy (2 bytes per value) and one residual norm per row
+ * (option "scan16", default 1): matching of up to 8 queries scans the copy - the scan is HBM-bound, half the bytes - and
+ * re-evaluates on the fp32 rows, exactly, every row the copy's rounding cannot exclude (triangle inequality on the measured
+ * residuals): the indices and distances of the fp32 search, not of a bf16 bank. */
 #define MOCHA_BANK_BF16 2
 int mocha_bank_set(mocha_ctx* ctx, const float* cnt_nm, const float* encoded, int64_t N, int flags, void* stream);
 /* tree.query(q, k=1), test_fullframework.py:296,443: exact Euclidean 1-NN of each z-scored

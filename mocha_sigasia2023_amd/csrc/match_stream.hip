@@ -278,6 +278,195 @@ hipError_t launch_match_topk(const void* bank, int bank_bf16, const float* query
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 bank at HALF the scan bytes, same result (round 3).  The scan is HBM-bound, so an fp32 bank of N rows costs N * 92 KB
+// per pass.  mocha_bank_set keeps, beside the fp32 rows, their centred bf16 copy b16_n = bf16(b_n - c) and per row
+//     rho_n >= || (b_n - c) - b16_n ||                  (mocha_rowresid: the rounding residual's norm, plus 1e-6 ||b_n - c||)
+// The few-query matcher then (1) scans the bf16 copy for EVERY row's coarse distance d16_n = ||(q - c) - b16_n|| (the kernel above
+// in all_keys mode: half the bytes), and (2) mocha_match_refine re-evaluates exactly - direct sum (q - b_n)^2 over the fp32 row -
+// every row the rounding cannot exclude.  By the triangle inequality | ||q - b_n|| - d16_n | <= rho_n (+ the fp32 accumulation of the
+// scan, priced at 2e-5 d16_n), so the true nearest row n* satisfies
+//     d16_n* - rho_n* <= ||q - b_n*|| <= ||q - b_m|| <= d16_m + rho_m      for the coarse minimum m,
+// and every row with  d16_n - rho'_n <= d16_m + rho'_m  (rho'_n = rho_n + 2e-5 d16_n) is a candidate.  The smallest exact distance wins,
+// ties to the lowest row: the result of the exact fp32 search, indices and distance.  On N(0,1) banks 2-4 rows qualify; a bank of
+// identical rows makes every row a candidate (index windows of RF_CAP rows, all evaluated).
+// One 1024-thread workgroup per query; a row's terms are summed by a number of waves fixed per query, so identical rows get
+// identical distances whatever else is in the list.
+// ---------------------------------------------------------------------------------------------------------------------
+static constexpr int RF_T = 1024, RF_W = RF_T / 64, RF_CAP = 4096;
+
+__global__ __launch_bounds__(256) void mocha_rowresid(const float* __restrict__ x, const float* __restrict__ centre,
+                                                      const unsigned short* __restrict__ x16, float* __restrict__ rho, int cols) {
+    __shared__ float red[2][4];
+    const size_t row = blockIdx.x;
+    float a = 0.f, nn = 0.f;
+    for (int i = threadIdx.x; i < cols; i += 256) {
+        const float t = x[row * cols + i] - centre[i];
+        const float d = t - __uint_as_float((unsigned)x16[row * cols + i] << 16);
+        a = fmaf(d, d, a); nn = fmaf(t, t, nn);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); nn += __shfl_xor(nn, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = nn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float r2 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), n2 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        rho[row] = sqrtf(r2) * 1.000001f + 1e-6f * sqrtf(n2);
+    }
+}
+
+hipError_t launch_rowresid(const float* x, const float* centre, const void* x16, float* rho, int64_t rows, int cols, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mocha_rowresid, dim3((unsigned)rows), dim3(256), 0, s, x, centre, (const unsigned short*)x16, rho, cols);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ float key_value(unsigned long long k) {
+    unsigned u = (unsigned)(k >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long long* __restrict__ keys /*[Q][N]: coarse d16^2 keys*/,
+                                                           const float* __restrict__ rho, const float* __restrict__ bank /*fp32 rows*/,
+                                                           const float* __restrict__ query /*fp32, uncentred*/, long long N, int D,
+                                                           int32_t* __restrict__ idx, float* __restrict__ dist) {
+    extern __shared__ __attribute__((aligned(16))) float rf_q[];       // [D]
+    __shared__ unsigned long long rk[RF_W];
+    __shared__ unsigned long long r_key;
+    __shared__ int cand[RF_CAP];
+    __shared__ int ncand, ntotal;
+    __shared__ float dsum[RF_W];
+    __shared__ unsigned long long best;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { ncand = 0; ntotal = 0; best = ~0ull; }
+    // the query row goes global -> LDS while the keys are read (LDS-DMA, 1 KB per wave instruction)
+    const size_t qo = (size_t)q * D;
+    for (int pi = wave; pi * 256 < D; pi += RF_W)
+        __builtin_amdgcn_global_load_lds(query + qo + pi * 256 + lane * 4, (__attribute__((address_space(3))) void*)(rf_q + pi * 256), 16, 0, 0);
+    // ---- 1. the coarse minimum
+    const unsigned long long* kq = keys + (size_t)q * N;
+    unsigned long long key = ~0ull;
+    for (long long n = tid; n < N; n += RF_T) { const unsigned long long k = kq[n]; key = k < key ? k : key; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long k2 = __shfl_xor(key, o); key = k2 < key ? k2 : key; }
+    if (lane == 0) rk[wave] = key;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's pieces of the query row have landed ...
+    __syncthreads();                                                  // ... and everyone else's
+    if (tid == 0) {
+        unsigned long long k = rk[0];
+        for (int w = 1; w < RF_W; ++w) k = rk[w] < k ? rk[w] : k;
+        r_key = k;
+    }
+    __syncthreads();
+    const unsigned nmin = (unsigned)(r_key & 0xffffffffull);
+    const float d16min = sqrtf(fmaxf(key_value(r_key), 0.f));
+    const float hi = d16min + rho[nmin] + 2e-5f * d16min;              // upper bound of the coarse minimum's exact distance
+    auto qualifies = [&](long long n) -> bool {
+        if ((unsigned)n == nmin) return true;
+        const float d = sqrtf(fmaxf(key_value(kq[n]), 0.f));
+        return d - rho[n] - 2e-5f * d <= hi;                           // NaN distances never qualify
+    };
+    // ---- 2. how many candidates in all: fixes the number of waves that share a row (one summation order per query)
+    int mine = 0;
+    for (long long n = tid; n < N; n += RF_T) mine += qualifies(n) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0 && mine) atomicAdd(&ntotal, mine);
+    __syncthreads();
+    const int total = ntotal;
+    int wpc = RF_W;
+    while (wpc > 1 && wpc * (total < RF_W ? total : RF_W) > RF_W) wpc >>= 1;
+    const int per = RF_W / wpc;
+    // ---- 3. index windows of RF_CAP rows: list, then exact distances in passes of `per` candidates
+    for (long long w0 = 0; w0 < N; w0 += RF_CAP) {
+        __syncthreads();
+        if (tid == 0) ncand = 0;
+        __syncthreads();
+        for (long long n = w0 + tid; n < w0 + RF_CAP && n < N; n += RF_T)
+            if (qualifies(n)) cand[atomicAdd(&ncand, 1)] = (int)n;
+        __syncthreads();
+        const int nc = ncand;
+        for (int p0 = 0; p0 < nc; p0 += per) {
+            const int nb = nc - p0 < per ? nc - p0 : per;
+            const int ci = wave / wpc, sub = wave % wpc;
+            float a = 0.f;
+            int row = 0;
+            if (ci < nb) {                                             // uniform per wave
+                row = cand[p0 + ci];
+                const int lanes = wpc * 64, l = sub * 64 + lane;
+                const f32x4* b = reinterpret_cast<const f32x4*>(bank + (size_t)row * D);
+                const int np = D / 4;
+                constexpr int NB = 12;
+                for (int it0 = 0; it0 * lanes < np; it0 += NB) {
+                    f32x4 wv_[NB];
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        int pc = (it0 + u) * lanes + l;
+                        pc = pc < np ? pc : np - 1;
+                        wv_[u] = __builtin_nontemporal_load(b + pc);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NB; ++u) {
+                        const int pc = (it0 + u) * lanes + l;
+                        if (pc < np) {
+                            const f32x4 d = *reinterpret_cast<const f32x4*>(rf_q + pc * 4) - wv_[u];
+                            a = fmaf(d[0], d[0], a); a = fmaf(d[1], d[1], a); a = fmaf(d[2], d[2], a); a = fmaf(d[3], d[3], a);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+            }
+            if (lane == 0) dsum[wave] = a;
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long bk = best;
+                for (int c = 0; c < nb; ++c) {
+                    float d2 = 0.f;
+                    for (int sw = 0; sw < wpc; ++sw) d2 += dsum[c * wpc + sw];
+                    // distances are >= 0 (or NaN, which sorts last): the plain bit pattern orders them
+                    const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)cand[p0 + c];
+                    bk = (bk == ~0ull) || k < bk ? k : bk;
+                }
+                best = bk;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        idx[q] = (int)(best & 0xffffffffull);
+        if (dist) dist[q] = sqrtf(__uint_as_float((unsigned)(best >> 32)));
+    }
+}
+
+hipError_t match_refine_init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_refine), hipFuncAttributeMaxDynamicSharedMemorySize, 23040 * 4);
+}
+
+// few queries against an fp32 bank through its centred bf16 copy: `qc` = the queries minus the centroid (scan operand), `query` the
+// queries themselves (exact re-rank); keys: 8 * N words of scratch
+hipError_t launch_match_scan16(const void* bank16, const float* rho, const float* bank, const float* qc, const float* query, int Q, int64_t N,
+                               int D, unsigned long long* keys, int32_t* idx, float* dist, hipStream_t s) {
+    if (Q <= 0) return hipSuccess;
+    if (D % MS_CHUNK_BF16 != 0 || D % 256 || D > 23040 || N < 1 || N > 0x7ffffff0ll) return hipErrorInvalidValue;
+    const int rows_per_wg = MS_WAVES * MS_ROWS_PER_WAVE;
+    const unsigned grid = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
+    for (int q0 = 0; q0 < Q; q0 += 8) {
+        const int nq = (Q - q0) < 8 ? (Q - q0) : 8;
+        const float* qp = qc + (size_t)q0 * D;
+#define MS16_LAUNCH(QQ) hipLaunchKernelGGL((mocha_match_stream<QQ, true>), dim3(grid), dim3(256), 0, s, bank16, qp, nq, (long long)N, D, keys, 1)
+        if (nq == 1) MS16_LAUNCH(1);
+        else if (nq == 2) MS16_LAUNCH(2);
+        else if (nq <= 4) MS16_LAUNCH(4);
+        else MS16_LAUNCH(8);
+#undef MS16_LAUNCH
+        hipLaunchKernelGGL(mocha_match_refine, dim3(nq), dim3(RF_T), (size_t)D * sizeof(float), s, keys, rho, bank, query + (size_t)q0 * D,
+                           (long long)N, D, idx + q0, dist ? dist + q0 : nullptr);
+    }
+    return hipGetLastError();
+}
+
 // fp32 -> bf16 (round to nearest even) copy of the matching bank, and its squared row norms are then
 // taken from the rounded values (launch_rownorm2_bf16) so that value and norm stay consistent
 __global__ __launch_bounds__(256) void mocha_to_bf16(const float* __restrict__ x, const float* __restrict__ sub, int cols4,

@@ -166,6 +166,11 @@ struct mocha_ctx {
     unsigned short* bank_x3 = nullptr; size_t bank_x3_cap = 0; bool bank_x3_valid = false;
     unsigned long long* best_ws[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t best_ws_n[MAX_SETS] = {0, 0, 0};
     unsigned long long* topk_keys = nullptr; size_t topk_keys_n = 0;       // every row's key of up to 8 queries (mocha_match_topk)
+    // fp32 banks of at least SCAN16_MIN rows also keep their centred bf16 copy and the rounding residual's norm per row: the
+    // few-query matcher scans the copy (half the bytes) and re-ranks exactly what the rounding cannot exclude (match_stream.hip)
+    bool scan16 = true;                // mocha_set_option("scan16", 0) scans the fp32 rows themselves
+    void* bank16f = nullptr; size_t bank16f_cap = 0; float* bank_rho = nullptr; size_t bank_rho_cap = 0; bool bank16f_valid = false;
+    unsigned long long* scan_keys[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t scan_keys_n[MAX_SETS] = {0, 0, 0};
 
     // captured per-window step (mocha_step_graph): one executable graph, re-captured when its key changes
     struct StepGraph {
@@ -680,6 +685,7 @@ int grow(mocha_ctx* c, DevBuf& b, size_t need) {
     return 0;
 }
 
+static constexpr int64_t SCAN16_MIN = 4096;        // rows from which an fp32 bank is scanned through its bf16 copy (few queries)
 static constexpr int64_t X3_BANK_MAX = 4096;       // rows: the packed image of a 4096-row bank (BASELINE configs[2]) is 566 MB
 
 // split of the many-query GEMM's K loop over gridDim.z so that a launch has about three tiles per CU
@@ -716,6 +722,15 @@ int ensure_match_scratch(mocha_ctx* c, int set, int Q, int64_t N, bool every_q_u
         for (int q = every_q_up_to ? 9 : Q; q <= Q; ++q) need = std::max(need, (size_t)match_ksplit(q, N) * q * (size_t)N);
         if ((rc = grow(c, c->match_S[set], need))) return rc;
     }
+    if (c->scan16 && !c->bank_is_bf16 && N >= SCAN16_MIN && c->scan_keys_n[set] < (size_t)8 * N) {      // every row's coarse key, 8 queries
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->scan_keys[set]) (void)hipFree(c->scan_keys[set]);
+        c->scan_keys[set] = nullptr; c->scan_keys_n[set] = 0;
+        void* kp = nullptr;
+        HIPCHK(c, hipMalloc(&kp, sizeof(unsigned long long) * 8 * (size_t)N));
+        c->scan_keys[set] = (unsigned long long*)kp; c->scan_keys_n[set] = (size_t)8 * N;
+        c->generation++;
+    }
     return 0;
 }
 
@@ -728,7 +743,8 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     if ((rc = ensure_match_scratch(c, set, Q, N, false))) return rc;
     // centred queries: the bf16 bank holds bf16(b - c) and the GEMMs work on centred operands.  The many-query bf16 pass takes
     // them as bf16 (match_qc holds Q x D bf16 then), everything else as fp32.
-    const bool need_qc = c->bank_is_bf16 || Q > 8;
+    const bool via16 = Q <= 8 && !c->bank_is_bf16 && c->bank16f_valid && c->scan16 && c->scan_keys_n[set] >= (size_t)8 * N;
+    const bool need_qc = c->bank_is_bf16 || Q > 8 || via16;
     if (need_qc) {
         if (c->bank_is_bf16 && Q > 8)
             LAUNCH(c, s, "mocha_center_bf16", "match.center", 0.0, 6.0 * Q * D, launch_center_bf16(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
@@ -736,6 +752,14 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
             LAUNCH(c, s, "mocha_sub_rows", "match.center", 0.0, 8.0 * Q * D, launch_sub_rows(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
     }
     const float* qc = need_qc ? c->match_qc[set].p : nullptr;
+    if (via16) {
+        // fp32 bank through its centred bf16 copy: every row's coarse distance from half the bytes, then the exact fp32 distances of
+        // the rows the rounding bound cannot exclude - the result of the fp32 search
+        LAUNCH(c, s, "mocha_match_stream<bf16>+refine", "match.stream16", 3.0 * Q * N * D,
+               ((Q + 7) / 8) * (double)N * D * 2.0 + 4.0 * Q * D + 16.0 * Q * N,
+               launch_match_scan16(c->bank16f, c->bank_rho, c->bank_cnt, qc, qnm, Q, N, D, c->scan_keys[set], idx, dist, s));
+        return 0;
+    }
     if (Q <= 8) {
         const void* bank = c->bank_is_bf16 ? (const void*)c->bank_bf16 : (const void*)c->bank_cnt;
         const double passes = (Q + 7) / 8;
@@ -829,6 +853,7 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     if (e == hipSuccess) e = gemm_init();
     if (e == hipSuccess) e = gemm_x3_init();
     if (e == hipSuccess) e = match_mfma_init();
+    if (e == hipSuccess) e = match_refine_init();
     if (e == hipSuccess) e = featurize_init();
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
@@ -846,6 +871,8 @@ void mocha_destroy(mocha_ctx* c) {
     if (c->bank_bf16) (void)hipFree(c->bank_bf16);
     if (c->bank_x3) (void)hipFree(c->bank_x3);
     if (c->pair_x3) (void)hipFree(c->pair_x3);
+    if (c->bank16f) (void)hipFree(c->bank16f);
+    for (auto* k : c->scan_keys) if (k) (void)hipFree(k);
     if (c->bcast_hdr) (void)hipFree(c->bcast_hdr);
     if (c->topk_keys) (void)hipFree(c->topk_keys);
     if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -1167,11 +1194,11 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
         c->bank_norm_cap = (size_t)N;
     }
     c->bank_N = N;
+    c->bank_is_bf16 = (flags & MOCHA_BANK_BF16) != 0;
     if (current) c->generation++;                         // a captured step has the previous bank's pointers and row count baked in
     // match scratch for every query count the workspace admits: a later match never allocates (capture-safe)
     for (int set = 0; set < mocha_ctx::MAX_SETS; ++set)
         if ((set == 0 || !c->wss[set].empty()) && (rc = ensure_match_scratch(c, set, set_windows(c, set), N, true))) return rc;
-    c->bank_is_bf16 = (flags & MOCHA_BANK_BF16) != 0;
     // centroid of the bank: the many-query GEMM and the bf16 copy work on b - centroid (see do_match)
     if (!c->bank_center && (rc = dev_alloc(c, &c->bank_center, D))) return rc;
     if (!c->center_scratch && (rc = dev_alloc(c, &c->center_scratch, 2 * column_mean_scratch_doubles((int)D)))) return rc;
@@ -1188,6 +1215,24 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
         LAUNCH(c, s, "mocha_rownorm2_bf16", "bank.norms", 2.0 * N * D, 2.0 * N * D, launch_rownorm2_bf16(c->bank_bf16, c->bank_norm, N, (int)D, s));
     } else {
         LAUNCH(c, s, "mocha_rownorm2", "bank.norms", 2.0 * N * D, 4.0 * N * D, launch_rownorm2(c->bank_cnt, c->bank_center, c->bank_norm, N, (int)D, s));
+    }
+    // few-query matching against a large fp32 bank scans its centred bf16 copy (half the bytes) and re-ranks exactly
+    if (current) c->bank16f_valid = false;
+    if (current && !c->bank_is_bf16 && c->scan16 && N >= SCAN16_MIN) {
+        if (c->bank16f_cap < (size_t)N) {
+            if (c->bank16f) (void)hipFree(c->bank16f);
+            c->bank16f = nullptr; c->bank16f_cap = 0;
+            HIPCHK(c, hipMalloc(&c->bank16f, (size_t)N * D * 2));
+            c->bank16f_cap = (size_t)N;
+        }
+        if (c->bank_rho_cap < (size_t)N) {
+            if (c->bank_rho) { dev_free(c, c->bank_rho); c->bank_rho = nullptr; }
+            if ((rc = dev_alloc(c, &c->bank_rho, (size_t)N))) return rc;
+            c->bank_rho_cap = (size_t)N;
+        }
+        LAUNCH(c, s, "mocha_to_bf16", "bank.to_bf16", 0.0, 6.0 * N * D, launch_to_bf16(c->bank_cnt, c->bank_center, (int)D, c->bank16f, (int64_t)N * D, s));
+        LAUNCH(c, s, "mocha_rowresid", "bank.resid", 3.0 * N * D, 6.0 * N * D, launch_rowresid(c->bank_cnt, c->bank_center, c->bank16f, c->bank_rho, N, (int)D, s));
+        c->bank16f_valid = true;
     }
     // many-query matching against a small fp32 bank runs on the plane engine: centred bank as its packed image (6 B per value)
     c->bank_x3_valid = false;
@@ -1330,9 +1375,10 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     // (everything bank_set_impl derives from a bank has a pair_* twin: norms, centroid, packed plane image - the user's
     // current bank and what was derived from it are exactly as before when the call returns)
     struct Saved { const float *cnt, *enc; int64_t N; bool bf16; float* norm; size_t norm_cap; float* center;
-                   unsigned short* x3; size_t x3_cap; bool x3_valid; } sv{
+                   unsigned short* x3; size_t x3_cap; bool x3_valid; bool v16; } sv{
         c->bank_cnt, c->bank_enc, c->bank_N, c->bank_is_bf16, c->bank_norm, c->bank_norm_cap, c->bank_center,
-        c->bank_x3, c->bank_x3_cap, c->bank_x3_valid};
+        c->bank_x3, c->bank_x3_cap, c->bank_x3_valid, c->bank16f_valid};
+    c->bank16f_valid = false;                             // the bf16 copy belongs to the user's bank, not to the transient one
     c->bank_norm = c->pair_norm; c->bank_norm_cap = c->pair_norm_cap; c->bank_center = c->pair_center;
     c->bank_x3 = c->pair_x3; c->bank_x3_cap = c->pair_x3_cap; c->bank_x3_valid = false;
     rc = bank_set_impl(c, WS(c, "qnm"), WS(c, "enc_s"), B_cha, MOCHA_BANK_BORROW, stream, false);
@@ -1344,7 +1390,7 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     }();
     c->pair_norm = c->bank_norm; c->pair_norm_cap = c->bank_norm_cap; c->pair_center = c->bank_center;
     c->pair_x3 = c->bank_x3; c->pair_x3_cap = c->bank_x3_cap;
-    c->bank_x3 = sv.x3; c->bank_x3_cap = sv.x3_cap; c->bank_x3_valid = sv.x3_valid;
+    c->bank_x3 = sv.x3; c->bank_x3_cap = sv.x3_cap; c->bank_x3_valid = sv.x3_valid; c->bank16f_valid = sv.v16;
     c->bank_cnt = sv.cnt; c->bank_enc = sv.enc; c->bank_N = sv.N; c->bank_is_bf16 = sv.bf16; c->bank_norm = sv.norm; c->bank_norm_cap = sv.norm_cap;
     c->bank_center = sv.center;
     if (rc) return rc;
@@ -1930,6 +1976,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "dual_min") { c->dual_min = value < 2 ? 2 : value; return 0; }
     if (n == "fold_decoder") { c->fold_decoder = value != 0; return 0; }
     if (n == "fold_joint") { c->fold_joint = value != 0; return 0; }
+    if (n == "scan16") { c->scan16 = value != 0; return 0; }             // takes effect at the next mocha_bank_set
     if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; return 0; }
     if (n == "attention_bf16x3") { c->attn_x3 = value != 0; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);
