@@ -87,11 +87,17 @@ hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, f
                              const float* ymean, const float* ystd, hipStream_t s);
 // per (b, channel) instance norm over n tokens (net/transformer.py:13-20).
 //   out = (x-mean)/(std+eps); mean_out (B,256) optional; zn = (out - gm)/gs optional
+// optional extras of the instance norm: zc = zn - centre (the matcher's centred queries, bit-identical to mocha_sub_rows on zn);
+// rows gathered from a table (x row of window b = table[clamp(row_idx[b])], the decoder's cha_encoded[frame_index]) and copied out
+struct InormExtra {
+    const float* centre = nullptr; float* zc = nullptr;
+    const float* table = nullptr; const int32_t* row_idx = nullptr; long long table_rows = 0; float* copy_out = nullptr;
+};
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
-                           int B, int n, hipStream_t s);
+                           int B, int n, hipStream_t s, const InormExtra* ex = nullptr);
 // AdaIN + the attention's mapping norm (net/transformer.py:108-113, 49-56):
 //   xad = (1+gamma)*IN(x)+beta ; qin = IN(xad) ; gb (B,512) = [gamma | beta]
-hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin, int B, int n, hipStream_t s);
+hipError_t launch_adain(const float* x, const float* gb, int gb_stride /*floats between windows*/, float* xad, float* qin, int B, int n, hipStream_t s);
 // u rows (b,t',p) x (dt*256+c) = 1/4 sum of the 4 reflect-indexed frames of tap dt (conv k=5 fused with AvgPool(4))
 hipError_t launch_window_sums(const float* y, float* u, int rows, int channels /*256 or 192*/, hipStream_t s);
 // ---- CVAE sampler pieces (cvae.hip; model_CVAE.py)

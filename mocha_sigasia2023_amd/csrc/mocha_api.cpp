@@ -340,7 +340,7 @@ int ensure_ws(mocha_ctx* c, int B) {
     const std::pair<const char*, size_t> plan[] = {
         {"hbar", 360 * 192}, {"ybar", 360 * 256}, {"u", 90 * 1280}, {"x5", T}, {"xA", 90 * 512}, {"t1", T}, {"xa", T}, {"xb", T},
         {"qkv", 90 * 3072}, {"ao", 90 * 1024}, {"hff", 90 * 512}, {"kin", T}, {"xad", T}, {"qin", T},
-        {"smean", 256}, {"s1", 512}, {"gb", 512}, {"g", 90 * 192}, {"y2c", (size_t)15 * V * 64},
+        {"smean", 256}, {"s1", 512 * 8}, {"gb", 512 * 8}, {"qc", T}, {"g", 90 * 192}, {"y2c", (size_t)15 * V * 64},
         {"z", (size_t)60 * V * 64}, {"enc_s", T}, {"enc_c", T}, {"qnm", T}, {"sel", T}, {"dec", T},
     };
     // free old workspaces
@@ -552,24 +552,33 @@ int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStr
 }
 
 // decoder (model.py:62-68; net/transformer.py:90-121 with adain=True)
-int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* outp, hipStream_t s) {
-    const int M = b * 90, H = c->cfg.dec_heads, DH = c->cfg.dec_dim_head, inner = H * DH;
+// gather_table / gather_idx: cha is cha_encoded[frame_index] (test_fullframework.py:298, 465) - the first kernel reads the bank rows
+// through the indices itself and leaves the gathered copy in the "sel" workspace (cha may then be null)
+int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* outp, hipStream_t s,
+                const float* gather_table = nullptr, const int32_t* gather_idx = nullptr, long long gather_rows = 0) {
+    const int M = b * 90, H = c->cfg.dec_heads, DH = c->cfg.dec_dim_head, inner = H * DH, L = c->cfg.dec_depth;
     // IN(cha) feeds every layer's keys; mean over tokens of cha feeds every layer's style MLP
-    LAUNCH(c, s, "mocha_instnorm", "dec.in_cha", 0.0, b * 90.0 * 256 * 4 * 2, launch_instnorm(cha, WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s));
+    if (gather_table) {
+        InormExtra ex; ex.table = gather_table; ex.row_idx = gather_idx; ex.table_rows = gather_rows; ex.copy_out = WS(c, "sel");
+        LAUNCH(c, s, "mocha_instnorm", "dec.in_cha", 0.0, b * 90.0 * 256 * 4 * 3, launch_instnorm(gather_table, WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s, &ex));
+        cha = WS(c, "sel");
+    } else {
+        LAUNCH(c, s, "mocha_instnorm", "dec.in_cha", 0.0, b * 90.0 * 256 * 4 * 2, launch_instnorm(cha, WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s));
+    }
+    // style MLPs of every layer at once: Linear 256->512, LeakyReLU, Linear 512->512 per layer          net/transformer.py:102-107
+    GemmParams s1 = plain(WS(c, "smean"), 256, DW(c, "dec.Ws1_all"), WS(c, "s1"), 512 * L, b, 512 * L, 256);
+    s1.bias = DW(c, "dec.bs1_all"); s1.act = 2;
+    GEMM(c, s, "dec.style1", s1);
+    GemmParams s2 = plain(WS(c, "s1"), 512 * L, DW(c, "dec.Ws2_blk"), WS(c, "gb"), 512 * L, b, 512 * L, 512 * L);
+    s2.bias = DW(c, "dec.bs2_all");
+    GEMM(c, s, "dec.style2", s2);
     const float* x = src;
     float* qb = WS(c, "qkv");
     float* kb = qb + (size_t)M * inner;
     float* vb = kb + (size_t)M * inner;
     for (int l = 0; l < c->cfg.dec_depth; ++l) {
         const std::string p = "dec" + std::to_string(l);
-        // style MLP: Linear 256->512, LeakyReLU, Linear 512->512           net/transformer.py:102-107
-        GemmParams s1 = plain(WS(c, "smean"), 256, DW(c, p + ".Ws1"), WS(c, "s1"), 512, b, 512, 256);
-        s1.bias = DW(c, p + ".bs1"); s1.act = 2;
-        GEMM(c, s, "dec.style1", s1);
-        GemmParams s2 = plain(WS(c, "s1"), 512, DW(c, p + ".Ws2"), WS(c, "gb"), 512, b, 512, 512);
-        s2.bias = DW(c, p + ".bs2");
-        GEMM(c, s, "dec.style2", s2);
-        LAUNCH(c, s, "mocha_adain", "dec.adain", 0.0, b * 90.0 * 256 * 4 * 3, launch_adain(x, WS(c, "gb"), WS(c, "xad"), WS(c, "qin"), b, 90, s));
+        LAUNCH(c, s, "mocha_adain", "dec.adain", 0.0, b * 90.0 * 256 * 4 * 3, launch_adain(x, WS(c, "gb") + (size_t)l * 512, 512 * L, WS(c, "xad"), WS(c, "qin"), b, 90, s));
         if (c->fold_decoder && DH == 256) {
             // S_h = IN(x) (Wq_h^T Wk_h) IN(cha)^T and out = sum_h (P_h cha) (Wv_h^T Wo_h^T): with dim_head == dim the key and
             // value projections fold into the query and output weights (exact algebra, net/transformer.py:62-76), so the
@@ -734,7 +743,8 @@ int ensure_match_scratch(mocha_ctx* c, int set, int Q, int64_t N, bool every_q_u
     return 0;
 }
 
-int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, hipStream_t s) {
+// qc_pre: the queries minus the current bank's centroid, fp32, when the caller's producer already wrote them (mocha_instnorm's zc)
+int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, hipStream_t s, const float* qc_pre = nullptr) {
     if (!c->bank_cnt || c->bank_N <= 0) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
     const int D = 90 * 256;
     const int64_t N = c->bank_N;
@@ -745,13 +755,14 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     // them as bf16 (match_qc holds Q x D bf16 then), everything else as fp32.
     const bool via16 = Q <= 8 && !c->bank_is_bf16 && c->bank16f_valid && c->scan16 && c->scan_keys_n[set] >= (size_t)8 * N;
     const bool need_qc = c->bank_is_bf16 || Q > 8 || via16;
-    if (need_qc) {
+    if (qc_pre && c->bank_is_bf16 && Q > 8) qc_pre = nullptr;      // that pass takes the centred queries as bf16 (mocha_center_bf16)
+    if (need_qc && !qc_pre) {
         if (c->bank_is_bf16 && Q > 8)
             LAUNCH(c, s, "mocha_center_bf16", "match.center", 0.0, 6.0 * Q * D, launch_center_bf16(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
         else
             LAUNCH(c, s, "mocha_sub_rows", "match.center", 0.0, 8.0 * Q * D, launch_sub_rows(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
     }
-    const float* qc = need_qc ? c->match_qc[set].p : nullptr;
+    const float* qc = need_qc ? (qc_pre ? qc_pre : c->match_qc[set].p) : nullptr;
     if (via16) {
         // fp32 bank through its centred bf16 copy: every row's coarse distance from half the bytes, then the exact fp32 distances of
         // the rows the rounding bound cannot exclude - the result of the fp32 search
@@ -1008,8 +1019,6 @@ int mocha_finalize_weights(mocha_ctx* c) {
     }
     for (int l = 0; l < c->cfg.dec_depth; ++l) {
         const std::string s = "decoder.layers." + std::to_string(l), d = "dec" + std::to_string(l);
-        up(d + ".Ws1", W(c, s + ".0.style.2.weight")); up(d + ".bs1", W(c, s + ".0.style.2.bias"));
-        up(d + ".Ws2", W(c, s + ".0.style.4.weight")); up(d + ".bs2", W(c, s + ".0.style.4.bias"));
         up(d + ".Wq", W(c, s + ".1.to_q.1.weight")); up(d + ".Wk", W(c, s + ".1.to_k.1.weight")); up(d + ".Wv", W(c, s + ".1.to_v.weight"));
         up(d + ".Wo", W(c, s + ".1.to_out.0.weight")); up(d + ".bo", W(c, s + ".1.to_out.0.bias"));
         up(d + ".W1", W(c, s + ".2.net.0.weight")); up(d + ".b1", W(c, s + ".2.net.0.bias"));
@@ -1040,6 +1049,24 @@ int mocha_finalize_weights(mocha_ctx* c) {
                 }
             up(d + ".Wqk", f32(qk)); up(d + ".Wvo", f32(vo));
         }
+    }
+    {
+        // the style MLPs of ALL decoder layers read the same input (the token mean of cha): one GEMM for every layer's first linear
+        // (weights stacked), one for the second (block-diagonal: layer l's 512 outputs see only layer l's hidden 512) - two launches
+        // instead of two per layer
+        const int L = c->cfg.dec_depth;
+        std::vector<float> w1((size_t)L * 512 * 256), b1v((size_t)L * 512), w2((size_t)L * 512 * L * 512, 0.f), b2v((size_t)L * 512);
+        for (int l = 0; l < L; ++l) {
+            const std::string sl = "decoder.layers." + std::to_string(l);
+            const auto& a1 = W(c, sl + ".0.style.2.weight"); const auto& c1 = W(c, sl + ".0.style.2.bias");
+            const auto& a2 = W(c, sl + ".0.style.4.weight"); const auto& c2 = W(c, sl + ".0.style.4.bias");
+            std::copy(a1.begin(), a1.end(), w1.begin() + (size_t)l * 512 * 256);
+            std::copy(c1.begin(), c1.end(), b1v.begin() + (size_t)l * 512);
+            std::copy(c2.begin(), c2.end(), b2v.begin() + (size_t)l * 512);
+            for (int o = 0; o < 512; ++o)
+                std::copy(a2.begin() + (size_t)o * 512, a2.begin() + (size_t)(o + 1) * 512, w2.begin() + ((size_t)l * 512 + o) * L * 512 + (size_t)l * 512);
+        }
+        up("dec.Ws1_all", w1); up("dec.bs1_all", b1v); up("dec.Ws2_blk", w2); up("dec.bs2_all", b2v);
     }
     // ---- to_mot joint block + head
     up("mot.Wg2", W(c, "to_mot.4.blk.gcn.conv.weight")); up("mot.bg2", W(c, "to_mot.4.blk.gcn.conv.bias"));
@@ -1326,10 +1353,12 @@ static int characterize_impl(mocha_ctx* c, const float* src_X, int B, const floa
         int32_t* ix = idx ? idx + b0 : c->idx_ws[c->cur];
         if ((r = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s, raw))) return r;
         if ((r = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return r;
-        LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * 2, launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s));
-        if ((r = do_match(c, WS(c, "qnm"), b, ix, nullptr, s))) return r;
-        LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, b * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), b, 90 * 256, c->bank_N, s));
-        if ((r = run_decoder(c, WS(c, "enc_s"), WS(c, "sel"), b, WS(c, "dec"), s))) return r;
+        // cnt, its z-score and - the bank's centroid is known - the matcher's centred queries in one pass
+        InormExtra ex; ex.centre = c->bank_center; ex.zc = WS(c, "qc");
+        LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * 3, launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s, &ex));
+        if ((r = do_match(c, WS(c, "qnm"), b, ix, nullptr, s, WS(c, "qc")))) return r;
+        // decoder on cha_encoded[frame_index]: its first kernel gathers the rows itself
+        if ((r = run_decoder(c, WS(c, "enc_s"), nullptr, b, WS(c, "dec"), s, c->bank_enc, ix, c->bank_N))) return r;
         return run_to_mot(c, WS(c, "dec"), b, Y + b0 * ys, s, raw);
     });
 }
@@ -1384,17 +1413,15 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     rc = bank_set_impl(c, WS(c, "qnm"), WS(c, "enc_s"), B_cha, MOCHA_BANK_BORROW, stream, false);
     int32_t* ix = idx ? idx : c->idx_ws[0];
     if (!rc) rc = do_match(c, WS(c, "qnm") + (size_t)B_cha * T, B_src, ix, nullptr, s);
-    if (!rc) rc = [&]() -> int {
-        LAUNCH(c, s, "mocha_gather_rows", "bank.gather", 0.0, B_src * 90.0 * 256 * 8, launch_gather_rows(c->bank_enc, ix, WS(c, "sel"), B_src, 90 * 256, c->bank_N, s));
-        return 0;
-    }();
     c->pair_norm = c->bank_norm; c->pair_norm_cap = c->bank_norm_cap; c->pair_center = c->bank_center;
     c->pair_x3 = c->bank_x3; c->pair_x3_cap = c->bank_x3_cap;
     c->bank_x3 = sv.x3; c->bank_x3_cap = sv.x3_cap; c->bank_x3_valid = sv.x3_valid; c->bank16f_valid = sv.v16;
     c->bank_cnt = sv.cnt; c->bank_enc = sv.enc; c->bank_N = sv.N; c->bank_is_bf16 = sv.bf16; c->bank_norm = sv.norm; c->bank_norm_cap = sv.norm_cap;
     c->bank_center = sv.center;
     if (rc) return rc;
-    if ((rc = run_decoder(c, WS(c, "enc_s") + (size_t)B_cha * T, WS(c, "sel"), B_src, WS(c, "dec"), s))) return rc;
+    // decoder on the matched character rows: the transient bank's encoded rows are rows [0, B_cha) of the workspace; the first kernel
+    // of the decoder gathers them through the indices
+    if ((rc = run_decoder(c, WS(c, "enc_s") + (size_t)B_cha * T, nullptr, B_src, WS(c, "dec"), s, WS(c, "enc_s"), ix, B_cha))) return rc;
     return run_to_mot(c, WS(c, "dec"), B_src, Y, s, raw);
 }
 

@@ -427,16 +427,28 @@ __device__ __forceinline__ void inorm_stats(const f32x4* xv, int cnt, int n, f32
 template <int QW>
 __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __restrict__ x, float* __restrict__ out,
                                                              float* __restrict__ mean_out, const float* __restrict__ gm,
-                                                             const float* __restrict__ gs, float* __restrict__ zn, int n) {
+                                                             const float* __restrict__ gs, float* __restrict__ zn, int n, InormExtra ex) {
     __shared__ f32x4 red[QW * IN_NG];
     const int b = blockIdx.x, ql = threadIdx.x % QW, g = threadIdx.x / QW;
     const int q = blockIdx.y * QW + ql;                     // channel quad 0..63
     const int cnt = (n - g + IN_NG - 1) / IN_NG;           // tokens g, g + NG, ...
-    const f32x4* xb = reinterpret_cast<const f32x4*>(x + (size_t)b * n * 256) + q;
+    const float* xrow = x + (size_t)b * n * 256;
+    if (ex.row_idx) {                                       // gathered input: cha_encoded[frame_index] (test_fullframework.py:298, 465), index clamped
+        long long r = ex.row_idx[b];
+        r = r < 0 ? 0 : (r >= ex.table_rows ? ex.table_rows - 1 : r);
+        xrow = ex.table + (size_t)r * n * 256;
+    }
+    const f32x4* xb = reinterpret_cast<const f32x4*>(xrow) + q;
     f32x4 xv[IN_MAXT];
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) xv[i] = xb[(size_t)(g + IN_NG * i) * 64];
+    if (ex.copy_out) {
+        f32x4* cb = reinterpret_cast<f32x4*>(ex.copy_out + (size_t)b * n * 256) + q;
+#pragma unroll
+        for (int i = 0; i < IN_MAXT; ++i)
+            if (i < cnt) cb[(size_t)(g + IN_NG * i) * 64] = xv[i];
+    }
     // the z-score's operands do not depend on the statistics: the small-batch variant (latency-bound) fetches them now, under the
     // two reductions; the large-batch one (bandwidth-bound, register-lean for occupancy) where they are used
     constexpr bool EARLY = QW < 64;
@@ -462,7 +474,9 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
             if (zn) {
                 const f32x4 m = EARLY ? zm[EARLY ? i : 0] : reinterpret_cast<const f32x4*>(gm)[t * 64 + q];
                 const f32x4 sd = EARLY ? zs[EARLY ? i : 0] : reinterpret_cast<const f32x4*>(gs)[t * 64 + q];
-                (reinterpret_cast<f32x4*>(zn + (size_t)b * n * 256) + q)[(size_t)t * 64] = (v - m) / sd;
+                const f32x4 z = (v - m) / sd;
+                (reinterpret_cast<f32x4*>(zn + (size_t)b * n * 256) + q)[(size_t)t * 64] = z;
+                if (ex.zc) (reinterpret_cast<f32x4*>(ex.zc + (size_t)b * n * 256) + q)[(size_t)t * 64] = z - reinterpret_cast<const f32x4*>(ex.centre)[t * 64 + q];
             }
         }
 }
@@ -471,18 +485,20 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
 static inline bool inorm_split(int B) { return B <= 32; }
 
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
-                           int B, int n, hipStream_t s) {
+                           int B, int n, hipStream_t s, const InormExtra* exp) {
     if (B <= 0) return hipSuccess;
     if (n > IN_NG * IN_MAXT || n < 2) return hipErrorInvalidValue;
-    if (inorm_split(B)) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n);
-    else hipLaunchKernelGGL(mocha_instnorm<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n);
+    InormExtra ex = exp ? *exp : InormExtra{};
+    if ((ex.zc && (!zn || !ex.centre)) || (ex.row_idx && (!ex.table || ex.table_rows < 1))) return hipErrorInvalidValue;
+    if (inorm_split(B)) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
+    else hipLaunchKernelGGL(mocha_instnorm<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     return hipGetLastError();
 }
 
 // AdaIN followed by the attention's own mapping norm (net/transformer.py:108-113 then :49-56):
 //   xad = (1+gamma) * IN(x) + beta ;  qin = IN(xad)
 template <int QW>
-__global__ __launch_bounds__(QW * IN_NG) void mocha_adain(const float* __restrict__ x, const float* __restrict__ gb,
+__global__ __launch_bounds__(QW * IN_NG) void mocha_adain(const float* __restrict__ x, const float* __restrict__ gb, int gb_stride,
                                                           float* __restrict__ xad, float* __restrict__ qin, int n) {
     __shared__ f32x4 red[QW * IN_NG];
     const int b = blockIdx.x, ql = threadIdx.x % QW, g = threadIdx.x / QW;
@@ -493,8 +509,8 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_adain(const float* __restric
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) xv[i] = xb[(size_t)(g + IN_NG * i) * 64];
-    f32x4 gamma1 = reinterpret_cast<const f32x4*>(gb + (size_t)b * 512)[q];
-    const f32x4 beta = reinterpret_cast<const f32x4*>(gb + (size_t)b * 512 + 256)[q];
+    f32x4 gamma1 = reinterpret_cast<const f32x4*>(gb + (size_t)b * gb_stride)[q];
+    const f32x4 beta = reinterpret_cast<const f32x4*>(gb + (size_t)b * gb_stride + 256)[q];
     gamma1 += 1.f;
     f32x4 mean, den;
     inorm_stats<QW>(xv, cnt, n, red, ql, g, mean, den);
@@ -512,11 +528,11 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_adain(const float* __restric
         if (i < cnt) qb[(size_t)(g + IN_NG * i) * 64] = (xv[i] - mean) / den;
 }
 
-hipError_t launch_adain(const float* x, const float* gb, float* xad, float* qin, int B, int n, hipStream_t s) {
+hipError_t launch_adain(const float* x, const float* gb, int gb_stride, float* xad, float* qin, int B, int n, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    if (n > IN_NG * IN_MAXT || n < 2) return hipErrorInvalidValue;
-    if (inorm_split(B)) hipLaunchKernelGGL(mocha_adain<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, gb, xad, qin, n);
-    else hipLaunchKernelGGL(mocha_adain<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, gb, xad, qin, n);
+    if (n > IN_NG * IN_MAXT || n < 2 || gb_stride < 512 || (gb_stride & 3)) return hipErrorInvalidValue;
+    if (inorm_split(B)) hipLaunchKernelGGL(mocha_adain<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, gb, gb_stride, xad, qin, n);
+    else hipLaunchKernelGGL(mocha_adain<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, gb, gb_stride, xad, qin, n);
     return hipGetLastError();
 }
 
