@@ -286,7 +286,13 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * "attention_bf16x3" (default 1): the Generator's attention (net/transformer.py:65-76; 90 tokens, head dim 128 / 256) computes
  * QK^T and PV the same way - K, Q, V and the softmax probabilities as three bf16 planes each, six MFMA passes per product,
  * fp32 accumulation and an fp32 softmax (attention_x3.hip); 0 = v_mfma_f32_32x32x2_f32 (attention.hip).  The CVAE sampler's
- * attention (head dim 64) always uses attention.hip. */
+ * attention (head dim 64) always uses attention.hip.
+ * "fold_joint" (default 1): the embedding joint block's 1x1 gcn conv folded into its k = 5 temporal conv at
+ * mocha_finalize_weights (net/blocks.py:126-134 applies them back to back with nothing in between: one linear map, K = 5 x 192);
+ * 0 runs the two convolutions as two GEMMs.  Differences are fp32 rounding only.
+ * "lanes" (default 1, 1..3): workspace sets / captured graphs for mocha_step_graph_lane; changing it re-plans the workspaces.
+ * "scan16" (default 1): see MOCHA_BANK_BF16 above - fp32 banks of >= 4096 rows are scanned through a centred bf16 copy with an
+ * exact fp32 re-rank when at most 8 queries are matched; takes effect at the next mocha_bank_set; 0 scans the fp32 rows. */
 int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
 
 /* y (M,N) = x (M,K) · w (N,K)^T + bias (N, may be NULL): nn.Linear (net/transformer.py:28-32, 57-61) as a stand-alone
