@@ -452,7 +452,7 @@ bool gemm_is_skinny(const GemmParams& p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// One or two windows (M <= 192: the streamed per-window step, the single-clip CVAE branch).  The 32 x 32 variant above puts such a
+// A handful of windows (M <= 768: the streamed per-window step, the CVAE branch for up to 4-8 clips).  The 32 x 32 variant above puts such a
 // GEMM on 24 ... 144 workgroups - a tenth of the chip's SIMDs - and a wave walks its K quarter in rounds of 64 (load round trip,
 // 32 dependent 64-cycle MFMAs, repeat): 8-16 us per launch, 30 launches per window.  Here a workgroup owns a 16 x 16 tile
 // (v_mfma_f32_16x16x4_f32, 32 cycles), so the same GEMM spreads over 4x the workgroups, and a wave issues EVERY load of its K
@@ -556,9 +556,12 @@ __global__ __launch_bounds__(256) void mocha_gemm_skinny16(GemmParams p) {
     *reinterpret_cast<f32x4*>(p.C + (size_t)row * p.ldc + col) = v;
 }
 
-// the 16 x 16 variant serves one or two windows (and the style MLP's single rows); K in whole groups of 16
+// the 16 x 16 variant serves up to 8 windows (and the style MLP's single rows); K in whole groups of 16
 bool gemm_is_skinny16(const GemmParams& p) {
-    return gemm_is_skinny(p) && p.M <= 192 && p.K % 16 == 0;
+    // measured (characterize against a 585-row bank, ms per call): up to 2 windows 0.31 / 0.34 either way; 3 windows 0.445 -> 0.399,
+    // 4: 0.458 -> 0.416, 6: 0.512 -> 0.498, 8: 0.598 -> 0.591 with the 16 x 16 tiles; beyond 768 rows no gain (the weights are
+    // re-read once per 16 rows)
+    return gemm_is_skinny(p) && p.M <= 768 && p.K % 16 == 0;
 }
 
 template <int BN>
