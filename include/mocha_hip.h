@@ -176,9 +176,10 @@ int mocha_step_graph_lane(mocha_ctx* ctx, int lane, const float* X1, const float
  *                          ncclAllGather, so that every xGMI link of the root carries a share instead of one ring
  *                          neighbour carrying all of it; centroid, row norms and the optional bf16 copy (flags &
  *                          MOCHA_BANK_BF16) are recomputed locally.  `comm` = an ncclComm_t created by the same librccl,
- *                          or NULL for the context's own.  Collective.  A 16-byte header {entries, bf16?} travels first
- *                          and every rank checks it against its own N / flags (one stream synchronisation), so a root
- *                          without that bank or a flags mismatch fails on ALL ranks instead of hanging the others; the
+ *                          or NULL for the context's own.  Collective.  Every rank first contributes a 16-byte header
+ *                          {entries, bf16?} as it understands the call; the headers are all-gathered and checked by
+ *                          every rank (one stream synchronisation), so a root without that bank, a flags mismatch or a
+ *                          single rank naming another size fails on ALL ranks instead of hanging some of them; the
  *                          payload is then enqueued on `stream`.
  *   mocha_set_rccl_library: which librccl to resolve (before the first mocha_comm_* call; process-wide).  A process that
  *                          already holds an RCCL - PyTorch wheels bundle their own copy - should name that file, so that one

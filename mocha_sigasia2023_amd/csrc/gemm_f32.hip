@@ -561,7 +561,9 @@ bool gemm_is_skinny16(const GemmParams& p) {
     // measured (characterize against a 585-row bank, ms per call): up to 2 windows 0.31 / 0.34 either way; 3 windows 0.445 -> 0.399,
     // 4: 0.458 -> 0.416, 6: 0.512 -> 0.498, 8: 0.598 -> 0.591 with the 16 x 16 tiles; beyond 768 rows no gain (the weights are
     // re-read once per 16 rows)
-    return gemm_is_skinny(p) && p.M <= 768 && p.K % 16 == 0;
+    // (and only while the weight matrix is small: it is re-read once per 16 rows - the decoder's block-diagonal style GEMM, 1024 x 1024,
+    // took 44 us at 585 rows here against 2 x 15.6 us for the two per-layer launches on the 32 x 32 tiles)
+    return gemm_is_skinny(p) && p.K % 16 == 0 && (p.M <= 192 || (p.M <= 768 && (long long)p.N * p.K <= 512 * 1024));
 }
 
 template <int BN>

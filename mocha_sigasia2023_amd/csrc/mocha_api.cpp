@@ -1632,25 +1632,33 @@ int mocha_bank_broadcast(mocha_ctx* c, void* comm_, int root, int64_t N, int fla
     hipStream_t s = (hipStream_t)stream;
     const size_t D = 90 * 256;
     const bool want_bf16 = (flags & MOCHA_BANK_BF16) != 0;
-    // Header first: the root announces {entries, bf16?} of the bank it is about to send (-1 entries: it has none of the size
-    // the call names), and EVERY rank checks it against its own arguments before any payload moves - a disagreement fails
-    // loudly on all ranks instead of leaving the others waiting in a collective the root never enters.
-    if (!c->bcast_hdr) HIPCHK(c, hipMalloc((void**)&c->bcast_hdr, 2 * sizeof(long long)));
-    long long hdr[2] = {-1, 0};
-    if (rank == root) {
-        hdr[0] = (c->bank_cnt && c->bank_N == N) ? (long long)N : -1;
-        hdr[1] = c->bank_is_bf16 ? 1 : 0;
-        HIPCHK(c, hipMemcpyAsync(c->bcast_hdr, hdr, sizeof hdr, hipMemcpyHostToDevice, s));
-    }
-    if (world > 1) NCCLCHK(c, g_rccl.Broadcast(c->bcast_hdr, c->bcast_hdr, 2, ncclInt64, root, comm, s));
-    HIPCHK(c, hipMemcpyAsync(hdr, c->bcast_hdr, sizeof hdr, hipMemcpyDeviceToHost, s));
+    // Header first: EVERY rank contributes {entries, bf16?} as it understands the call - the root from the bank it is about to send
+    // (-1 entries: it has none of the size the call names), the others from their arguments - the headers are all-gathered, and
+    // every rank checks all of them before any payload moves.  All ranks see the same headers, so a disagreement fails loudly on
+    // ALL ranks instead of leaving some of them inside a collective the others never enter.
+    if (world > 4096) return fail(c, MOCHA_ERR_ARG, "bank_broadcast: %d ranks", world);
+    if (!c->bcast_hdr) HIPCHK(c, hipMalloc((void**)&c->bcast_hdr, 2 * 4096 * sizeof(long long)));
+    std::vector<long long> hdr((size_t)2 * world, 0);
+    long long mine[2] = {(long long)N, want_bf16 ? 1 : 0};
+    if (rank == root) { mine[0] = (c->bank_cnt && c->bank_N == N) ? (long long)N : -1; mine[1] = c->bank_is_bf16 ? 1 : 0; }
+    HIPCHK(c, hipMemcpyAsync(c->bcast_hdr + 2 * rank, mine, sizeof mine, hipMemcpyHostToDevice, s));
+    if (world > 1) NCCLCHK(c, g_rccl.AllGather(c->bcast_hdr + 2 * rank, c->bcast_hdr, 2, ncclInt64, comm, s));
+    HIPCHK(c, hipMemcpyAsync(hdr.data(), c->bcast_hdr, hdr.size() * sizeof(long long), hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));
-    if (hdr[0] != (long long)N)
+    if (hdr[2 * root] != (long long)N || hdr[2 * root] < 0) {
+        if (hdr[2 * root] < 0)
+            return fail(c, MOCHA_ERR_STATE, "bank_broadcast: the root (rank %d) has no current bank of the number of entries it was called with", root);
         return fail(c, MOCHA_ERR_STATE, "bank_broadcast: the root (rank %d) has no current bank of %lld entries (it announced %lld)", root,
-                    (long long)N, hdr[0]);
-    if ((hdr[1] != 0) != want_bf16)
-        return fail(c, MOCHA_ERR_ARG, "bank_broadcast: the root's bank was set %s MOCHA_BANK_BF16 but rank %d asks for the opposite: every "
-                    "rank must match against the same bank", hdr[1] ? "with" : "without", rank);
+                    (long long)N, hdr[2 * root]);
+    }
+    for (int r = 0; r < world; ++r) {
+        if (hdr[2 * r] != hdr[2 * root])
+            return fail(c, MOCHA_ERR_ARG, "bank_broadcast: rank %d asks for %lld entries, the root (rank %d) sends %lld: every rank must name the same bank",
+                        r, hdr[2 * r], root, hdr[2 * root]);
+        if (hdr[2 * r + 1] != hdr[2 * root + 1])
+            return fail(c, MOCHA_ERR_ARG, "bank_broadcast: the root's bank was set %s MOCHA_BANK_BF16 but rank %d asks for the opposite: every "
+                        "rank must match against the same bank", hdr[2 * root + 1] ? "with" : "without", r);
+    }
     if (rank != root) {
         if (c->bank_cap < (size_t)N) {
             HIPCHK(c, hipDeviceSynchronize());

@@ -105,13 +105,16 @@ def test_bank_broadcast_reaches_every_rank_bit_for_bit(standin, tmp_path, world)
 
 @pytest.mark.timeout(600)
 def test_disagreeing_ranks_fail_loudly_on_every_rank(standin, tmp_path):
-    """A bf16 / fp32 flag mismatch or a wrong entry count is caught by the header every rank checks: all ranks raise, none
-    hangs in a collective the root never entered, and the communicator still works afterwards."""
-    run_ranks(standin, 2, "mismatch", tmp_path)
-    for r in range(2):
-        flags_msg, count_msg, idx = open(tmp_path / f"mismatch_rank{r}.txt").read().split("\n")
+    """A bf16 / fp32 flag mismatch, a wrong entry count on every rank, and a wrong entry count on ONE non-root rank are caught by
+    the all-gathered headers every rank checks: all ranks raise, none hangs in a collective the others never entered, and the
+    communicator still works afterwards."""
+    run_ranks(standin, 3, "mismatch", tmp_path)
+    for r in range(3):
+        flags_msg, count_msg, lone_msg, idx = open(tmp_path / f"mismatch_rank{r}.txt").read().split("\n")
         assert "MOCHA_BANK_BF16" in flags_msg and "opposite" in flags_msg
-        assert "no current bank of 10 entries" in count_msg
+        assert "no current bank" in count_msg
+        # one rank alone disagrees: the all-gathered headers fail EVERY rank - the others name it, it sees the root's announcement
+        assert ("rank 2 asks for 10 entries" in lone_msg) if r != 2 else ("it announced 9" in lone_msg), lone_msg
         assert idx == str(list(range(9)))
 
 
