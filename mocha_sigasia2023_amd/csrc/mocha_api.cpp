@@ -569,9 +569,19 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
     GemmParams s1 = plain(WS(c, "smean"), 256, DW(c, "dec.Ws1_all"), WS(c, "s1"), 512 * L, b, 512 * L, 256);
     s1.bias = DW(c, "dec.bs1_all"); s1.act = 2;
     GEMM(c, s, "dec.style1", s1);
-    GemmParams s2 = plain(WS(c, "s1"), 512 * L, DW(c, "dec.Ws2_blk"), WS(c, "gb"), 512 * L, b, 512 * L, 512 * L);
-    s2.bias = DW(c, "dec.bs2_all");
-    GEMM(c, s, "dec.style2", s2);
+    if (b <= 192 || L == 1) {
+        // a handful of windows: launch count matters, the block-diagonal matrix's zero half does not
+        GemmParams s2 = plain(WS(c, "s1"), 512 * L, DW(c, "dec.Ws2_blk"), WS(c, "gb"), 512 * L, b, 512 * L, 512 * L);
+        s2.bias = DW(c, "dec.bs2_all");
+        GEMM(c, s, "dec.style2", s2);
+    } else {
+        for (int l = 0; l < L; ++l) {                     // large batches: layer l's 512 x 512 on its own slice of the hidden activations
+            const std::string p = "dec" + std::to_string(l);
+            GemmParams s2 = plain(WS(c, "s1") + (size_t)l * 512, 512 * L, DW(c, p + ".Ws2"), WS(c, "gb") + (size_t)l * 512, 512 * L, b, 512, 512);
+            s2.bias = DW(c, p + ".bs2");
+            GEMM(c, s, "dec.style2", s2);
+        }
+    }
     const float* x = src;
     float* qb = WS(c, "qkv");
     float* kb = qb + (size_t)M * inner;
@@ -1019,6 +1029,7 @@ int mocha_finalize_weights(mocha_ctx* c) {
     }
     for (int l = 0; l < c->cfg.dec_depth; ++l) {
         const std::string s = "decoder.layers." + std::to_string(l), d = "dec" + std::to_string(l);
+        up(d + ".Ws2", W(c, s + ".0.style.4.weight")); up(d + ".bs2", W(c, s + ".0.style.4.bias"));      // per layer, for large batches
         up(d + ".Wq", W(c, s + ".1.to_q.1.weight")); up(d + ".Wk", W(c, s + ".1.to_k.1.weight")); up(d + ".Wv", W(c, s + ".1.to_v.weight"));
         up(d + ".Wo", W(c, s + ".1.to_out.0.weight")); up(d + ".bo", W(c, s + ".1.to_out.0.bias"));
         up(d + ".W1", W(c, s + ".2.net.0.weight")); up(d + ".b1", W(c, s + ".2.net.0.bias"));
