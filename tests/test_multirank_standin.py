@@ -162,3 +162,19 @@ def test_bench_demo_two_ranks_runs_the_broadcast_and_probe(standin):
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec.get("bank_broadcast_error") is None and rec["bank_broadcast_ms"] > 0
     assert len(rec["per_rank_frames_per_s"]) == 2 and rec["value"] > 0
+
+
+@pytest.mark.timeout(1500)
+def test_bench_under_torch_distributed_run_two_ranks(standin):
+    """The driver's own launch line for N > 1 - `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` - with two ranks on GPU 0: bench.py reads RANK / LOCAL_RANK / WORLD_SIZE from the
+    launcher's environment, prints ONE line on rank 0, whole-job value = sum over the ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(REPO, "bench.py"), "--gpus", "2", "--windows", "64", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, env=_env(standin, MOCHA_BENCH_ONE_GPU="1", MOCHA_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=1200)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["bank_broadcast_error"] is None and len(rec["per_rank_frames_per_s"]) == 2
+    assert abs(rec["value"] - sum(rec["per_rank_frames_per_s"])) < 0.2 * rec["value"]
