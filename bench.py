@@ -195,6 +195,15 @@ def bank4k(a):
     if rank == 0:
         bank_nm = torch.randn((NB, 90 * 256), device=dev, generator=g)
         bank_enc = torch.randn((NB, 90, 256), device=dev, generator=g)
+        # a bank of pure noise would send every window to the same row: plant a noisy copy of every window's own z-scored features
+        # at row 4 i (set-up, untimed), so that the matches - and the gathered rows - are distinct like a real character bank's
+        with torch.no_grad():
+            full = torch.from_numpy(synthetic.pose_windows(1, W, V)).to(dev)
+            _, _, nm_all = model.encode(full, mean, std)
+            nm_all = nm_all.reshape(W, -1)
+            gap = (torch.cdist(nm_all, nm_all) + 1e30 * torch.eye(W, device=dev)).min().item()      # closest two windows
+            bank_nm[0:4 * W:4] = nm_all + (0.1 * gap / (90 * 256) ** 0.5) * torch.randn((W, 90 * 256), device=dev, generator=g)
+            del full, nm_all
     bank = ContextBank(model, bank_nm, bank_enc, bf16=True) if rank == 0 else None
     bcast_ms = None
     if torch.distributed.is_initialized():

@@ -143,6 +143,17 @@ def test_config4_streamed_clip_x_16k_bank():
     bank_nm = torch.randn((NB, D), device=dev(), generator=g)
     src = T(synthetic.pose_windows(5, W, V))
     ost = O.to_torch_state(sd)
+    # against pure noise every window would match the same row: plant noisy copies of the windows' own features at scattered rows, so
+    # that the 285 answers are 285 different rows (and near-ties exist: two copies per window, the farther one 1e-3 further away)
+    _, _, nm0 = model.encode(src, mean, std)
+    rows = torch.randperm(NB, device=dev(), generator=g)[: 2 * W]
+    nm0 = nm0.reshape(W, D)
+    gap = (torch.cdist(nm0, nm0) + 1e30 * torch.eye(W, device=dev())).min().item()         # the closest two windows of the clip
+    noise = (0.1 * gap / D ** 0.5) * torch.randn((W, D), device=dev(), generator=g)     # |noise| = a tenth of that
+    bank_nm[rows[:W]] = nm0.reshape(W, D) + noise
+    bank_nm[rows[W:]] = nm0.reshape(W, D) + noise * 1.001
+    planted = rows[:W].cpu().numpy()
+    print(f"config4: closest two windows {gap:.3f} apart, feature norm {nm0.norm(dim=1).mean().item():.1f}")
     for bf16 in (False, True):
         bank = ContextBank(model, bank_nm, bank_nm.view(NB, 90, 256), bf16=bf16)
         Yb, ib = bank.characterize(src, mean, std, return_index=True)          # batched: the many-query (GEMM) matcher
@@ -170,6 +181,7 @@ def test_config4_streamed_clip_x_16k_bank():
         else:
             ridx, _ = O.match_bruteforce(q, bank_np)
         assert np.array_equal(idx_stream, ridx)
+        assert len(set(idx_stream.tolist())) == W and (bf16 or np.array_equal(idx_stream, planted))
         sel = np.arange(0, W, 19)
         with torch.no_grad():
             eo, _ = O.encode(ost, src.cpu()[sel])
