@@ -431,7 +431,9 @@ void x3_drop_images(mocha_ctx* c) {
 
 int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
     const double flops = 2.0 * p.M * (double)p.N * p.K;
-    const double bytes = 4.0 * ((double)p.M * p.K / (p.gather ? p.ntaps : 1) * (p.R) + (double)p.N * p.K + (double)p.M * p.N * p.ksplit);
+    // algorithmic bytes: every operand once - activations, weights, the output, and the residual matrix where the epilogue adds one
+    const double bytes = 4.0 * ((double)p.M * p.K / (p.gather ? p.ntaps : 1) * (p.R) + (double)p.N * p.K + (double)p.M * p.N * p.ksplit +
+                                (p.residual ? (double)p.M * p.N : 0.0));
     if (c->gemm_x3 && gemm_x3_supports(p)) {
         const unsigned short* img = nullptr;
         int rc = x3_image(c, s, p, &img);
