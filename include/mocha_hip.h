@@ -288,6 +288,11 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * QK^T and PV the same way - K, Q, V and the softmax probabilities as three bf16 planes each, six MFMA passes per product,
  * fp32 accumulation and an fp32 softmax (attention_x3.hip); 0 = v_mfma_f32_32x32x2_f32 (attention.hip).  The CVAE sampler's
  * attention (head dim 64) always uses attention.hip.
+ * "attention_split_max" (default 192; PROCESS-wide, a diagnostic): up to this many (window, head) pairs the head-dim-256 attention
+ * (the decoder's) gives each pair twelve waves - four groups contract a quarter of the head dim each, the partial score tiles are
+ * summed through LDS in a fixed order, each group then writes a quarter of the output columns - because a one-window launch is
+ * otherwise a serial chain of twelve staging steps per wave.  Same operands and products; the scores are summed in a different
+ * association than the three-wave kernel's, so results agree to fp32 rounding.  0 = always the three-wave kernel.
  * "fold_joint" (default 1): the embedding joint block's 1x1 gcn conv folded into its k = 5 temporal conv at
  * mocha_finalize_weights (net/blocks.py:126-134 applies them back to back with nothing in between: one linear map, K = 5 x 192);
  * 0 runs the two convolutions as two GEMMs.  Differences are fp32 rounding only.

@@ -267,11 +267,241 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(PF2 ? 2 : 3
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// A handful of windows (streaming: ONE window, two or four (window, head) pairs on a 256-CU chip): the launch above is then a serial
+// chain per wave - eight K/Q chunks and four V passes at head dim 256, each a staging step, two barriers and 36 / 108 MFMAs - and
+// that chain, not the memory system, is what the caller waits for.  This variant gives a (window, head) pair TWELVE waves, four
+// groups of three: group g contracts a quarter of the head dim for all 96 x 96 scores (its own K/Q stages), the four partial score
+// tiles are summed through LDS in a fixed order by every group (so all groups hold bit-identical scores and repeat the cheap
+// softmax), and group g then produces a quarter of the output columns (one 64-dim V pass at head dim 256; half of one at 128).
+// Per wave: 2 chunks + 1 pass instead of 8 + 4.  The score sums are associated differently from the kernel above (four partial sums
+// instead of one running sum), so results agree to fp32 rounding, not bit for bit.
+template <int DH>
+__global__ __launch_bounds__(768) void mocha_attention_x3_split(AttnParams p) {
+    constexpr int NTHR = 192, NKT = 3, NG = 4;
+    constexpr int NC = DH / 32, NCG = NC / NG;           // K/Q chunks of 32 dims: in all, per group
+    constexpr int ND = DH == 256 ? 2 : 1;                // 32-dim output blocks per group in phase 3
+    extern __shared__ __attribute__((aligned(16))) unsigned short smx[];          // [NG][AX_LDS]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = wave / 3, w = wave - grp * 3;        // group, query block
+    const int gtid = tid - grp * NTHR;
+    const int l31 = lane & 31, hh = lane >> 5;
+    unsigned short* Ks = smx + grp * AX_LDS;
+    unsigned short* Qs = Ks + AX_OPER;
+    unsigned short* Vs = Ks;
+
+    const int id = blockIdx.x;
+    const int slot = id >> 3;
+    const int head = slot % p.heads;
+    const int b = (slot / p.heads) * 8 + (id & 7);
+    if (b >= p.B) return;
+    const int nq = p.nq, nk = p.nk;
+    const float* qg = p.q + (size_t)b * nq * p.ldq + head * DH;
+    const float* kg = p.k + (size_t)b * nk * p.ldk + head * (p.hsk < 0 ? DH : p.hsk);
+    const float* vg = p.v + (size_t)b * nk * p.ldv + head * (p.hsv < 0 ? DH : p.hsv);
+    const __amdgpu_buffer_rsrc_t rsq = make_rsrc(qg), rsk = make_rsrc(kg), rsv = make_rsrc(vg);
+
+    // ---------------- phase 1: this group's quarter of S^T[key][query]
+    f32x16 st[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
+    f32x4 kr[NCG][4], qr[NCG][4];
+    int st_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = gtid + NTHR * i;
+        const int row = f >> 3, c = f & 7;
+        const int rk = row < nk ? row : nk - 1, rq = row < nq ? row : nq - 1;
+        const unsigned k_off = (unsigned)(rk * p.ldk + c * 4) * 4u, q_off = (unsigned)(rq * p.ldq + c * 4) * 4u;
+        st_off[i] = (c >> 1) * AX_BLK + row * 8 + (c & 1) * 4;
+#pragma unroll
+        for (int j = 0; j < NCG; ++j) {                  // every chunk of the group is in flight from the start
+            kr[j][i] = bload(rsk, k_off, (unsigned)(grp * NCG + j) * 128u);
+            qr[j][i] = bload(rsq, q_off, (unsigned)(grp * NCG + j) * 128u);
+        }
+    }
+    // this group's V columns (phase 3): pass dp of 64 dims
+    const int dp = DH == 256 ? grp : grp >> 1;
+    const int d0 = DH == 256 ? 0 : (grp & 1);
+    f32x4 vr[8];
+    int vs_off[8];
+    auto fetch_v = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int f = gtid + NTHR * i;
+            const int row = f >> 4, c4 = (f & 15) * 4;
+            const int rv = row < nk ? row : nk - 1;
+            vs_off[i] = row * 64 + c4;
+            vr[i] = bload(rsv, (unsigned)(rv * p.ldv + c4) * 4u, (unsigned)dp * 256u);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < NCG; ++j) {
+        if (j) __syncthreads();                          // every wave is done reading the previous chunk's stage
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 pk[3], pq[3];
+            plane_split4(kr[j][i], pk);
+            plane_split4(qr[j][i], pq);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                *reinterpret_cast<u32x2*>(Ks + q * AX_PLANE + st_off[i]) = pk[q];
+                *reinterpret_cast<u32x2*>(Qs + q * AX_PLANE + st_off[i]) = pq[q];
+            }
+        }
+        if (j == NCG - 1) fetch_v();                     // the chunk registers are free: V arrives under the MFMAs, the sum and the softmax
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            s16x8 a[3][NKT], bq[3];
+            const int blk = (ks * 2 + hh) * AX_BLK;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int t = 0; t < NKT; ++t) a[q][t] = *reinterpret_cast<const s16x8*>(Ks + q * AX_PLANE + blk + (t * 32 + l31) * 8);
+                bq[q] = *reinterpret_cast<const s16x8*>(Qs + q * AX_PLANE + blk + (w * 32 + l31) * 8);
+            }
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                for (int t = 0; t < NKT; ++t)
+                    st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PLANE_PA[pr]][t], bq[PLANE_PB[pr]], st[t], 0, 0, 0);
+        }
+    }
+    // ---------------- the four partial tiles of a query block, summed in group order by every group
+    __syncthreads();
+    {
+        float* red = reinterpret_cast<float*>(Ks);       // [query block][tile quad 0..11][lane][4]
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const f32x4 v = {st[t][4 * qd], st[t][4 * qd + 1], st[t][4 * qd + 2], st[t][4 * qd + 3]};
+                *reinterpret_cast<f32x4*>(red + ((w * 12 + t * 4 + qd) * 64 + lane) * 4) = v;
+            }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smx) + ((w * 12 + t * 4 + qd) * 64 + lane) * 4);
+#pragma unroll
+            for (int g = 1; g < NG; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(smx + g * AX_LDS) + ((w * 12 + t * 4 + qd) * 64 + lane) * 4);
+                acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+            }
+            st[t][4 * qd] = acc[0]; st[t][4 * qd + 1] = acc[1]; st[t][4 * qd + 2] = acc[2]; st[t][4 * qd + 3] = acc[3];
+        }
+
+    // ---------------- phase 2: softmax over keys for this lane's query (as above)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= nk) st[t][r] = -INFINITY;
+            mx = fmaxf(mx, st[t][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float c2 = p.scale * 1.44269504088896340736f;
+    const float mb = -mx * c2;
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(st[t][r], c2, mb));
+            st[t][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+    s16x8 pp[NKT][2][3];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const f32x4 lo = {st[t][8 * j] * inv, st[t][8 * j + 1] * inv, st[t][8 * j + 2] * inv, st[t][8 * j + 3] * inv};
+            const f32x4 hi = {st[t][8 * j + 4] * inv, st[t][8 * j + 5] * inv, st[t][8 * j + 6] * inv, st[t][8 * j + 7] * inv};
+            u32x2 a[3], b2[3];
+            plane_split4(lo, a); plane_split4(hi, b2);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const u32x4 v = {a[q][0], a[q][1], b2[q][0], b2[q][1]};
+                pp[t][j][q] = __builtin_bit_cast(s16x8, v);
+            }
+        }
+
+    // ---------------- phase 3: this group's output columns
+    __syncthreads();                                     // every wave has read the partial sums: the stage becomes V's
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32x2 pv[3];
+        plane_split4(vr[i], pv);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(Vs + q * AX_VPLANE + vs_off[i]) = pv[q];
+    }
+    __syncthreads();
+    const int query = w * 32 + l31;
+    float* og = p.out + ((size_t)b * nq + query) * p.ldo + head * DH + dp * 64 + d0 * 32;
+    const int tr_base = ((4 * hh + ((lane & 15) >> 2)) * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) + 32 * d0;
+    f32x16 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                s16x8 va[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const unsigned short* src = Vs + q * AX_VPLANE + tr_base + (32 * t + 16 * j) * 64 + 32 * d;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(src + 8 * 64));
+                    va[q] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int pr = 0; pr < 6; ++pr)
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PLANE_PA[pr]], pp[t][j][PLANE_PB[pr]], o[d], 0, 0, 0);
+            }
+    if (query < nq) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v = {o[d][4 * g], o[d][4 * g + 1], o[d][4 * g + 2], o[d][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(og + d * 32 + 8 * g + 4 * hh) = v;
+            }
+    }
+}
+
+static constexpr size_t AX_SPLIT_LDS = (size_t)4 * AX_LDS * sizeof(unsigned short);     // 150 528 B
+hipError_t attention_x3_init() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_attention_x3_split<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AX_SPLIT_LDS);
+}
+int attention_x3_split_max = 192;                        // (window, head) pairs up to which the twelve-wave variant is launched (head dim 256: the
+                                                         // decoder's four heads, 48 windows; whole decoder 109 vs 116 us at one window, 236 vs 244 at 32,
+                                                         // equal at 64 windows, slower from 96 - tools/attn_split_ab.py)
+
 hipError_t launch_attention_x3(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     if (p.nq < 1 || p.nk < 1 || p.nq > 96 || p.nk > 96 || (p.dh != 128 && p.dh != 256)) return hipErrorInvalidValue;
     dim3 grid((unsigned)(((p.B + 7) / 8) * 8 * p.heads));
     const bool pf2 = (long long)p.B * p.heads <= 256;    // fewer (window, head) workgroups than CUs: latency-bound, prefetch two steps ahead
+    if (p.dh == 256 && (long long)p.B * p.heads <= attention_x3_split_max) {
+        // head dim 128 (the encoder) has one chunk per group left to split: measured equal to the two-steps-ahead variant, which it keeps
+        hipLaunchKernelGGL((mocha_attention_x3_split<256>), grid, dim3(768), AX_SPLIT_LDS, s, p);
+        return hipGetLastError();
+    }
     if (p.dh == 128) {
         if (pf2) hipLaunchKernelGGL((mocha_attention_x3<128, true>), grid, dim3(192), 0, s, p);
         else hipLaunchKernelGGL((mocha_attention_x3<128, false>), grid, dim3(192), 0, s, p);

@@ -67,6 +67,8 @@ struct AttnParams {
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 // the same on the bf16 matrix pipe with exact three-plane operands (attention_x3.hip): nq, nk <= 96, dh = 128 / 256
 hipError_t launch_attention_x3(const AttnParams& p, hipStream_t s);
+hipError_t attention_x3_init();              // one-time function attributes (dynamic LDS of the twelve-wave small-batch variant)
+extern int attention_x3_split_max;           // (window, head) pairs up to which that variant is launched (diagnostics may lower it to 0)
 
 // ---------------------------------------------------------------------------------------
 // Small bandwidth-bound kernels

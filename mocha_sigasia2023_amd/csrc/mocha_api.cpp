@@ -875,6 +875,7 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = gemm_init();
     if (e == hipSuccess) e = gemm_x3_init();
+    if (e == hipSuccess) e = attention_x3_init();
     if (e == hipSuccess) e = match_mfma_init();
     if (e == hipSuccess) e = match_refine_init();
     if (e == hipSuccess) e = featurize_init();
@@ -2025,6 +2026,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "fold_decoder") { c->fold_decoder = value != 0; return 0; }
     if (n == "fold_joint") { c->fold_joint = value != 0; return 0; }
     if (n == "scan16") { c->scan16 = value != 0; return 0; }             // takes effect at the next mocha_bank_set
+    if (n == "attention_split_max") { attention_x3_split_max = value < 0 ? 0 : value; return 0; }      // process-wide (diagnostic)
     if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; return 0; }
     if (n == "attention_bf16x3") { c->attn_x3 = value != 0; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);

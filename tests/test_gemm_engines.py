@@ -136,3 +136,30 @@ def test_attention_prefetch_variants_are_bit_identical():
     assert torch.equal(e65[:64], e64)
     d65, d64 = model.decoder(tok, cha), model.decoder(tok[:64].contiguous(), cha[:64].contiguous())
     assert torch.equal(d65[:64], d64)
+
+
+@pytest.mark.parametrize("B", [1, 3, 32])
+def test_twelve_wave_decoder_attention_against_the_three_wave_kernel(B):
+    """Up to 192 (window, head) pairs (48 windows of four heads) the head-dim-256 attention runs as mocha_attention_x3_split (four wave groups, each a quarter of
+    the head dim, partial scores summed through LDS): same products, another association of the score sums.  Against the
+    three-wave kernel on the same decoder call the outputs agree to fp32 rounding, and against the exact-f32 attention as closely
+    as that kernel does.  B = 3 leaves five of the eight padded workgroups of the XCD-aware grid without a window."""
+    sd = weights.synthetic_state_dict(31, 1.2)
+    model = Generator(device="cuda:0").load_state_dict(sd).eval()
+    tok = torch.from_numpy(synthetic.token_features(7, B)).cuda()
+    cha = torch.from_numpy(synthetic.token_features(8, B)).cuda()
+    try:
+        d_split = model.decoder(tok, cha).clone()
+        again = model.decoder(tok, cha)
+        assert torch.equal(d_split, again)                       # deterministic: the partial sums are added in group order
+        model.set_option("attention_split_max", 0)
+        d_three = model.decoder(tok, cha).clone()
+        model.set_option("attention_bf16x3", 0)
+        d_f32 = model.decoder(tok, cha).clone()
+    finally:
+        model.set_option("attention_bf16x3", 1)
+        model.set_option("attention_split_max", 192)
+    scale = max(1.0, float(d_three.abs().max()))
+    assert float((d_split - d_three).abs().max()) < 2e-6 * scale
+    assert float((d_split - d_f32).abs().max()) < 2e-5 * scale
+    assert not torch.equal(d_split, d_three) or B == 0           # it IS another kernel (a silent fallback would be bit-identical)
