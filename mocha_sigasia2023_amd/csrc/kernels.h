@@ -171,9 +171,11 @@ hipError_t launch_gather_blend(const float* src, const int32_t* idx, const float
 hipError_t launch_to_bf16(const float* x, const float* sub /*per-column, or null*/, int cols, void* y, int64_t n, hipStream_t s);
 // fp32 bank scanned through its centred bf16 copy, exact re-rank of what the rounding cannot exclude (match_stream.hip)
 hipError_t match_refine_init();
+size_t match_scan16_scratch_words(int64_t N);        // launch_match_scan16's scratch buffer, in 8-byte words; the first ..._head_words() must be zero at first use
+size_t match_scan16_scratch_head_words();
 hipError_t launch_rowresid(const float* x, const float* centre, const void* x16, float* rho, int64_t rows, int cols, hipStream_t s);
 hipError_t launch_match_scan16(const void* bank16, const float* rho, const float* bank, const float* qc, const float* query, int Q, int64_t N,
-                               int D, unsigned long long* keys, int32_t* idx, float* dist, hipStream_t s);
+                               int D, unsigned long long* scratch, int32_t* idx, float* dist, hipStream_t s);
 hipError_t launch_rownorm2_bf16(const void* x, float* out, int64_t rows, int cols, hipStream_t s);
 // out[q] = src[idx[q]] rows of `cols` floats
 hipError_t launch_gather_rows(const float* src, const int32_t* idx, float* out, int Q, int cols, int64_t nrows, hipStream_t s);

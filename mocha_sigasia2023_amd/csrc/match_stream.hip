@@ -290,10 +290,12 @@ hipError_t launch_match_topk(const void* bank, int bank_bf16, const float* query
 // and every row with  d16_n - rho'_n <= d16_m + rho'_m  (rho'_n = rho_n + 2e-5 d16_n) is a candidate.  The smallest exact distance wins,
 // ties to the lowest row: the result of the exact fp32 search, indices and distance.  On N(0,1) banks 2-4 rows qualify; a bank of
 // identical rows makes every row a candidate (index windows of RF_CAP rows, all evaluated).
-// One 1024-thread workgroup per query; a row's terms are summed by a number of waves fixed per query, so identical rows get
-// identical distances whatever else is in the list.
+// RF_SPLIT 1024-thread workgroups per query, each re-ranking the candidates of its slice of the rows (a bank whose rows crowd within
+// the copy's rounding of the best one - hundreds of candidates - is spread over the chip); the workgroup that finishes last picks the
+// smallest (distance, row) key.  A row's terms are summed by a number of waves fixed per query (from the candidate count over ALL
+// rows), so identical rows get identical distances whatever else is in the list and however the slices fall.
 // ---------------------------------------------------------------------------------------------------------------------
-static constexpr int RF_T = 1024, RF_W = RF_T / 64, RF_CAP = 4096;
+static constexpr int RF_T = 1024, RF_W = RF_T / 64, RF_CAP = 4096, RF_SPLIT = 16;
 
 __global__ __launch_bounds__(256) void mocha_rowresid(const float* __restrict__ x, const float* __restrict__ centre,
                                                       const unsigned short* __restrict__ x16, float* __restrict__ rho, int cols) {
@@ -330,7 +332,8 @@ __device__ __forceinline__ float key_value(unsigned long long k) {
 __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long long* __restrict__ keys /*[Q][N]: coarse d16^2 keys*/,
                                                            const float* __restrict__ rho, const float* __restrict__ bank /*fp32 rows*/,
                                                            const float* __restrict__ query /*fp32, uncentred*/, long long N, int D,
-                                                           int32_t* __restrict__ idx, float* __restrict__ dist) {
+                                                           int32_t* __restrict__ idx, float* __restrict__ dist,
+                                                           unsigned long long* __restrict__ part /*[Q][RF_SPLIT]*/, unsigned* __restrict__ ticket /*[Q]*/) {
     extern __shared__ __attribute__((aligned(16))) float rf_q[];       // [D]
     __shared__ unsigned long long rk[RF_W];
     __shared__ unsigned long long r_key;
@@ -338,7 +341,8 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
     __shared__ int ncand, ntotal;
     __shared__ float dsum[RF_W];
     __shared__ unsigned long long best;
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int is_last;
+    const int q = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) { ncand = 0; ntotal = 0; best = ~0ull; }
     // the query row goes global -> LDS while the keys are read (LDS-DMA, 1 KB per wave instruction)
     const size_t qo = (size_t)q * D;
@@ -378,12 +382,14 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
     int wpc = RF_W;
     while (wpc > 1 && wpc * (total < RF_W ? total : RF_W) > RF_W) wpc >>= 1;
     const int per = RF_W / wpc;
-    // ---- 3. index windows of RF_CAP rows: list, then exact distances in passes of `per` candidates
-    for (long long w0 = 0; w0 < N; w0 += RF_CAP) {
+    // ---- 3. this workgroup's slice of the rows, in index windows of RF_CAP: list, then exact distances in passes of `per` candidates
+    const long long per_slice = (N + RF_SPLIT - 1) / RF_SPLIT;
+    const long long lo = (long long)sl * per_slice, hi_row = lo + per_slice < N ? lo + per_slice : N;
+    for (long long w0 = lo; w0 < hi_row; w0 += RF_CAP) {
         __syncthreads();
         if (tid == 0) ncand = 0;
         __syncthreads();
-        for (long long n = w0 + tid; n < w0 + RF_CAP && n < N; n += RF_T)
+        for (long long n = w0 + tid; n < w0 + RF_CAP && n < hi_row; n += RF_T)
             if (qualifies(n)) cand[atomicAdd(&ncand, 1)] = (int)n;
         __syncthreads();
         const int nc = ncand;
@@ -434,21 +440,45 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
             __syncthreads();
         }
     }
+    // ---- 4. the slices' winners: each workgroup publishes its own, the one that arrives last picks the smallest (distance, row) key.
+    // The ticket counts arrivals and is never reset (RF_SPLIT divides 2^32; calls that share a scratch buffer are ordered by their stream).
+    __syncthreads();
     if (tid == 0) {
-        idx[q] = (int)(best & 0xffffffffull);
-        if (dist) dist[q] = sqrtf(__uint_as_float((unsigned)(best >> 32)));
+        __atomic_store_n(part + (size_t)q * RF_SPLIT + sl, best, __ATOMIC_RELAXED);
+        __threadfence();
+        const unsigned t = atomicAdd(ticket + q, 1u);
+        is_last = (t % RF_SPLIT) == RF_SPLIT - 1;
+    }
+    __syncthreads();
+    if (is_last && tid == 0) {
+        __threadfence();
+        unsigned long long bk = ~0ull;
+        for (int i = 0; i < RF_SPLIT; ++i) {
+            const unsigned long long k = __atomic_load_n(part + (size_t)q * RF_SPLIT + i, __ATOMIC_RELAXED);
+            bk = k < bk ? k : bk;
+        }
+        idx[q] = (int)(bk & 0xffffffffull);
+        if (dist) dist[q] = sqrtf(__uint_as_float((unsigned)(bk >> 32)));
     }
 }
+
+// words of scratch launch_match_scan16 needs for a bank of N rows: the slices' winners and the arrival tickets (the head: must be
+// ZERO when the buffer is first used), then 8 queries' keys
+size_t match_scan16_scratch_head_words() { return 8 * RF_SPLIT + 8; }
+size_t match_scan16_scratch_words(int64_t N) { return match_scan16_scratch_head_words() + (size_t)8 * N; }
 
 hipError_t match_refine_init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_refine), hipFuncAttributeMaxDynamicSharedMemorySize, 23040 * 4);
 }
 
 // few queries against an fp32 bank through its centred bf16 copy: `qc` = the queries minus the centroid (scan operand), `query` the
-// queries themselves (exact re-rank); keys: 8 * N words of scratch
+// queries themselves (exact re-rank); scratch: match_scan16_scratch_words(N) words, head zeroed once
 hipError_t launch_match_scan16(const void* bank16, const float* rho, const float* bank, const float* qc, const float* query, int Q, int64_t N,
-                               int D, unsigned long long* keys, int32_t* idx, float* dist, hipStream_t s) {
+                               int D, unsigned long long* scratch, int32_t* idx, float* dist, hipStream_t s) {
     if (Q <= 0) return hipSuccess;
+    // scratch: [slice winners 8 x RF_SPLIT][arrival tickets 8][coarse keys 8 x N] - the head at a fixed place whatever N
+    unsigned long long* part = scratch;
+    unsigned long long* keys = scratch + match_scan16_scratch_head_words();
     if (D % MS_CHUNK_BF16 != 0 || D % 256 || D > 23040 || N < 1 || N > 0x7ffffff0ll) return hipErrorInvalidValue;
     const int rows_per_wg = MS_WAVES * MS_ROWS_PER_WAVE;
     const unsigned grid = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
@@ -461,8 +491,8 @@ hipError_t launch_match_scan16(const void* bank16, const float* rho, const float
         else if (nq <= 4) MS16_LAUNCH(4);
         else MS16_LAUNCH(8);
 #undef MS16_LAUNCH
-        hipLaunchKernelGGL(mocha_match_refine, dim3(nq), dim3(RF_T), (size_t)D * sizeof(float), s, keys, rho, bank, query + (size_t)q0 * D,
-                           (long long)N, D, idx + q0, dist ? dist + q0 : nullptr);
+        hipLaunchKernelGGL(mocha_match_refine, dim3(nq, RF_SPLIT), dim3(RF_T), (size_t)D * sizeof(float), s, keys, rho, bank, query + (size_t)q0 * D,
+                           (long long)N, D, idx + q0, dist ? dist + q0 : nullptr, part, reinterpret_cast<unsigned*>(part + 8 * RF_SPLIT));
     }
     return hipGetLastError();
 }

@@ -748,7 +748,9 @@ int ensure_match_scratch(mocha_ctx* c, int set, int Q, int64_t N, bool every_q_u
         if (c->scan_keys[set]) (void)hipFree(c->scan_keys[set]);
         c->scan_keys[set] = nullptr; c->scan_keys_n[set] = 0;
         void* kp = nullptr;
-        HIPCHK(c, hipMalloc(&kp, sizeof(unsigned long long) * 8 * (size_t)N));
+        HIPCHK(c, hipMalloc(&kp, sizeof(unsigned long long) * match_scan16_scratch_words(N)));
+        // the head (slice winners, arrival tickets of mocha_match_refine) starts at zero; the tickets only ever count up
+        HIPCHK(c, hipMemset(kp, 0, sizeof(unsigned long long) * match_scan16_scratch_head_words()));
         c->scan_keys[set] = (unsigned long long*)kp; c->scan_keys_n[set] = (size_t)8 * N;
         c->generation++;
     }

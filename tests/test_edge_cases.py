@@ -276,6 +276,12 @@ def test_few_query_scan_through_the_bf16_copy_is_the_fp32_search(model):
         for Q in (1, 2, 3, 8):                                   # every instance of the scan kernel
             dq, iq = ContextBank(model, tb, tb.view(N, 90, 256)).query(tq[:Q])
             assert np.array_equal(iq[:, 0].cpu().numpy().astype(np.int64), i1[:Q])
+        # the re-rank runs as 16 workgroups per query, each on a slice of the rows; the last to arrive (a ticket that only counts up,
+        # kept in the bank's scratch) picks the winner: many calls on one bank, with varying query counts in between, same answers
+        bank_obj = ContextBank(model, tb, tb.view(N, 90, 256))
+        for rep in range(35):
+            dq, iq = bank_obj.query(tq[: 1 + rep % 8])
+            assert np.array_equal(iq[:, 0].cpu().numpy().astype(np.int64), i1[: 1 + rep % 8]), (name, rep)
     bad = torch.from_numpy(rnd[:3].copy()).cuda(); bad[1, 7] = float("nan")
     d, i = ContextBank(model, torch.from_numpy(rnd).cuda(), torch.from_numpy(rnd).cuda().view(N, 90, 256)).query(bad)
     i = i[:, 0].cpu().tolist()

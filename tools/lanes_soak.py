@@ -10,6 +10,14 @@ g = torch.Generator(device=dev); g.manual_seed(7)
 nm = torch.randn((16384, 90 * 256), device=dev, generator=g)
 m_, s_ = synthetic.cnt_norm(7)
 src = torch.from_numpy(synthetic.pose_windows(5, 285)).to(dev)
+# a bank of pure noise sends every window to the same row: plant noisy copies of the windows' own features (a tenth of the gap between
+# the closest two windows away) at scattered rows, so that the 285 gathers are 285 different rows
+with torch.no_grad():
+    mean, std = torch.from_numpy(m_).to(dev), torch.from_numpy(s_).to(dev)
+    nm0 = model.encode(src, mean, std)[2].reshape(285, -1)
+    gap = (torch.cdist(nm0, nm0) + 1e30 * torch.eye(285, device=dev)).min().item()
+    rows = torch.randperm(16384, device=dev, generator=g)[:285]
+    nm[rows] = nm0 + (0.1 * gap / nm0.shape[1] ** 0.5) * torch.randn(nm0.shape, device=dev, generator=g)
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 for bf16 in (False, True):
     bank = ContextBank(model, nm, nm.view(-1, 90, 256), bf16=bf16)
