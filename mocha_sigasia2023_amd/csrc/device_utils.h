@@ -92,6 +92,11 @@ __device__ __forceinline__ void plane_split8(const float (&x)[8], s16x8_t (&out)
         out[q] = __builtin_bit_cast(s16x8_t, v);
     }
 }
+// fp32 -> bf16 bits, round to nearest even; a NaN stays a NaN (v_cvt_pk_bf16_f32).  ONE definition: the matcher's bounds rely on the
+// centred bf16 query plane being rounded identically wherever it is produced (mocha_center_bf16, mocha_instnorm's zc16) and measured
+// (mocha_match_select's ||dq||)
+__device__ __forceinline__ unsigned bf16_bits(float x) { return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x); }
+
 // the order the six products a_i b_j (i + j <= 2) are accumulated in: low-order ones first, a0 b0 last
 static constexpr int PLANE_PA[6] = {0, 1, 2, 0, 1, 0}, PLANE_PB[6] = {2, 1, 0, 1, 0, 0};
 

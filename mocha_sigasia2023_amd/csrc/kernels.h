@@ -92,7 +92,8 @@ hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, f
 // optional extras of the instance norm: zc = zn - centre (the matcher's centred queries, bit-identical to mocha_sub_rows on zn);
 // rows gathered from a table (x row of window b = table[clamp(row_idx[b])], the decoder's cha_encoded[frame_index]) and copied out
 struct InormExtra {
-    const float* centre = nullptr; float* zc = nullptr;
+    const float* centre = nullptr; float* zc = nullptr;      // zc: (z-score - centre), fp32
+    unsigned short* zc16 = nullptr;                          // the same as bf16 (round to nearest even): the many-query bf16 pass's query plane
     const float* table = nullptr; const int32_t* row_idx = nullptr; long long table_rows = 0; float* copy_out = nullptr;
 };
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,

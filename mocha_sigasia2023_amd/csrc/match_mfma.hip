@@ -24,9 +24,6 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned bf16_bits(float x) {        // round to nearest even; a NaN stays a NaN (v_cvt_pk_bf16_f32)
-    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)x);
-}
 
 // out = bf16(x - centre) row by row: the centred queries of the bf16 coarse pass.  One thread per 8 elements, flat grid
 // (a few hundred query rows do not fill the chip with one workgroup per row).

@@ -758,7 +758,9 @@ int ensure_match_scratch(mocha_ctx* c, int set, int Q, int64_t N, bool every_q_u
 }
 
 // qc_pre: the queries minus the current bank's centroid, fp32, when the caller's producer already wrote them (mocha_instnorm's zc)
-int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, hipStream_t s, const float* qc_pre = nullptr) {
+// (fp32; bf16 where the many-query pass against a bf16 bank wants them so: qc_pre_bf16, mocha_instnorm's zc16)
+int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, hipStream_t s, const void* qc_pre_any = nullptr,
+             bool qc_pre_bf16 = false) {
     if (!c->bank_cnt || c->bank_N <= 0) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
     const int D = 90 * 256;
     const int64_t N = c->bank_N;
@@ -769,7 +771,9 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     // them as bf16 (match_qc holds Q x D bf16 then), everything else as fp32.
     const bool via16 = Q <= 8 && !c->bank_is_bf16 && c->bank16f_valid && c->scan16 && c->scan_keys_n[set] >= (size_t)8 * N;
     const bool need_qc = c->bank_is_bf16 || Q > 8 || via16;
-    if (qc_pre && c->bank_is_bf16 && Q > 8) qc_pre = nullptr;      // that pass takes the centred queries as bf16 (mocha_center_bf16)
+    // the many-query pass against a bf16 bank takes the centred queries as bf16, everything else as fp32: a precomputed copy of the
+    // other kind is of no use (mocha_center_bf16 / mocha_sub_rows then make the right one)
+    const float* qc_pre = (qc_pre_any && qc_pre_bf16 == (c->bank_is_bf16 && Q > 8)) ? static_cast<const float*>(qc_pre_any) : nullptr;
     if (need_qc && !qc_pre) {
         if (c->bank_is_bf16 && Q > 8)
             LAUNCH(c, s, "mocha_center_bf16", "match.center", 0.0, 6.0 * Q * D, launch_center_bf16(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
@@ -1370,9 +1374,12 @@ static int characterize_impl(mocha_ctx* c, const float* src_X, int B, const floa
         if ((r = run_embed(c, src_X + b0 * xs, b, WS(c, "x5"), true, s, raw))) return r;
         if ((r = run_encoder(c, WS(c, "x5"), b, WS(c, "enc_s"), s))) return r;
         // cnt, its z-score and - the bank's centroid is known - the matcher's centred queries in one pass
-        InormExtra ex; ex.centre = c->bank_center; ex.zc = WS(c, "qc");
-        LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * 3, launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s, &ex));
-        if ((r = do_match(c, WS(c, "qnm"), b, ix, nullptr, s, WS(c, "qc")))) return r;
+        // (as one bf16 plane where the many-query pass against a bf16 bank will read them: no mocha_center_bf16 launch)
+        const bool q16 = c->bank_is_bf16 && b > 8;
+        InormExtra ex; ex.centre = c->bank_center;
+        if (q16) ex.zc16 = reinterpret_cast<unsigned short*>(WS(c, "qc")); else ex.zc = WS(c, "qc");
+        LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (q16 ? 2.5 : 3.0), launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s, &ex));
+        if ((r = do_match(c, WS(c, "qnm"), b, ix, nullptr, s, WS(c, "qc"), q16))) return r;
         // decoder on cha_encoded[frame_index]: its first kernel gathers the rows itself
         if ((r = run_decoder(c, WS(c, "enc_s"), nullptr, b, WS(c, "dec"), s, c->bank_enc, ix, c->bank_N))) return r;
         return run_to_mot(c, WS(c, "dec"), b, Y + b0 * ys, s, raw);

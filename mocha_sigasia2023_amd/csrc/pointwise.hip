@@ -476,7 +476,14 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
                 const f32x4 sd = EARLY ? zs[EARLY ? i : 0] : reinterpret_cast<const f32x4*>(gs)[t * 64 + q];
                 const f32x4 z = (v - m) / sd;
                 (reinterpret_cast<f32x4*>(zn + (size_t)b * n * 256) + q)[(size_t)t * 64] = z;
-                if (ex.zc) (reinterpret_cast<f32x4*>(ex.zc + (size_t)b * n * 256) + q)[(size_t)t * 64] = z - reinterpret_cast<const f32x4*>(ex.centre)[t * 64 + q];
+                if (ex.zc || ex.zc16) {
+                    const f32x4 zc = z - reinterpret_cast<const f32x4*>(ex.centre)[t * 64 + q];
+                    if (ex.zc) (reinterpret_cast<f32x4*>(ex.zc + (size_t)b * n * 256) + q)[(size_t)t * 64] = zc;
+                    if (ex.zc16) {
+                        const u32x2_t w = {bf16_bits(zc[0]) | (bf16_bits(zc[1]) << 16), bf16_bits(zc[2]) | (bf16_bits(zc[3]) << 16)};
+                        (reinterpret_cast<u32x2_t*>(ex.zc16 + (size_t)b * n * 256) + q)[(size_t)t * 64] = w;
+                    }
+                }
             }
         }
 }
@@ -489,7 +496,7 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
     if (B <= 0) return hipSuccess;
     if (n > IN_NG * IN_MAXT || n < 2) return hipErrorInvalidValue;
     InormExtra ex = exp ? *exp : InormExtra{};
-    if ((ex.zc && (!zn || !ex.centre)) || (ex.row_idx && (!ex.table || ex.table_rows < 1))) return hipErrorInvalidValue;
+    if (((ex.zc || ex.zc16) && (!zn || !ex.centre)) || (ex.row_idx && (!ex.table || ex.table_rows < 1))) return hipErrorInvalidValue;
     if (inorm_split(B)) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     else hipLaunchKernelGGL(mocha_instnorm<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     return hipGetLastError();

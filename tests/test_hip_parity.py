@@ -273,6 +273,35 @@ def test_bf16_bank_many_queries_agrees_with_fp32():
     assert (i32 == i16).mean() >= 0.95                    # random N(0,1) banks: gaps >> bf16 rounding
 
 
+@pytest.mark.parametrize("B", [9, 40, 130])
+def test_characterize_on_a_bf16_bank_is_encode_then_query(B):
+    """Against a bf16 bank with more than 8 windows, characterize()'s instance norm writes the matcher's centred bf16 query plane
+    itself (InormExtra::zc16) instead of a mocha_center_bf16 launch on the z-scored features.  Same subtraction, same rounding: the
+    indices must be those of encode() -> ContextBank.query() on the same windows, and the poses those of the decoder on the rows
+    those indices gather."""
+    sd = weights.synthetic_state_dict(12, 1.3)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    mean, std = synthetic.cnt_norm(6)
+    r = np.random.Generator(np.random.PCG64(77))
+    src = T(synthetic.pose_windows(31, B))
+    with torch.no_grad():
+        _, _, nm = model.encode(src, T(mean), T(std))
+    nm = nm.reshape(B, -1)
+    # a bank with near neighbours for every query (so that a differently rounded query plane WOULD change candidates) and noise rows
+    bank_nm = torch.cat([nm + T((2e-3 * r.standard_normal(nm.shape)).astype(np.float32)),
+                         nm + T((3e-3 * r.standard_normal(nm.shape)).astype(np.float32)),
+                         T(r.standard_normal((300, nm.shape[1])).astype(np.float32))])
+    bank_enc = T(r.standard_normal((bank_nm.shape[0], 90, 256)).astype(np.float32))
+    bank = ContextBank(model, bank_nm, bank_enc, bf16=True)
+    Y, idx = bank.characterize(src, T(mean), T(std), return_index=True)
+    iq = bank.query(nm.contiguous(), return_distance=False)[:, 0]
+    assert torch.equal(idx.view(-1).to(torch.int64), iq.view(-1).to(torch.int64))
+    with torch.no_grad():
+        enc, _, _ = model.encode(src, T(mean), T(std))
+        Y2 = model.to_mot(model.decoder(enc, bank.gather(iq.to(torch.int32).contiguous())))
+    assert float((Y - Y2).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("lanes", [1, 2, 3])
 def test_streaming_lanes_reproduce_the_synchronous_steps(lanes):
     """BASELINE configs[4] pipelined: run_clip keeps up to three captured per-window steps in flight on their own lanes (workspace
