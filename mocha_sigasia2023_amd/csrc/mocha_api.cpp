@@ -448,8 +448,9 @@ int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
     return 0;
 }
 // the Generator's attention (90 tokens, head dim 128 / 256): plane products on the bf16 pipe unless switched off
-const char* attn_kernel_name(const mocha_ctx* c, int DH) {
+const char* attn_kernel_name(const mocha_ctx* c, int DH, long long pairs = 1 << 30) {
     const bool x3 = c->attn_x3 && (DH == 128 || DH == 256);
+    if (x3 && DH == 256 && pairs <= attention_x3_split_max) return "mocha_attention_x3_split<256>";
     return x3 ? (DH == 128 ? "mocha_attention_x3<128>" : "mocha_attention_x3<256>") : (DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>");
 }
 hipError_t attention(const mocha_ctx* c, const AttnParams& a, hipStream_t s) {
@@ -598,7 +599,7 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
             GemmParams gq = plain(WS(c, "qin"), 256, DW(c, p + ".Wqk"), qb, inner, M, inner, 256);
             GEMM(c, s, "dec.q", gq);
             AttnParams a{qb, WS(c, "kin"), cha, WS(c, "ao"), inner, 256, 256, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5), 0, 0};
-            LAUNCH(c, s, attn_kernel_name(c, DH), "dec.attn", 4.0 * b * H * 90.0 * 90 * DH, 4.0 * M * (2 * inner + 2 * 256),
+            LAUNCH(c, s, attn_kernel_name(c, DH, (long long)b * H), "dec.attn", 4.0 * b * H * 90.0 * 90 * DH, 4.0 * M * (2 * inner + 2 * 256),
                    attention(c, a, s));
             float* out = (l == c->cfg.dec_depth - 1) ? outp : WS(c, "xa");
             int rc = run_out_ff(c, p, WS(c, "ao"), inner, WS(c, "xad"), M, c->cfg.dec_mlp, out, s, ".Wvo");
@@ -613,7 +614,7 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
         GemmParams gv = plain(cha, 256, DW(c, p + ".Wv"), vb, inner, M, inner, 256);
         GEMM(c, s, "dec.v", gv);
         AttnParams a{qb, kb, vb, WS(c, "ao"), inner, inner, inner, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5)};
-        LAUNCH(c, s, attn_kernel_name(c, DH), "dec.attn", 4.0 * b * H * 90.0 * 90 * DH,
+        LAUNCH(c, s, attn_kernel_name(c, DH, (long long)b * H), "dec.attn", 4.0 * b * H * 90.0 * 90 * DH,
                4.0 * M * 4 * inner, attention(c, a, s));
         float* out = (l == c->cfg.dec_depth - 1) ? outp : WS(c, "xa");
         int rc = run_out_ff(c, p, WS(c, "ao"), inner, WS(c, "xad"), M, c->cfg.dec_mlp, out, s);
