@@ -92,12 +92,13 @@ int mocha_embed(mocha_ctx* ctx, const float* X, int B, float* tokens, int add_po
 /* model.encoder(tokens), model.py:53-59, net/transformer.py:90-95 (test_fullframework.py:192). */
 int mocha_encoder(mocha_ctx* ctx, const float* tokens, int B, float* encoded, void* stream);
 /* mean_variance_norm(encoded.permute(0,2,1)).permute(0,2,1), net/transformer.py:13-20
- * (test_fullframework.py:193).  If cnt_mean/cnt_std (90,256) and cnt_nm are non-NULL also
- * writes cnt_nm = (cnt - cnt_mean) / cnt_std (test_fullframework.py:293,297,442). */
+ * (test_fullframework.py:193).  If cnt_nm is non-NULL also writes cnt_nm = (cnt - cnt_mean) / cnt_std
+ * (test_fullframework.py:293,297,442; cnt_mean / cnt_std (90,256) are then required).  cnt may be NULL when only cnt_nm is
+ * wanted (at least one of the two must be given). */
 int mocha_mvn(mocha_ctx* ctx, const float* encoded, int B, float* cnt,
               const float* cnt_mean, const float* cnt_std, float* cnt_nm, void* stream);
-/* Fused demo encode sequence test_fullframework.py:190-193: embed, +pos_emb, encoder and
- * (when cnt != NULL) the cnt feature; cnt_nm as in mocha_mvn. */
+/* Fused demo encode sequence test_fullframework.py:190-193: embed, +pos_emb, encoder and - each when its pointer is non-NULL -
+ * the cnt feature and its z-scored copy cnt_nm (as in mocha_mvn: cnt_nm needs cnt_mean / cnt_std, not cnt). */
 int mocha_encode(mocha_ctx* ctx, const float* X, int B, float* encoded, float* cnt,
                  const float* cnt_mean, const float* cnt_std, float* cnt_nm, void* stream);
 /* model.decoder(src_enc, cha_enc), model.py:62-68, net/transformer.py:90-121 (test_fullframework.py:301,455,465). */

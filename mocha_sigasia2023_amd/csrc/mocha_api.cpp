@@ -1151,11 +1151,12 @@ int mocha_mvn(mocha_ctx* c, const float* encoded, int B, float* cnt, const float
               float* cnt_nm, void* stream) {
     if (!c) return MOCHA_ERR_ARG;                      // needs no weights: usable on a bare context
     if (B == 0) return 0;                              // empty batch: nothing to do, pointers may be null
-    if (!encoded || !cnt || B < 0) return fail(c, MOCHA_ERR_ARG, "bad mvn arguments");
+    if (!encoded || (!cnt && !cnt_nm) || B < 0) return fail(c, MOCHA_ERR_ARG, "bad mvn arguments");
+    if (cnt_nm && (!cnt_mean || !cnt_std)) return fail(c, MOCHA_ERR_ARG, "mocha_mvn: cnt_nm needs cnt_mean and cnt_std");
     HIPCHK(c, hipSetDevice(c->device));
-    const bool zn = cnt_nm && cnt_mean && cnt_std;
+    const bool zn = cnt_nm != nullptr;
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * (zn ? 3 : 2), launch_instnorm(encoded, cnt, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr, zn ? cnt_nm : nullptr, B, 90, s));
+    LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * (1 + (cnt ? 1 : 0) + (zn ? 1 : 0)), launch_instnorm(encoded, cnt, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr, zn ? cnt_nm : nullptr, B, 90, s));
     return 0;
 }
 
@@ -1163,14 +1164,15 @@ int mocha_encode(mocha_ctx* c, const float* X, int B, float* encoded, float* cnt
                  const float* cnt_std, float* cnt_nm, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
     const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in, ts = 90 * 256;
-    const bool zn = cnt && cnt_nm && cnt_mean && cnt_std;
+    if (cnt_nm && (!cnt_mean || !cnt_std)) return fail(c, MOCHA_ERR_ARG, "mocha_encode: cnt_nm needs cnt_mean and cnt_std");
+    const bool zn = cnt_nm != nullptr;                      // cnt itself is optional: the z-scored copy alone is a valid request
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         int r = run_embed(c, X + b0 * xs, b, WS(c, "x5"), true, s);      // x5 is free again once the body block has read it
         if (r) return r;
         if ((r = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s))) return r;
-        if (cnt)
-            LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (zn ? 3 : 2),
-                   launch_instnorm(encoded + b0 * ts, cnt + b0 * ts, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
+        if (cnt || zn)
+            LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (1 + (cnt ? 1 : 0) + (zn ? 1 : 0)),
+                   launch_instnorm(encoded + b0 * ts, cnt ? cnt + b0 * ts : nullptr, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
                                    zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
         return 0;
     });
@@ -1722,14 +1724,15 @@ int mocha_encode_raw(mocha_ctx* c, const float* X_raw, int B, float* encoded, fl
                      const float* cnt_std, float* cnt_nm, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
     const size_t xs = (size_t)60 * (c->cfg.V + 1) * c->cfg.C_in, ts = 90 * 256;
-    const bool zn = cnt && cnt_nm && cnt_mean && cnt_std;
+    if (cnt_nm && (!cnt_mean || !cnt_std)) return fail(c, MOCHA_ERR_ARG, "mocha_encode_raw: cnt_nm needs cnt_mean and cnt_std");
+    const bool zn = cnt_nm != nullptr;
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         int r;
         if ((r = run_embed(c, X_raw + b0 * xs, b, WS(c, "x5"), true, s, true))) return r;
         if ((r = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s))) return r;
-        if (cnt)
-            LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (zn ? 3 : 2),
-                   launch_instnorm(encoded + b0 * ts, cnt + b0 * ts, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
+        if (cnt || zn)
+            LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (1 + (cnt ? 1 : 0) + (zn ? 1 : 0)),
+                   launch_instnorm(encoded + b0 * ts, cnt ? cnt + b0 * ts : nullptr, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
                                    zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
         return 0;
     });
