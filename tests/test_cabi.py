@@ -108,3 +108,15 @@ def test_bcast_plan_covers_every_float_exactly_once():
 def test_build_info_names_the_toolchain():
     lib = _built()
     assert lib.mocha_build_info().decode().startswith("hipcc HIP ")
+
+
+def test_native_host_example_builds_against_the_header_and_library():
+    """examples/cabi_demo.cpp (C++ + the HIP runtime, no torch) compiles against include/mocha_hip.h and links against the in-tree
+    libmocha_hip.so - hipcc cross-compiles without a GPU; tests/test_native_host.py runs it on the GPU box."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["make", "-C", os.path.join(root, "examples")], check=True, capture_output=True)
+    exe = os.path.join(root, "examples", "cabi_demo")
+    assert os.path.exists(exe)
+    needed = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-d", exe], capture_output=True, text=True).stdout
+    assert "libmocha_hip.so" in needed and "libtorch" not in needed and "libpython" not in needed
