@@ -402,6 +402,32 @@ def post_record(model, dev, W):
     return out
 
 
+def bank_build_record(model, dev, V):
+    """Row N4: building a character bank on the device - 4 096 synthetic windows encoded (mot_embedding, encoder, cnt), the
+    bank's cnt_mean / cnt_std (mocha_column_stats: compute_cnt_norm.py:157-179), the z-score, and mocha_bank_set with the bf16 copy,
+    centroid, row norms (collect_CVAE_feature_action.py:167-189 + the demo's BallTree construction, test_fullframework.py:293-294).
+    Wall clock with one synchronisation at the end, best of three."""
+    from mocha_sigasia2023_amd import ContextBank, bank as BK, synthetic
+    N = 4096
+    X = torch.from_numpy(synthetic.pose_windows(77, N, V)).to(dev)
+    tw = torch.from_numpy(synthetic.temporal_weight(15, 6, 256)).to(dev)
+
+    def build():
+        b = BK.build_bank(model, X)
+        std = (b["cnt_std"].clamp_min(1e-6) / tw).contiguous()
+        nm = ((b["cnt"] - b["cnt_mean"]) / std).reshape(N, -1)
+        return ContextBank(model, nm, b["encoded"], bf16=True)
+    best = None
+    for _ in range(4):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        bank = build()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+        del bank
+    return {"windows": N, "ms": best * 1e3, "windows_per_s": N / best,
+            "note": "encode 4 096 windows + cnt statistics + z-score + mocha_bank_set (bf16 copy, centroid, norms); the z-score is a torch expression here"}
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
@@ -623,6 +649,7 @@ def main():
                 out["stream_16k"] = stream_record(model, dev, V)
                 out["ours"] = ours_record(model, dev)
                 out["post"] = post_record(model, dev, W)
+                out["bank_build"] = bank_build_record(model, dev, V)
                 if V != 24:
                     sd24 = synthetic_state_dict(seed=1777, gain=1.0, layout="mocha")
                     m24 = Generator(layout="mocha", device=dev).load_state_dict(sd24).eval()
