@@ -147,14 +147,32 @@ def transformer(sd, name, x, sty=None, depth=2, heads=4, stages=None):
     return x
 
 
+# configs/config.yaml:19,25 (encoder_heads / decoder_heads): the one model dimension the weights' shapes do not determine (depth is
+# counted from the state_dict, dim_head = inner / heads).  Tests of non-default configurations set it through heads_config().
+HEADS = {'encoder': 4, 'decoder': 4}
+
+
+class heads_config:
+    """with heads_config(enc, dec): ... - the oracle's encoder / decoder head counts inside the block (model.py:53-68)."""
+
+    def __init__(self, enc=4, dec=4):
+        self.new = {'encoder': enc, 'decoder': dec}
+
+    def __enter__(self):
+        self.old = dict(HEADS); HEADS.update(self.new)
+
+    def __exit__(self, *a):
+        HEADS.update(self.old)
+
+
 def encoder(sd, tokens, stages=None):
     """model.py:53-59 — Transformer(dim 256, depth 2, heads 4, dim_head 128, mlp 512, adain=False)."""
-    return transformer(sd, 'encoder', tokens, None, depth=_depth(sd, 'encoder'), heads=4, stages=stages)
+    return transformer(sd, 'encoder', tokens, None, depth=_depth(sd, 'encoder'), heads=HEADS['encoder'], stages=stages)
 
 
 def decoder(sd, src_enc, cha_enc, stages=None):
     """model.py:62-68 — Transformer(dim 256, depth 2, heads 4, dim_head 256, mlp 512, adain=True)."""
-    return transformer(sd, 'decoder', src_enc, cha_enc, depth=_depth(sd, 'decoder'), heads=4, stages=stages)
+    return transformer(sd, 'decoder', src_enc, cha_enc, depth=_depth(sd, 'decoder'), heads=HEADS['decoder'], stages=stages)
 
 
 def _depth(sd, name):

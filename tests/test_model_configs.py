@@ -1,0 +1,57 @@
+"""Model configurations other than the shipped one (run with -m gpu).  The reference builds its Generator from configs/config.yaml
+(model.py:16-80): depths, head counts and head dims are free there; mocha_create accepts depth 1..8, dim_head 128 / 256 on either
+side and heads x dim_head <= 1024 (everything else fails loudly, tests/test_cabi.py).  Every accepted variation must still be the
+reference's arithmetic: compared with the oracle on seeded weights of those shapes, through forward, the demo's characterize sequence,
+and at batch sizes that select the small-batch kernels (skinny GEMMs, twelve-wave attention for head dim 256 on EITHER side) and the
+tiled / plane engines."""
+import numpy as np
+import pytest
+import torch
+
+from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, weights
+from oracle import mocha_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+CONFIGS = {
+    "enc 1 x (4 x 128), dec 3 x (4 x 256)": dict(encoder_depth=1, decoder_depth=3),
+    "enc 2 x (4 x 256), dec 2 x (4 x 128)": dict(encoder_dim_head=256, decoder_dim_head=128),
+    "enc 3 x (8 x 128), dec 1 x (2 x 256)": dict(encoder_depth=3, encoder_heads=8, decoder_depth=1, decoder_heads=2),
+    "enc 2 x (1 x 128), dec 4 x (3 x 256)": dict(encoder_heads=1, decoder_depth=4, decoder_heads=3),
+    "enc 8 x (2 x 256), dec 8 x (8 x 128)": dict(encoder_depth=8, encoder_heads=2, encoder_dim_head=256, decoder_depth=8, decoder_heads=8,
+                                                 decoder_dim_head=128),
+}
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("B", [2, 40])
+def test_other_model_configurations_against_the_oracle(name, B):
+    cfg = dict(weights.DEFAULT_CFG, **CONFIGS[name])
+    layout = "mocha"
+    sd = weights.synthetic_state_dict(4242, 1.0 if cfg["encoder_depth"] + cfg["decoder_depth"] > 8 else 1.3, layout, cfg=cfg)
+    model = Generator(cfg, layout=layout, device="cuda:0").load_state_dict(sd).eval()
+    src = synthetic.pose_windows(11, B, 24)
+    cha = synthetic.pose_windows(12, B, 24)
+    mean, std = synthetic.cnt_norm(5)
+    ost = O.to_torch_state(sd)
+    with O.heads_config(cfg["encoder_heads"], cfg["decoder_heads"]), torch.no_grad():
+        ref_fwd = O.generator_forward(ost, torch.from_numpy(src), torch.from_numpy(cha)).numpy()
+        ref_enc, ref_cnt = O.encode(ost, torch.from_numpy(cha))
+        ref_Y, ref_idx = O.characterize(ost, torch.from_numpy(src), torch.from_numpy(cha), mean, std)
+    ts, tc = torch.from_numpy(src).cuda(), torch.from_numpy(cha).cuda()
+    tm, tsd = torch.from_numpy(mean).cuda(), torch.from_numpy(std).cuda()
+    with torch.no_grad():
+        Y = model(ts, tc)
+        enc, cnt, nm = model.encode(tc, tm, tsd)
+        Yc, idx = ContextBank(model, nm.reshape(B, -1), enc).characterize(ts, tm, tsd, return_index=True)
+        Yp, idxp = model.characterize_pair(ts, tc, tm, tsd, return_index=True)
+    scale = max(1.0, float(np.abs(ref_fwd).max()))
+    assert np.abs(Y.cpu().numpy() - ref_fwd).max() < TOL * scale, name
+    es = max(1.0, float(ref_enc.abs().max()))
+    assert float((enc.cpu() - ref_enc).abs().max()) < TOL * es and float((cnt.cpu() - ref_cnt).abs().max()) < TOL * max(1.0, float(ref_cnt.abs().max()))
+    same = idx.view(-1).cpu().numpy() == ref_idx
+    assert same.mean() >= 0.9, (name, same.mean())               # near-ties of the synthetic features may legitimately swap
+    ys = max(1.0, float(ref_Y.abs().max()))
+    assert float((Yc.cpu()[same] - ref_Y[same]).abs().max()) < TOL * ys
+    assert torch.equal(idxp.view(-1), idx.view(-1)) and float((Yp - Yc).abs().max()) < 1e-5 * ys
