@@ -31,7 +31,7 @@ from mocha_sigasia2023_amd import synthetic, weights  # noqa: E402
 from mocha_sigasia2023_amd.skeleton import skeleton_constants  # noqa: E402
 
 
-def build_reference_generator(layout):
+def build_reference_generator(layout, overrides=None):
     """Instantiate the reference Generator; for 'mixamo' swap the two hard-coded 'mocha'
     pool modules after construction."""
     cwd = os.getcwd()
@@ -48,6 +48,9 @@ def build_reference_generator(layout):
         if layout != "mocha":
             cfg["graph"]["joint"]["layout"] = layout
             cfg["graph"]["bodypart"]["layout"] = layout
+        for k, v in (overrides or {}).items():              # configs/config.yaml:13-31: depths, heads, head dims
+            assert k in cfg, k
+            cfg[k] = v
         G = Generator(cfg)
         if layout != "mocha":
             G.mot_embedding[3] = PoolJointToBodypart(layout)
@@ -99,6 +102,34 @@ def run_variant(name, layout, seed, gain, B):
     np.savez(path, **out, meta=np.array(repr(meta)))
     print(name, {k: (v.shape, float(np.abs(v).max())) for k, v in out.items()})
     return path
+
+
+# model configurations other than the shipped one (model.py:16-80 reads them from the config): the reference built with them, our
+# seeded weights of those shapes, B = 2; only the outputs are stored (inputs and weights are regenerated from the seeds)
+CONFIG_VARIANTS = {
+    "e1h4d128_d3h4d256": dict(encoder_depth=1, decoder_depth=3),
+    "e2h4d256_d2h4d128": dict(encoder_dim_head=256, decoder_dim_head=128),
+    "e3h8d128_d1h2d256": dict(encoder_depth=3, encoder_heads=8, decoder_depth=1, decoder_heads=2),
+    "e2h1d128_d4h3d256": dict(encoder_heads=1, decoder_depth=4, decoder_heads=3),
+}
+
+
+def run_config_variants():
+    out = {}
+    for name, ov in CONFIG_VARIANTS.items():
+        G, mvn = build_reference_generator("mocha", ov)
+        cfg = dict(weights.DEFAULT_CFG, **ov)
+        sd = weights.synthetic_state_dict(seed=909, gain=1.3, layout="mocha", cfg=cfg)
+        G.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        src = torch.from_numpy(synthetic.pose_windows(910, 2, 24)); cha = torch.from_numpy(synthetic.pose_windows(911, 2, 24))
+        with torch.no_grad():
+            tokens = G.mot_embedding(cha)
+            enc = G.encoder(tokens + G.pos_emb[:, :tokens.shape[1]])
+            out[f"{name}_cha_encoded"] = enc.numpy()
+            out[f"{name}_Y_forward"] = G(src, cha).numpy()
+    np.savez(os.path.join(HERE, "generator_config_variants.npz"), **out,
+             meta=np.array(repr(dict(seed=909, gain=1.3, src_seed=910, cha_seed=911, B=2, variants=CONFIG_VARIANTS, torch=torch.__version__))))
+    print("config variants", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items()})
 
 
 def run_graph_constants():
@@ -370,6 +401,7 @@ if __name__ == "__main__":
     run_variant("mocha24_g1", "mocha", seed=1777, gain=1.0, B=2)
     run_variant("mocha24_g2", "mocha", seed=4242, gain=2.0, B=1)
     run_variant("mixamo22_g1", "mixamo", seed=2222, gain=1.0, B=1)
+    run_config_variants()
     run_match()
     run_cvae()
     run_featurize()

@@ -55,3 +55,23 @@ def test_other_model_configurations_against_the_oracle(name, B):
     ys = max(1.0, float(ref_Y.abs().max()))
     assert float((Yc.cpu()[same] - ref_Y[same]).abs().max()) < TOL * ys
     assert torch.equal(idxp.view(-1), idx.view(-1)) and float((Yp - Yc).abs().max()) < 1e-5 * ys
+
+
+def test_other_model_configurations_against_the_reference_fixture():
+    """The same through fixtures the reference itself produced for four such configurations (tests/golden/make_golden.py::
+    run_config_variants): the HIP path, not only the oracle, is held to the reference's outputs."""
+    import ast
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "generator_config_variants.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    src = torch.from_numpy(synthetic.pose_windows(meta["src_seed"], meta["B"], 24)).cuda()
+    cha = torch.from_numpy(synthetic.pose_windows(meta["cha_seed"], meta["B"], 24)).cuda()
+    for name, ov in meta["variants"].items():
+        cfg = dict(weights.DEFAULT_CFG, **ov)
+        sd = weights.synthetic_state_dict(meta["seed"], meta["gain"], "mocha", cfg=cfg)
+        model = Generator(cfg, layout="mocha", device="cuda:0").load_state_dict(sd).eval()
+        with torch.no_grad():
+            enc, _ = model.encode(cha)
+            Y = model(src, cha)
+        assert np.abs(enc.cpu().numpy() - z[f"{name}_cha_encoded"]).max() < TOL * max(1.0, float(np.abs(z[f"{name}_cha_encoded"]).max())), name
+        assert np.abs(Y.cpu().numpy() - z[f"{name}_Y_forward"]).max() < TOL, name

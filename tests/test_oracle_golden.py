@@ -97,3 +97,24 @@ def test_temporal_weight():
     w = O.temporal_weight()
     assert w.shape == (90, 256) and w[0, 0] == 1.0 and w[-1, -1] == 3.0
     assert np.array_equal(w, synthetic.temporal_weight())
+
+
+def test_model_configurations_other_than_the_shipped_one(golden_dir):
+    """The oracle with other depths / head counts / head dims against the REFERENCE built with them (make_golden.py::
+    run_config_variants: model.py:16-80 from an edited configs/config.yaml dict): depth is counted from the state_dict, the head dim
+    follows from the weights' shapes, the head counts come through heads_config()."""
+    import ast
+    import torch
+    from mocha_sigasia2023_amd import synthetic, weights
+    z = np.load(os.path.join(golden_dir, "generator_config_variants.npz"))
+    meta = ast.literal_eval(str(z["meta"]))
+    src = torch.from_numpy(synthetic.pose_windows(meta["src_seed"], meta["B"], 24))
+    cha = torch.from_numpy(synthetic.pose_windows(meta["cha_seed"], meta["B"], 24))
+    for name, ov in meta["variants"].items():
+        cfg = dict(weights.DEFAULT_CFG, **ov)
+        ost = O.to_torch_state(weights.synthetic_state_dict(meta["seed"], meta["gain"], "mocha", cfg=cfg))
+        with O.heads_config(cfg["encoder_heads"], cfg["decoder_heads"]), torch.no_grad():
+            enc, _ = O.encode(ost, cha)
+            Y = O.generator_forward(ost, src, cha)
+        assert np.abs(enc.numpy() - z[f"{name}_cha_encoded"]).max() < 2e-5, name
+        assert np.abs(Y.numpy() - z[f"{name}_Y_forward"]).max() < 5e-6, name
