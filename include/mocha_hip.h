@@ -18,6 +18,8 @@
  *     scratch for every query count the workspace admits), mocha_bank_broadcast, mocha_set_option and the first call
  *     with a batch larger than any before.  Each such replacement bumps mocha_generation(ctx): a caller that captured
  *     calls into its own HIP graph compares the generation before replaying (mocha_step_graph does so itself);
+ *   - a NULL where a required device pointer belongs is MOCHA_ERR_ARG ("... null argument"), never a launch; with an empty batch
+ *     (B == 0) the tensor pointers may be NULL and nothing is touched (tests/test_edge_cases.py);
  *   - functions return 0 on success, a negative mocha_status otherwise;
  *     mocha_last_error(ctx) gives the message.  The caller owns every in/out buffer; the
  *     context owns the device copies of the weights, the bank (unless borrowed) and the

@@ -689,6 +689,12 @@ int ready(mocha_ctx* c, int B) {
     return 0;
 }
 
+// required device pointers of a call with B > 0: a NULL must come back as an error code, not as a GPU fault that takes the host down
+#define NEED_PTRS(c, B, what, ...)                                                                     \
+    do {                                                                                               \
+        if ((B) > 0) { const void* need__[] = {__VA_ARGS__}; for (const void* p__ : need__) if (!p__) return fail((c), MOCHA_ERR_ARG, what ": null argument"); } \
+    } while (0)
+
 // Nearest bank entry of every query (BallTree.query(k=1), test_fullframework.py:296,443).
 // Precision: the rows of one character's bank sit close together far from the origin (||b||^2 ~ 1e5, gaps between the
 // best candidates ~ 1e-2), so ||b||^2 - 2 q.b in fp32 cannot rank them.  Few queries: the HBM-bound scan evaluates
@@ -1133,6 +1139,7 @@ int mocha_graph_constants(mocha_ctx* c, float* A_j, float* A_b, float* pool, flo
 
 int mocha_embed(mocha_ctx* c, const float* X, int B, float* tokens, int add_pos, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
+    NEED_PTRS(c, B, "mocha_embed", X, tokens);
     const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in, ts = 90 * 256;
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         return run_embed(c, X + b0 * xs, b, tokens + b0 * ts, add_pos != 0, s);
@@ -1141,6 +1148,7 @@ int mocha_embed(mocha_ctx* c, const float* X, int B, float* tokens, int add_pos,
 
 int mocha_encoder(mocha_ctx* c, const float* tokens, int B, float* encoded, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
+    NEED_PTRS(c, B, "mocha_encoder", tokens, encoded);
     const size_t ts = 90 * 256;
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         return run_encoder(c, tokens + b0 * ts, b, encoded + b0 * ts, s);
@@ -1163,6 +1171,7 @@ int mocha_mvn(mocha_ctx* c, const float* encoded, int B, float* cnt, const float
 int mocha_encode(mocha_ctx* c, const float* X, int B, float* encoded, float* cnt, const float* cnt_mean,
                  const float* cnt_std, float* cnt_nm, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
+    NEED_PTRS(c, B, "mocha_encode", X, encoded);
     const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in, ts = 90 * 256;
     if (cnt_nm && (!cnt_mean || !cnt_std)) return fail(c, MOCHA_ERR_ARG, "mocha_encode: cnt_nm needs cnt_mean and cnt_std");
     const bool zn = cnt_nm != nullptr;                      // cnt itself is optional: the z-scored copy alone is a valid request
@@ -1180,6 +1189,7 @@ int mocha_encode(mocha_ctx* c, const float* X, int B, float* encoded, float* cnt
 
 int mocha_decoder(mocha_ctx* c, const float* src_enc, const float* cha_enc, int B, float* out, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
+    NEED_PTRS(c, B, "mocha_decoder", src_enc, cha_enc, out);
     const size_t ts = 90 * 256;
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         return run_decoder(c, src_enc + b0 * ts, cha_enc + b0 * ts, b, out + b0 * ts, s);
@@ -1188,6 +1198,7 @@ int mocha_decoder(mocha_ctx* c, const float* src_enc, const float* cha_enc, int 
 
 int mocha_to_mot(mocha_ctx* c, const float* tokens, int B, float* Y, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
+    NEED_PTRS(c, B, "mocha_to_mot", tokens, Y);
     const size_t ts = 90 * 256, ys = (size_t)60 * c->cfg.V * c->cfg.C_in;
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         return run_to_mot(c, tokens + b0 * ts, b, Y + b0 * ys, s);
@@ -1196,6 +1207,7 @@ int mocha_to_mot(mocha_ctx* c, const float* tokens, int B, float* Y, void* strea
 
 int mocha_forward(mocha_ctx* c, const float* src_X, const float* cha_X, int B, float* Y, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
+    NEED_PTRS(c, B, "mocha_forward", src_X, cha_X, Y);
     const size_t xs = (size_t)60 * c->cfg.V * c->cfg.C_in;
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         int r;
@@ -1723,6 +1735,7 @@ int mocha_set_pose_norm(mocha_ctx* c, const float* x_mean, const float* x_std, c
 int mocha_encode_raw(mocha_ctx* c, const float* X_raw, int B, float* encoded, float* cnt, const float* cnt_mean,
                      const float* cnt_std, float* cnt_nm, void* stream) {
     int rc = ready(c, B); if (rc) return rc;
+    NEED_PTRS(c, B, "mocha_encode_raw", X_raw, encoded);
     const size_t xs = (size_t)60 * (c->cfg.V + 1) * c->cfg.C_in, ts = 90 * 256;
     if (cnt_nm && (!cnt_mean || !cnt_std)) return fail(c, MOCHA_ERR_ARG, "mocha_encode_raw: cnt_nm needs cnt_mean and cnt_std");
     const bool zn = cnt_nm != nullptr;

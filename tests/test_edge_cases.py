@@ -286,3 +286,30 @@ def test_few_query_scan_through_the_bf16_copy_is_the_fp32_search(model):
     d, i = ContextBank(model, torch.from_numpy(rnd).cuda(), torch.from_numpy(rnd).cuda().view(N, 90, 256)).query(bad)
     i = i[:, 0].cpu().tolist()
     assert i[0] == 0 and i[2] == 2 and 0 <= i[1] < N and not np.isfinite(d[1, 0].item())
+
+
+def test_null_pointers_come_back_as_error_codes(model):
+    """A NULL where a device pointer is required is an argument error of the C ABI (status + message), not a GPU fault that takes
+    the host process down; with an empty batch the pointers may be NULL.  Called below the Python mirror, straight at the ABI."""
+    from mocha_sigasia2023_amd.generator import _ptr, _stream
+    x = torch.zeros((2, 60, model.V, 15), device="cuda:0")
+    tok = torch.zeros((2, 90, 256), device="cuda:0")
+    ctx = model._ctx
+    cases = [("mocha_embed", (_ptr(None), 2, _ptr(tok), 1, _stream())), ("mocha_embed", (_ptr(x), 2, _ptr(None), 1, _stream())),
+             ("mocha_encoder", (_ptr(tok), 2, _ptr(None), _stream())), ("mocha_decoder", (_ptr(tok), _ptr(None), 2, _ptr(tok), _stream())),
+             ("mocha_to_mot", (_ptr(None), 2, _ptr(x), _stream())), ("mocha_forward", (_ptr(x), _ptr(x), 2, _ptr(None), _stream())),
+             ("mocha_encode", (_ptr(x), 2, _ptr(None), _ptr(None), _ptr(None), _ptr(None), _ptr(None), _stream()))]
+    for name, args in cases:
+        with pytest.raises(RuntimeError, match="null argument"):
+            ctx.call(name, *args)
+    ctx.call("mocha_encoder", _ptr(None), 0, _ptr(None), _stream())              # empty batch: nothing is touched
+    ctx.call("mocha_forward", _ptr(None), _ptr(None), 0, _ptr(None), _stream())
+    # cnt is optional in mocha_encode: the z-scored copy alone (a bank build needs nothing else); it equals the one written beside cnt
+    X = torch.from_numpy(synthetic.pose_windows(3, 4, model.V)).cuda()
+    mean, std = (torch.from_numpy(a).cuda() for a in synthetic.cnt_norm(3))
+    enc, nm = torch.empty((4, 90, 256), device="cuda:0"), torch.empty((4, 90, 256), device="cuda:0")
+    ctx.call("mocha_encode", _ptr(X), 4, _ptr(enc), _ptr(None), _ptr(mean), _ptr(std), _ptr(nm), _stream())
+    e2, _, nm2 = model.encode(X, mean, std)
+    assert torch.equal(enc, e2) and torch.equal(nm, nm2)
+    with pytest.raises(RuntimeError, match="needs cnt_mean"):
+        ctx.call("mocha_encode", _ptr(X), 4, _ptr(enc), _ptr(None), _ptr(None), _ptr(None), _ptr(nm), _stream())
