@@ -37,7 +37,7 @@ template <int Q, bool BF16>
 __global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict__ bank,
                                                           const float* __restrict__ query, int nq, long long N, int D,
                                                           unsigned long long* __restrict__ partial /*[Q8][gridDim.x] or [Q8][N]*/,
-                                                          int all_keys) {
+                                                          int all_keys, unsigned long long* __restrict__ wgmin = nullptr /*all_keys: [Q8][gridDim.x] too*/) {
     constexpr int MS_CHUNK = BF16 ? MS_CHUNK_BF16 : MS_CHUNK_F32;
     __shared__ __attribute__((aligned(16))) float qs[Q * MS_CHUNK];
     __shared__ unsigned long long wbest[MS_WAVES][Q];
@@ -147,12 +147,12 @@ __global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict
         if (lane == 0) wbest[wave][q] = kmin;
     }
     __syncthreads();
-    if (all_keys) return;
+    if (all_keys && !wgmin) return;
     if (tid < Q) {
         unsigned long long k = wbest[0][tid];
 #pragma unroll
         for (int w = 1; w < MS_WAVES; ++w) k = wbest[w][tid] < k ? wbest[w][tid] : k;
-        partial[(size_t)tid * gridDim.x + blockIdx.x] = k;
+        (all_keys ? wgmin : partial)[(size_t)tid * gridDim.x + blockIdx.x] = k;
     }
 }
 
@@ -292,8 +292,9 @@ hipError_t launch_match_topk(const void* bank, int bank_bf16, const float* query
 // identical rows makes every row a candidate (index windows of RF_CAP rows, all evaluated).
 // RF_SPLIT 1024-thread workgroups per query, each re-ranking the candidates of its slice of the rows (a bank whose rows crowd within
 // the copy's rounding of the best one - hundreds of candidates - is spread over the chip); the workgroup that finishes last picks the
-// smallest (distance, row) key.  A row's terms are summed by a number of waves fixed per query (from the candidate count over ALL
-// rows), so identical rows get identical distances whatever else is in the list and however the slices fall.
+// smallest (distance, row) key.  The coarse minimum comes from the scan's per-workgroup minima (the scan writes them beside the keys), so
+// a workgroup reads its own sixteenth of the keys only.  A row's terms are summed in 16 fixed segments, one per wave, added in segment
+// order: identical rows get identical distances whatever else is in the list and however the slices fall.
 // ---------------------------------------------------------------------------------------------------------------------
 static constexpr int RF_T = 1024, RF_W = RF_T / 64, RF_CAP = 4096, RF_SPLIT = 16;
 
@@ -330,7 +331,8 @@ __device__ __forceinline__ float key_value(unsigned long long k) {
 }
 
 __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long long* __restrict__ keys /*[Q][N]: coarse d16^2 keys*/,
-                                                           const float* __restrict__ rho, const float* __restrict__ bank /*fp32 rows*/,
+                                                           const unsigned long long* __restrict__ wgmin /*[Q][nwg]: the scan's per-workgroup minima*/,
+                                                           int nwg, const float* __restrict__ rho, const float* __restrict__ bank /*fp32 rows*/,
                                                            const float* __restrict__ query /*fp32, uncentred*/, long long N, int D,
                                                            int32_t* __restrict__ idx, float* __restrict__ dist,
                                                            unsigned long long* __restrict__ part /*[Q][RF_SPLIT]*/, unsigned* __restrict__ ticket /*[Q]*/) {
@@ -338,20 +340,34 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
     __shared__ unsigned long long rk[RF_W];
     __shared__ unsigned long long r_key;
     __shared__ int cand[RF_CAP];
-    __shared__ int ncand, ntotal;
-    __shared__ float dsum[RF_W];
+    __shared__ int ncand;
+    __shared__ float dsum[2][RF_W];
     __shared__ unsigned long long best;
     __shared__ int is_last;
     const int q = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { ncand = 0; ntotal = 0; best = ~0ull; }
-    // the query row goes global -> LDS while the keys are read (LDS-DMA, 1 KB per wave instruction)
+    if (tid == 0) { ncand = 0; best = ~0ull; }
+    // the query row goes global -> LDS while the minima are read (LDS-DMA, 1 KB per wave instruction)
     const size_t qo = (size_t)q * D;
     for (int pi = wave; pi * 256 < D; pi += RF_W)
         __builtin_amdgcn_global_load_lds(query + qo + pi * 256 + lane * 4, (__attribute__((address_space(3))) void*)(rf_q + pi * 256), 16, 0, 0);
-    // ---- 1. the coarse minimum
+    // this workgroup's slice of the rows; up to RF_KPT keys and residual bounds per thread are fetched NOW, beside the minima
     const unsigned long long* kq = keys + (size_t)q * N;
+    const long long per_slice = (N + RF_SPLIT - 1) / RF_SPLIT;
+    const long long lo = (long long)sl * per_slice, hi_row = lo + per_slice < N ? lo + per_slice : N;
+    constexpr int RF_KPT = 2;
+    const bool in_regs = per_slice <= (long long)RF_KPT * RF_T;
+    unsigned long long kreg[RF_KPT]; float rreg[RF_KPT];
+#pragma unroll
+    for (int u = 0; u < RF_KPT; ++u) {
+        const long long n = lo + tid + (long long)u * RF_T;
+        const bool ok = in_regs && n < hi_row;
+        kreg[u] = ok ? kq[n] : ~0ull;
+        rreg[u] = ok ? rho[n] : 0.f;
+    }
+    // ---- 1. the coarse minimum, from the scan's per-workgroup minima
+    const unsigned long long* wq = wgmin + (size_t)q * nwg;
     unsigned long long key = ~0ull;
-    for (long long n = tid; n < N; n += RF_T) { const unsigned long long k = kq[n]; key = k < key ? k : key; }
+    for (int i = tid; i < nwg; i += RF_T) { const unsigned long long k = wq[i]; key = k < key ? k : key; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long k2 = __shfl_xor(key, o); key = k2 < key ? k2 : key; }
     if (lane == 0) rk[wave] = key;
@@ -366,71 +382,76 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
     const unsigned nmin = (unsigned)(r_key & 0xffffffffull);
     const float d16min = sqrtf(fmaxf(key_value(r_key), 0.f));
     const float hi = d16min + rho[nmin] + 2e-5f * d16min;              // upper bound of the coarse minimum's exact distance
-    auto qualifies = [&](long long n) -> bool {
+    auto qualifies = [&](long long n, unsigned long long k, float r) -> bool {
         if ((unsigned)n == nmin) return true;
-        const float d = sqrtf(fmaxf(key_value(kq[n]), 0.f));
-        return d - rho[n] - 2e-5f * d <= hi;                           // NaN distances never qualify
+        const float d = sqrtf(fmaxf(key_value(k), 0.f));
+        return d - r - 2e-5f * d <= hi;                                // NaN distances never qualify
     };
-    // ---- 2. how many candidates in all: fixes the number of waves that share a row (one summation order per query)
-    int mine = 0;
-    for (long long n = tid; n < N; n += RF_T) mine += qualifies(n) ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
-    if (lane == 0 && mine) atomicAdd(&ntotal, mine);
-    __syncthreads();
-    const int total = ntotal;
-    int wpc = RF_W;
-    while (wpc > 1 && wpc * (total < RF_W ? total : RF_W) > RF_W) wpc >>= 1;
-    const int per = RF_W / wpc;
-    // ---- 3. this workgroup's slice of the rows, in index windows of RF_CAP: list, then exact distances in passes of `per` candidates
-    const long long per_slice = (N + RF_SPLIT - 1) / RF_SPLIT;
-    const long long lo = (long long)sl * per_slice, hi_row = lo + per_slice < N ? lo + per_slice : N;
+    // ---- 2. index windows of RF_CAP rows of the slice: list, then exact distances.  EVERY wave takes part in EVERY row: the row's
+    // D / 4 pieces are cut into RF_W fixed segments, wave w sums segment w (lanes stride it, then a wave reduction) and the RF_W segment
+    // sums are added in segment order - the result does not depend on how many rows are in the list, in this slice or in any other,
+    // so identical rows get identical distances wherever they sit (ties then go to the lowest row).  Two rows are in flight per wave.
+    const int seg = (D / 4) / RF_W;                                     // pieces per segment (D % 256 == 0: a whole number)
+    const f32x4* qseg = reinterpret_cast<const f32x4*>(rf_q) + wave * seg;
     for (long long w0 = lo; w0 < hi_row; w0 += RF_CAP) {
         __syncthreads();
         if (tid == 0) ncand = 0;
         __syncthreads();
-        for (long long n = w0 + tid; n < w0 + RF_CAP && n < hi_row; n += RF_T)
-            if (qualifies(n)) cand[atomicAdd(&ncand, 1)] = (int)n;
+        if (in_regs) {
+#pragma unroll
+            for (int u = 0; u < RF_KPT; ++u) {
+                const long long n = lo + tid + (long long)u * RF_T;
+                if (n >= w0 && n < w0 + RF_CAP && n < hi_row && qualifies(n, kreg[u], rreg[u])) cand[atomicAdd(&ncand, 1)] = (int)n;
+            }
+        } else {
+            for (long long n = w0 + tid; n < w0 + RF_CAP && n < hi_row; n += RF_T)
+                if (qualifies(n, kq[n], rho[n])) cand[atomicAdd(&ncand, 1)] = (int)n;
+        }
         __syncthreads();
         const int nc = ncand;
-        for (int p0 = 0; p0 < nc; p0 += per) {
-            const int nb = nc - p0 < per ? nc - p0 : per;
-            const int ci = wave / wpc, sub = wave % wpc;
-            float a = 0.f;
-            int row = 0;
-            if (ci < nb) {                                             // uniform per wave
-                row = cand[p0 + ci];
-                const int lanes = wpc * 64, l = sub * 64 + lane;
-                const f32x4* b = reinterpret_cast<const f32x4*>(bank + (size_t)row * D);
-                const int np = D / 4;
-                constexpr int NB = 12;
-                for (int it0 = 0; it0 * lanes < np; it0 += NB) {
-                    f32x4 wv_[NB];
+        for (int p0 = 0; p0 < nc; p0 += 2) {
+            const int nb = nc - p0 < 2 ? nc - p0 : 2;
+            constexpr int NL = 6;                                       // 16-byte loads per lane and row: covers segments of up to 384 pieces
+            f32x4 wv_[2][NL];
 #pragma unroll
-                    for (int u = 0; u < NB; ++u) {
-                        int pc = (it0 + u) * lanes + l;
-                        pc = pc < np ? pc : np - 1;
-                        wv_[u] = __builtin_nontemporal_load(b + pc);
+            for (int c = 0; c < 2; ++c) {
+                const int row = cand[p0 + (c < nb ? c : 0)];
+                const f32x4* b = reinterpret_cast<const f32x4*>(bank + (size_t)row * D) + wave * seg;
+#pragma unroll
+                for (int u = 0; u < NL; ++u) {
+                    int pc = u * 64 + lane;
+                    pc = pc < seg ? pc : seg - 1;
+                    wv_[c][u] = __builtin_nontemporal_load(b + pc);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int u = 0; u < NL; ++u) {
+                    const int pc = u * 64 + lane;
+                    if (pc < seg) {
+                        const f32x4 d = qseg[pc] - wv_[c][u];
+                        a = fmaf(d[0], d[0], a); a = fmaf(d[1], d[1], a); a = fmaf(d[2], d[2], a); a = fmaf(d[3], d[3], a);
                     }
-#pragma unroll
-                    for (int u = 0; u < NB; ++u) {
-                        const int pc = (it0 + u) * lanes + l;
-                        if (pc < np) {
-                            const f32x4 d = *reinterpret_cast<const f32x4*>(rf_q + pc * 4) - wv_[u];
-                            a = fmaf(d[0], d[0], a); a = fmaf(d[1], d[1], a); a = fmaf(d[2], d[2], a); a = fmaf(d[3], d[3], a);
-                        }
+                }
+                for (int pc0 = NL * 64; pc0 < seg; pc0 += 64) {         // longer rows (not the path's D): the rest of the segment
+                    const int pc = pc0 + lane;
+                    if (pc < seg && c < nb) {
+                        const f32x4 d = qseg[pc] - reinterpret_cast<const f32x4*>(bank + (size_t)cand[p0 + c] * D)[wave * seg + pc];
+                        a = fmaf(d[0], d[0], a); a = fmaf(d[1], d[1], a); a = fmaf(d[2], d[2], a); a = fmaf(d[3], d[3], a);
                     }
                 }
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+                if (lane == 0) dsum[c][wave] = a;
             }
-            if (lane == 0) dsum[wave] = a;
             __syncthreads();
             if (tid == 0) {
                 unsigned long long bk = best;
                 for (int c = 0; c < nb; ++c) {
                     float d2 = 0.f;
-                    for (int sw = 0; sw < wpc; ++sw) d2 += dsum[c * wpc + sw];
+                    for (int sw = 0; sw < RF_W; ++sw) d2 += dsum[c][sw];
                     // distances are >= 0 (or NaN, which sorts last): the plain bit pattern orders them
                     const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)cand[p0 + c];
                     bk = (bk == ~0ull) || k < bk ? k : bk;
@@ -440,7 +461,7 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
             __syncthreads();
         }
     }
-    // ---- 4. the slices' winners: each workgroup publishes its own, the one that arrives last picks the smallest (distance, row) key.
+    // ---- 3. the slices' winners: each workgroup publishes its own, the one that arrives last picks the smallest (distance, row) key.
     // The ticket counts arrivals and is never reset (RF_SPLIT divides 2^32; calls that share a scratch buffer are ordered by their stream).
     __syncthreads();
     if (tid == 0) {
@@ -465,7 +486,8 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
 // words of scratch launch_match_scan16 needs for a bank of N rows: the slices' winners and the arrival tickets (the head: must be
 // ZERO when the buffer is first used), then 8 queries' keys
 size_t match_scan16_scratch_head_words() { return 8 * RF_SPLIT + 8; }
-size_t match_scan16_scratch_words(int64_t N) { return match_scan16_scratch_head_words() + (size_t)8 * N; }
+static size_t scan_nwg(int64_t N) { const int r = MS_WAVES * MS_ROWS_PER_WAVE; return (size_t)((N + r - 1) / r); }
+size_t match_scan16_scratch_words(int64_t N) { return match_scan16_scratch_head_words() + (size_t)8 * N + (size_t)8 * scan_nwg(N); }
 
 hipError_t match_refine_init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_refine), hipFuncAttributeMaxDynamicSharedMemorySize, 23040 * 4);
@@ -476,22 +498,23 @@ hipError_t match_refine_init() {
 hipError_t launch_match_scan16(const void* bank16, const float* rho, const float* bank, const float* qc, const float* query, int Q, int64_t N,
                                int D, unsigned long long* scratch, int32_t* idx, float* dist, hipStream_t s) {
     if (Q <= 0) return hipSuccess;
-    // scratch: [slice winners 8 x RF_SPLIT][arrival tickets 8][coarse keys 8 x N] - the head at a fixed place whatever N
+    // scratch: [slice winners 8 x RF_SPLIT][arrival tickets 8][coarse keys 8 x N][the scan workgroups' minima 8 x N / 16] - the head at a fixed place whatever N
     unsigned long long* part = scratch;
     unsigned long long* keys = scratch + match_scan16_scratch_head_words();
+    unsigned long long* wgmin = keys + (size_t)8 * N;          // [8][workgroups of the scan]
     if (D % MS_CHUNK_BF16 != 0 || D % 256 || D > 23040 || N < 1 || N > 0x7ffffff0ll) return hipErrorInvalidValue;
     const int rows_per_wg = MS_WAVES * MS_ROWS_PER_WAVE;
     const unsigned grid = (unsigned)((N + rows_per_wg - 1) / rows_per_wg);
     for (int q0 = 0; q0 < Q; q0 += 8) {
         const int nq = (Q - q0) < 8 ? (Q - q0) : 8;
         const float* qp = qc + (size_t)q0 * D;
-#define MS16_LAUNCH(QQ) hipLaunchKernelGGL((mocha_match_stream<QQ, true>), dim3(grid), dim3(256), 0, s, bank16, qp, nq, (long long)N, D, keys, 1)
+#define MS16_LAUNCH(QQ) hipLaunchKernelGGL((mocha_match_stream<QQ, true>), dim3(grid), dim3(256), 0, s, bank16, qp, nq, (long long)N, D, keys, 1, wgmin)
         if (nq == 1) MS16_LAUNCH(1);
         else if (nq == 2) MS16_LAUNCH(2);
         else if (nq <= 4) MS16_LAUNCH(4);
         else MS16_LAUNCH(8);
 #undef MS16_LAUNCH
-        hipLaunchKernelGGL(mocha_match_refine, dim3(nq, RF_SPLIT), dim3(RF_T), (size_t)D * sizeof(float), s, keys, rho, bank, query + (size_t)q0 * D,
+        hipLaunchKernelGGL(mocha_match_refine, dim3(nq, RF_SPLIT), dim3(RF_T), (size_t)D * sizeof(float), s, keys, wgmin, (int)grid, rho, bank, query + (size_t)q0 * D,
                            (long long)N, D, idx + q0, dist ? dist + q0 : nullptr, part, reinterpret_cast<unsigned*>(part + 8 * RF_SPLIT));
     }
     return hipGetLastError();
