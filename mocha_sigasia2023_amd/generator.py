@@ -502,10 +502,18 @@ class StreamingCharacterizer:
             self.model._ctx.call("mocha_characterize", _ptr(self.x), 1, _ptr(self.mean), _ptr(self.std), _ptr(self.y),
                                  _ptr(self.idx), _stream())
 
-    def step(self, window: torch.Tensor):
+    @property
+    def input(self) -> torch.Tensor:
+        """The captured step's own input window (1, 60, V, 15): a producer that writes the next window straight into it - the
+        featurisation kernel, a sensor copy - and then calls ``step()`` without an argument saves the device-to-device copy
+        (one 4 µs kernel of the 0.41 ms step)."""
+        return self.x
+
+    def step(self, window: Optional[torch.Tensor] = None):
         """window (60, V, 15) or (1, 60, V, 15) on the GPU -> (Y (60, V, 15) view, idx tensor view); both
-        are overwritten by the next step."""
-        self.x.copy_(window.reshape(self.x.shape), non_blocking=True)
+        are overwritten by the next step.  Without an argument the window already in ``self.input`` is characterized."""
+        if window is not None:
+            self.x.copy_(window.reshape(self.x.shape), non_blocking=True)
         self._enqueue()
         return self.y[0], self.idx
 

@@ -362,6 +362,11 @@ def test_streaming_graph_replay_matches_batched():
             y, idx = sc.step(src[i])
             assert int(idx.item()) == int(io[i])
             assert absmax(y, Yo[i].numpy()) < TOL
+            # the zero-copy form: the producer writes the window into the step's own input, step() takes no argument
+            y1 = y.clone()
+            sc.input.zero_(); sc.input.copy_(src[i][None])
+            y2, idx2 = sc.step()
+            assert torch.equal(y2, y1) and int(idx2.item()) == int(io[i])
 
 
 def test_fused_pose_normalisation():
