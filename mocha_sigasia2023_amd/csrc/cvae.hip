@@ -59,27 +59,39 @@ hipError_t launch_cvae_prior_tokens(const float* c, const float* mu_tok, const f
 
 // z = mu (+ eps * exp(0.5 logvar)), mu = x[:,0], logvar = x[:,1]  (model_CVAE.py:77-87);
 // memory = [z, c] (:160); queries = pe[:nq] (zeros + positional encoding, :161-162)
+// One wave per output row, 16 bytes per lane: row 0 of a clip is z, rows 1..nc its condition tokens, the next nq rows the queries
+// (a first version walked all 271 rows in ONE workgroup per clip with 4-byte accesses: 35 us per frame of the CVAE branch for one clip).
 __global__ __launch_bounds__(256) void mocha_cvae_latent(const float* __restrict__ x, int ntok, const float* __restrict__ eps,
                                                          const float* __restrict__ c, int nc, const float* __restrict__ pe, int nq,
                                                          float* __restrict__ mem, float* __restrict__ qout, float* __restrict__ mu_out,
-                                                         float* __restrict__ lv_out) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float mu = x[((size_t)b * ntok) * 256 + tid], lv = x[((size_t)b * ntok + 1) * 256 + tid];
-    float z = mu;
-    if (eps) z = mu + eps[(size_t)b * 256 + tid] * expf(0.5f * lv);
-    if (mu_out) mu_out[(size_t)b * 256 + tid] = mu;
-    if (lv_out) lv_out[(size_t)b * 256 + tid] = lv;
-    float* mb = mem + (size_t)b * (nc + 1) * 256;
-    mb[tid] = z;
-    for (int i = 0; i < nc; ++i) mb[(size_t)(i + 1) * 256 + tid] = c[((size_t)b * nc + i) * 256 + tid];
-    float* qb = qout + (size_t)b * nq * 256;
-    for (int i = 0; i < nq; ++i) qb[(size_t)i * 256 + tid] = pe[(size_t)i * 256 + tid];
+                                                         float* __restrict__ lv_out, int rows_per_clip /*1 + nc + nq*/, int rows /*B * rows_per_clip*/) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), q = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int b = row / rows_per_clip, r = row - b * rows_per_clip;
+    if (r == 0) {
+        const f32x4 mu = reinterpret_cast<const f32x4*>(x)[((size_t)b * ntok) * 64 + q], lv = reinterpret_cast<const f32x4*>(x)[((size_t)b * ntok + 1) * 64 + q];
+        f32x4 z = mu;
+        if (eps) {
+            const f32x4 e = reinterpret_cast<const f32x4*>(eps)[(size_t)b * 64 + q];
+            z[0] = mu[0] + e[0] * expf(0.5f * lv[0]); z[1] = mu[1] + e[1] * expf(0.5f * lv[1]);
+            z[2] = mu[2] + e[2] * expf(0.5f * lv[2]); z[3] = mu[3] + e[3] * expf(0.5f * lv[3]);
+        }
+        if (mu_out) reinterpret_cast<f32x4*>(mu_out)[(size_t)b * 64 + q] = mu;
+        if (lv_out) reinterpret_cast<f32x4*>(lv_out)[(size_t)b * 64 + q] = lv;
+        reinterpret_cast<f32x4*>(mem)[((size_t)b * (nc + 1)) * 64 + q] = z;
+    } else if (r <= nc) {
+        reinterpret_cast<f32x4*>(mem)[((size_t)b * (nc + 1) + r) * 64 + q] = reinterpret_cast<const f32x4*>(c)[((size_t)b * nc + (r - 1)) * 64 + q];
+    } else {
+        const int i = r - 1 - nc;
+        reinterpret_cast<f32x4*>(qout)[((size_t)b * nq + i) * 64 + q] = reinterpret_cast<const f32x4*>(pe)[(size_t)i * 64 + q];
+    }
 }
 
 hipError_t launch_cvae_latent(const float* x, int ntok, const float* eps, const float* c, int nc, const float* pe, int nq, float* mem,
                               float* q, float* mu_out, float* logvar_out, int B, hipStream_t s) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mocha_cvae_latent, dim3(B), dim3(256), 0, s, x, ntok, eps, c, nc, pe, nq, mem, q, mu_out, logvar_out);
+    const int rpc = 1 + nc + nq, rows = B * rpc;
+    hipLaunchKernelGGL(mocha_cvae_latent, dim3((rows + 3) / 4), dim3(256), 0, s, x, ntok, eps, c, nc, pe, nq, mem, q, mu_out, logvar_out, rpc, rows);
     return hipGetLastError();
 }
 
