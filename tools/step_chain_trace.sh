@@ -10,8 +10,9 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 from mocha_sigasia2023_amd import Generator, synthetic, synthetic_state_dict
 dev = torch.device("cuda:0")
 model = Generator(layout="mixamo", device=dev).load_state_dict(synthetic_state_dict(1777, 1.0, "mixamo")).eval()
-src = torch.from_numpy(synthetic.pose_windows(1777, 585, 22)).to(dev)
-cha = torch.from_numpy(synthetic.pose_windows(4242, 585, 22)).to(dev)
+W = int(os.environ.get("MOCHA_TRACE_WINDOWS", "585"))      # windows per clip
+src = torch.from_numpy(synthetic.pose_windows(1777, W, 22)).to(dev)
+cha = torch.from_numpy(synthetic.pose_windows(4242, W, 22)).to(dev)
 mean, std = (torch.from_numpy(a).to(dev) for a in synthetic.cnt_norm(7))      # device tensors: numpy statistics would be copied (and the
                                                                               # device drained) on every call
 for _ in range(24): model.characterize_pair(src, cha, mean, std)
