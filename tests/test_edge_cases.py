@@ -313,3 +313,36 @@ def test_null_pointers_come_back_as_error_codes(model):
     assert torch.equal(enc, e2) and torch.equal(nm, nm2)
     with pytest.raises(RuntimeError, match="needs cnt_mean"):
         ctx.call("mocha_encode", _ptr(X), 4, _ptr(enc), _ptr(None), _ptr(None), _ptr(None), _ptr(nm), _stream())
+
+
+@pytest.mark.parametrize("N", [4096, 4097, 20011, 40000, 70001])
+def test_bf16_copy_scan_at_odd_bank_sizes(model, N):
+    """The re-rank's branches by bank size: a slice's keys held in registers (up to 2 048 rows per slice: N <= 32 768) or re-read
+    (beyond), one index window per slice or several (more than 4 096 rows per slice: N > 65 536), row counts that are not a
+    multiple of the scan's 16 rows per workgroup or of the 16 slices, the winner in the first / last row and in the last slice's
+    ragged end, and near-duplicates of the winner spread over the slices.  Against the fp32 scan and a float64 search."""
+    from mocha_sigasia2023_amd import ContextBank
+    D = 90 * 256
+    g = torch.Generator(device="cuda:0"); g.manual_seed(N)
+    bank = torch.randn((N, D), device="cuda:0", generator=g)
+    pick = torch.tensor([0, N - 1, N // 2, N - 3, 17, (N * 15) // 16 + 1, N // 16, 4095], device="cuda:0")
+    q = bank[pick] + 0.05 * torch.randn((8, D), device="cuda:0", generator=g)
+    # near-duplicates of query 2's winner in other slices: farther by 1e-3 of the distance - candidates the bound cannot exclude
+    for j in range(1, 16, 3):
+        r = (N // 2 + j * (N // 16)) % N
+        if r not in pick.tolist():
+            bank[r] = q[2] + 1.001 * (bank[N // 2] - q[2])
+    ri, rd = _torch_bruteforce(q, bank)
+    assert torch.equal(ri, pick.long())
+    model.set_option("scan16", 1)
+    b1 = ContextBank(model, bank, bank.view(N, 90, 256))
+    d1, i1 = b1.query(q)
+    for Q in (1, 3):
+        dq, iq = b1.query(q[:Q])
+        assert torch.equal(iq, i1[:Q]) and torch.equal(dq, d1[:Q])
+    del b1
+    model.set_option("scan16", 0)
+    d0, i0 = ContextBank(model, bank, bank.view(N, 90, 256)).query(q)
+    model.set_option("scan16", 1)
+    assert torch.equal(i1[:, 0].long(), ri) and torch.equal(i0[:, 0].long(), ri)
+    assert torch.allclose(d1, d0, rtol=1e-5) and torch.allclose(d1[:, 0].double(), rd, rtol=1e-5)
