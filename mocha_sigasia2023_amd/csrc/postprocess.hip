@@ -264,25 +264,45 @@ __global__ __launch_bounds__(64) void mocha_post_clip(PostParams p) {
             stq(ikr + chain[2] * 4, qmul(qinv(gr[3]), qmul(r1, gr[2])));
         }
 
-        if (BP && BE) {
-            // fold the synthetic root into bone 1 (:677-681) and convert to Euler angles in degrees (quat.py:346-355)
-            for (int j = 1; j < J; ++j) {
-                d3 pj = ld3(pos + j * 3);
-                dq q = ldq(ikr + j * 4);
-                if (j == 1) { pj = qrot(root_rot, pj) + root_pos; q = qmul(root_rot, q); }
-                st3(BP + ((size_t)i * V + (j - 1)) * 3, pj);
-                const double r2d = 57.29577951308232;
-                d3 eu = {atan2(2 * (q.w * q.x + q.y * q.z), 1 - 2 * (q.x * q.x + q.y * q.y)), asin(clamp1(2 * (q.w * q.y - q.z * q.x))),
-                         atan2(2 * (q.w * q.z + q.x * q.y), 1 - 2 * (q.y * q.y + q.z * q.z))};
-                st3(BE + ((size_t)i * V + (j - 1)) * 3, eu * r2d);
-            }
-        }
+        // the BVH channels of this frame are made by mocha_post_bvh, in parallel over frames and bones, once the loop is through: it
+        // needs the frame's running root, which is not otherwise kept (POS[i][0] is the BLENDED root): parked in bone 1's position slot
+        if (BP && BE) st3(BP + (size_t)i * V * 3, root_pos);
     }
+}
+
+// BVH channels (test_fullframework.py:677-681; quat.py:346-355): fold the synthetic root into bone 1, Euler angles in degrees.  No
+// dependence between frames or bones - 3 float64 inverse trigonometric functions per bone, which the frame loop above used to
+// evaluate one after the other in its single lane (72 per frame: most of its 46 us per frame for one clip).
+__global__ __launch_bounds__(256) void mocha_post_bvh(PostParams p) {
+    const int V = p.V, J = V + 1, N = p.n_frames;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)p.n_clips * N * V) return;
+    const int j = (int)(t % V) + 1;
+    const long long ci = t / V;                     // clip * N + frame
+    const double* pos = p.pos + (size_t)ci * J * 3;
+    const double* ikr = p.ik_rot + (size_t)ci * J * 4;
+    double* bp = p.bvh_pos + ((size_t)ci * V + (j - 1)) * 3;
+    d3 pj = ld3(pos + j * 3);
+    dq q = ldq(ikr + j * 4);
+    if (j == 1) {
+        const d3 root_pos = ld3(bp);                // parked by the frame loop
+        const dq root_rot = ldq(p.rot + (size_t)ci * J * 4);       // ROT[frame][0]: the running root rotation (rotations are not blended)
+        pj = qrot(root_rot, pj) + root_pos; q = qmul(root_rot, q);
+    }
+    st3(bp, pj);
+    const double r2d = 57.29577951308232;
+    d3 eu = {atan2(2 * (q.w * q.x + q.y * q.z), 1 - 2 * (q.x * q.x + q.y * q.y)), asin(clamp1(2 * (q.w * q.y - q.z * q.x))),
+             atan2(2 * (q.w * q.z + q.x * q.y), 1 - 2 * (q.y * q.y + q.z * q.z))};
+    st3(p.bvh_euler + ((size_t)ci * V + (j - 1)) * 3, eu * r2d);
 }
 
 hipError_t launch_post_clip(const PostParams& p, hipStream_t s) {
     if (p.n_clips <= 0 || p.n_frames <= 0) return hipSuccess;
     hipLaunchKernelGGL(mocha_post_clip, dim3((p.n_clips + 63) / 64), dim3(64), 0, s, p);
+    if (p.bvh_pos && p.bvh_euler) {
+        const long long n = (long long)p.n_clips * p.n_frames * p.V;
+        hipLaunchKernelGGL(mocha_post_bvh, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
+    }
     return hipGetLastError();
 }
 
