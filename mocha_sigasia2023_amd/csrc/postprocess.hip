@@ -114,9 +114,18 @@ struct ContactRec {
     d3 position, velocity, point, target, off_x, off_v;
 };
 
+// One WAVE per clip (round 3; the first version ran a clip in one lane, 64 clips per wave): the frame loop is sequential, but inside a
+// frame the work has width - lane j owns bone j (its blended position is a per-bone recurrence over frames, kept in a register), lane 0
+// also integrates the root, lane 32 + c runs contact c's state machine and two-bone IK - and everything a frame needs from memory (the
+// bone's 13 head values, the root's source velocities, the contact flags) is fetched one frame AHEAD, so the per-frame critical path is
+// the float64 arithmetic itself: root integration, then the chain and the IK of a contact, with one exchange through LDS between them.
+// Every value is computed by the same expressions in the same order as before (and as the oracle): results are unchanged.
 __global__ __launch_bounds__(64) void mocha_post_clip(PostParams p) {
-    const int clip = blockIdx.x * 64 + threadIdx.x;
-    if (clip >= p.n_clips) return;
+    __shared__ double sh_pos[MOCHA_MAX_BONES * 3], sh_rot[MOCHA_MAX_BONES * 4];
+    __shared__ double sh_w[6];                                   // wv, wa of the frame (the contact reset of frame 0 needs them)
+    __shared__ double sh_ikq[MOCHA_MAX_CONTACT][2][4];
+    __shared__ int sh_ikv[MOCHA_MAX_CONTACT];
+    const int clip = blockIdx.x, lane = threadIdx.x;
     const int V = p.V, J = V + 1, N = p.n_frames;
     const float* heads = p.heads + (size_t)clip * N * V * 13;
     const float* speed = p.speed + (size_t)clip * N;
@@ -127,58 +136,103 @@ __global__ __launch_bounds__(64) void mocha_post_clip(PostParams p) {
     double* POS = p.pos + (size_t)clip * N * J * 3;
     double* ROT = p.rot + (size_t)clip * N * J * 4;
     double* IKR = p.ik_rot + (size_t)clip * N * J * 4;
-    double* BP = p.bvh_pos ? p.bvh_pos + (size_t)clip * N * V * 3 : nullptr;
-    double* BE = p.bvh_euler ? p.bvh_euler + (size_t)clip * N * V * 3 : nullptr;
+    double* BP = (p.bvh_pos && p.bvh_euler) ? p.bvh_pos + (size_t)clip * N * V * 3 : nullptr;
     const double dt = p.dt;
     const double ydamp = (4.0 * 0.6931471805599453) / (p.halflife + 1e-5) / 2.0;             // Inertialization.py:13-14, 40
     const double eydt = 1.0 / (1.0 + ydamp * dt + 0.48 * (ydamp * dt) * (ydamp * dt) + 0.235 * (ydamp * dt) * (ydamp * dt) * (ydamp * dt));
 
-    ContactRec cr[MOCHA_MAX_CONTACT];
-    d3 root_pos = {0, 0, 0};
+    const bool is_joint = lane < J, is_bone = lane >= 1 && lane < J;
+    const int ci = lane - 32;
+    const bool is_contact = ci >= 0 && ci < p.n_contact;
+    // a contact lane's chain toe -> ... -> root (quat.py:241-273 recursion order, evaluated top-down), fixed for the clip
+    int chain[MOCHA_MAX_CHAIN], depth = 0;
+    if (is_contact)
+        for (int b = p.contact_bones[ci]; b != -1 && depth < MOCHA_MAX_CHAIN; b = p.parents[b]) chain[depth++] = b;
+    // which contacts write this bone's IK rotation (chain[3] the hip, chain[2] the knee), in contact order
+    int ik_slot[MOCHA_MAX_CONTACT];
+#pragma unroll
+    for (int c = 0; c < MOCHA_MAX_CONTACT; ++c) {
+        ik_slot[c] = -1;
+        if (c < p.n_contact && is_joint) {
+            int ch[MOCHA_MAX_CHAIN], d = 0;
+            for (int b = p.contact_bones[c]; b != -1 && d < MOCHA_MAX_CHAIN; b = p.parents[b]) ch[d++] = b;
+            if (d >= 5) { if (ch[3] == lane) ik_slot[c] = 0; else if (ch[2] == lane) ik_slot[c] = 1; }
+        }
+    }
+
+    // per-lane state
+    ContactRec cr;                                              // contact lanes
+    d3 root_pos = {0, 0, 0};                                    // lane 0
     dq root_rot = {1, 0, 0, 0};
+    d3 prev_p = {0, 0, 0};                                      // joint lanes: this bone's position in the previous frame
+    // inputs of the frame about to be processed, fetched one frame ahead
+    float hn[13];                                               // bone lanes
+    float r_speed = 0.f, r_sspeed = 1.f, r_rv[3] = {0, 0, 0}, r_ra[3] = {0, 0, 0};            // lane 0
+    unsigned char c_flag = 0;                                   // contact lanes
+    auto fetch = [&](int i) __attribute__((always_inline)) {
+        if (i >= N) return;
+        if (is_bone) {
+            const float* hj = heads + ((size_t)i * V + (lane - 1)) * 13;
+#pragma unroll
+            for (int k = 0; k < 13; ++k) hn[k] = hj[k];
+        }
+        if (lane == 0) {
+            r_speed = speed[i]; r_sspeed = sspeed[i];
+            r_rv[0] = rvel_s[i * 3]; r_rv[1] = rvel_s[i * 3 + 1]; r_rv[2] = rvel_s[i * 3 + 2];
+            r_ra[0] = rang_s[i * 3]; r_ra[1] = rang_s[i * 3 + 1]; r_ra[2] = rang_s[i * 3 + 2];
+        }
+        if (is_contact) c_flag = contact[(size_t)i * p.n_contact + ci];
+    };
+    fetch(0);
 
     for (int i = 0; i < N; ++i) {
-        const float* h = heads + (size_t)i * V * 13;
+        // this frame's inputs into locals, the next frame's on their way
+        float h[13];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) h[k] = hn[k];
+        const float f_speed = r_speed, f_sspeed = r_sspeed;
+        const float f_rv[3] = {r_rv[0], r_rv[1], r_rv[2]}, f_ra[3] = {r_ra[0], r_ra[1], r_ra[2]};
+        const bool in_state = c_flag != 0;
+        fetch(i + 1);
+
         double* pos = POS + (size_t)i * J * 3;
         double* rot = ROT + (size_t)i * J * 4;
         double* ikr = IKR + (size_t)i * J * 4;
-        // root-velocity ratio in float32, as NumPy computes it on float32 arrays (test_fullframework.py:492-496)
-        float ratio = speed[i] / sspeed[i];
-        if (ratio > 3.0f || ratio < 0.33f) ratio = 1.0f;
-        const d3 rv = {(double)(rvel_s[i * 3] * ratio), (double)(rvel_s[i * 3 + 1] * ratio), (double)(rvel_s[i * 3 + 2] * ratio)};
-        const d3 ra = {(double)rang_s[i * 3], (double)rang_s[i * 3 + 1], (double)rang_s[i * 3 + 2]};
-        const d3 wv = qrot(root_rot, rv), wa = qrot(root_rot, ra);                             // :499-502
-        const d3 new_root_pos = root_pos + wv * dt;
-        const dq new_root_rot = qmul(root_rot, from_scaled_angle_axis(wa * dt));
-        // positions (blended with the previous frame's after the first one, :537/:627), rotations
-        const double* prev = i ? POS + (size_t)(i - 1) * J * 3 : nullptr;
-        for (int j = 0; j < J; ++j) {
-            d3 pj, vj;
-            dq rj;
-            if (j == 0) { pj = new_root_pos; vj = wv; rj = new_root_rot; }
-            else {
-                const float* hj = h + (size_t)(j - 1) * 13;
-                pj = {(double)hj[0], (double)hj[1], (double)hj[2]};
-                rj = {(double)hj[3], (double)hj[4], (double)hj[5], (double)hj[6]};
-                vj = {(double)hj[7], (double)hj[8], (double)hj[9]};
-            }
-            if (prev && p.blend_enabled) pj = (ld3(prev + j * 3) + vj * dt) * 0.5 + pj * 0.5;
-            st3(pos + j * 3, pj);
-            stq(rot + j * 4, rj);
-            stq(ikr + j * 4, rj);
+        d3 pj = {0, 0, 0}, vj = {0, 0, 0};
+        dq rj = {1, 0, 0, 0};
+        if (lane == 0) {
+            // root-velocity ratio in float32, as NumPy computes it on float32 arrays (test_fullframework.py:492-496)
+            float ratio = f_speed / f_sspeed;
+            if (ratio > 3.0f || ratio < 0.33f) ratio = 1.0f;
+            const d3 rv = {(double)(f_rv[0] * ratio), (double)(f_rv[1] * ratio), (double)(f_rv[2] * ratio)};
+            const d3 ra = {(double)f_ra[0], (double)f_ra[1], (double)f_ra[2]};
+            const d3 wv = qrot(root_rot, rv), wa = qrot(root_rot, ra);                         // :499-502
+            root_pos = root_pos + wv * dt;
+            root_rot = qmul(root_rot, from_scaled_angle_axis(wa * dt));
+            pj = root_pos; vj = wv; rj = root_rot;
+            st3(sh_w, wv); st3(sh_w + 3, wa);
+            if (BP) st3(BP + (size_t)i * V * 3, root_pos);          // for mocha_post_bvh: the running (unblended) root of this frame
+        } else if (is_bone) {
+            pj = {(double)h[0], (double)h[1], (double)h[2]};
+            rj = {(double)h[3], (double)h[4], (double)h[5], (double)h[6]};
+            vj = {(double)h[7], (double)h[8], (double)h[9]};
         }
-        root_pos = new_root_pos;
-        root_rot = new_root_rot;
+        if (is_joint) {
+            // positions (blended with the previous frame's after the first one, :537/:627), rotations
+            if (i && p.blend_enabled) pj = (prev_p + vj * dt) * 0.5 + pj * 0.5;
+            prev_p = pj;
+            st3(pos + lane * 3, pj);
+            stq(rot + lane * 4, rj);
+            st3(sh_pos + lane * 3, pj);
+            stq(sh_rot + lane * 4, rj);
+        }
+        if (lane < MOCHA_MAX_CONTACT) sh_ikv[lane] = 0;
+        __syncthreads();
 
-        for (int ci = 0; ci < p.n_contact; ++ci) {
-            const int toe = p.contact_bones[ci];
-            // chain toe -> ... -> root (quat.py:241-273 recursion order, evaluated top-down)
-            int chain[MOCHA_MAX_CHAIN], depth = 0;
-            for (int b = toe; b != -1 && depth < MOCHA_MAX_CHAIN; b = p.parents[b]) chain[depth++] = b;
-            d3 gp[MOCHA_MAX_CHAIN];
-            dq gr[MOCHA_MAX_CHAIN];
+        if (is_contact) {
             if (i == 0) {
                 // contact reset with the global position / velocity of the toe (fk_vel_bone, quat.py:207-238)
+                const d3 wv = ld3(sh_w), wa = ld3(sh_w + 3);
                 d3 gv = {0, 0, 0}, ga = {0, 0, 0}, gpp = {0, 0, 0};
                 dq grr = {1, 0, 0, 0};
                 for (int k = depth - 1; k >= 0; --k) {
@@ -186,12 +240,12 @@ __global__ __launch_bounds__(64) void mocha_post_clip(PostParams p) {
                     d3 lv, la;
                     if (b == 0) { lv = wv; la = wa; }
                     else {
-                        const float* hb = h + (size_t)(b - 1) * 13;
+                        const float* hb = heads + (size_t)(b - 1) * 13;                        // frame 0
                         lv = {(double)hb[7], (double)hb[8], (double)hb[9]};
                         la = {(double)hb[10], (double)hb[11], (double)hb[12]};
                     }
-                    const d3 lp = ld3(pos + b * 3);
-                    const dq lr = ldq(rot + b * 4);
+                    const d3 lp = ld3(sh_pos + b * 3);
+                    const dq lr = ldq(sh_rot + b * 4);
                     if (k == depth - 1) { gpp = lp; gv = lv; grr = lr; ga = la; }
                     else {
                         const d3 rp = qrot(grr, lp);
@@ -201,72 +255,78 @@ __global__ __launch_bounds__(64) void mocha_post_clip(PostParams p) {
                         grr = qmul(grr, lr);
                     }
                 }
-                ContactRec& c = cr[ci];
-                c.state = false; c.lock = false;
-                c.position = gpp; c.velocity = gv; c.point = gpp; c.target = gpp;
-                c.off_x = {0, 0, 0}; c.off_v = {0, 0, 0};
-                continue;
+                cr.state = false; cr.lock = false;
+                cr.position = gpp; cr.velocity = gv; cr.point = gpp; cr.target = gpp;
+                cr.off_x = {0, 0, 0}; cr.off_v = {0, 0, 0};
+            } else if (p.ik_enabled && depth >= 5) {
+                d3 gp[MOCHA_MAX_CHAIN];
+                dq gr[MOCHA_MAX_CHAIN];
+                for (int k = depth - 1; k >= 0; --k) {
+                    const int b = chain[k];
+                    const d3 lp = ld3(sh_pos + b * 3);
+                    const dq lr = ldq(sh_rot + b * 4);
+                    if (k == depth - 1) { gp[k] = lp; gr[k] = lr; }
+                    else { gp[k] = qrot(gr[k + 1], lp) + gp[k + 1]; gr[k] = qmul(gr[k + 1], lr); }
+                }
+                // chain[0] toe, [1] heel, [2] knee, [3] hip, [4] the hip's parent
+                ContactRec& c = cr;
+                const d3 in_pos = gp[0];
+                // Inertialization.py:300-377
+                const d3 in_vel = (in_pos - c.target) * (1.0 / (dt + 1e-8));
+                c.target = in_pos;
+                {
+                    const d3 j1 = c.off_v + c.off_x * ydamp;                                   // :39-54
+                    c.off_x = eydt * (c.off_x + j1 * dt);
+                    c.off_v = eydt * (c.off_v - j1 * (ydamp * dt));
+                }
+                if (c.lock) { c.position = c.point + c.off_x; c.velocity = c.off_v; }
+                else { c.position = in_pos + c.off_x; c.velocity = in_vel + c.off_v; }
+                const bool unlock = c.lock && len(c.point - in_pos) > p.unlock_radius;
+                if (!c.state && in_state) {
+                    c.lock = true;
+                    c.point = c.position;
+                    c.point.y = p.foot_height;
+                    c.off_x = (in_pos + c.off_x) - c.point;
+                    c.off_v = in_vel + c.off_v;
+                } else if ((c.lock && c.state && !in_state) || unlock) {
+                    c.lock = false;
+                    c.off_x = (c.point + c.off_x) - in_pos;
+                    c.off_v = c.off_v - in_vel;
+                }
+                c.state = in_state;
+                if (c.position.y < p.foot_height) c.position.y = p.foot_height;                // test_fullframework.py:581-582
+                // two-bone IK (quat.py:295-343): a hip, b knee, c heel
+                const d3 a = gp[3], b = gp[2], e = gp[1];
+                const d3 target = c.position + (gp[1] - gp[0]);
+                const d3 fwd = qrot(gr[2], d3{0.0, 1.0, 0.0});
+                const double max_ext = len(a - b) + len(b - e) - p.max_length_buffer;
+                d3 t = target;
+                if (len(target - a) > max_ext) t = a + max_ext * normalize(target - a);
+                const d3 axis_rot = normalize(cross(normalize(e - a), fwd));
+                const double lab = len(b - a), lcb = len(b - e), lat = len(t - a);
+                const double ac_ab_0 = acos(clamp1(dot(normalize(e - a), normalize(b - a))));
+                const double ba_bc_0 = acos(clamp1(dot(normalize(a - b), normalize(e - b))));
+                const double ac_ab_1 = acos(clamp1((lab * lab + lat * lat - lcb * lcb) / (2.0 * lab * lat)));
+                const double ba_bc_1 = acos(clamp1((lab * lab + lcb * lcb - lat * lat) / (2.0 * lab * lcb)));
+                const dq r0 = from_angle_axis(ac_ab_1 - ac_ab_0, axis_rot);
+                const dq r1 = from_angle_axis(ba_bc_1 - ba_bc_0, axis_rot);
+                const d3 c_a = normalize(e - a), t_a = normalize(t - a);
+                const dq r2 = from_angle_axis(acos(clamp1(dot(c_a, t_a))), normalize(cross(c_a, t_a)));
+                stq(&sh_ikq[ci][0][0], qmul(qinv(gr[4]), qmul(r2, qmul(r0, gr[3]))));          // the hip's (chain[3])
+                stq(&sh_ikq[ci][1][0], qmul(qinv(gr[3]), qmul(r1, gr[2])));                    // the knee's (chain[2])
+                sh_ikv[ci] = 1;
             }
-            if (!p.ik_enabled || depth < 5) continue;
-            for (int k = depth - 1; k >= 0; --k) {
-                const int b = chain[k];
-                const d3 lp = ld3(pos + b * 3);
-                const dq lr = ldq(rot + b * 4);
-                if (k == depth - 1) { gp[k] = lp; gr[k] = lr; }
-                else { gp[k] = qrot(gr[k + 1], lp) + gp[k + 1]; gr[k] = qmul(gr[k + 1], lr); }
-            }
-            // chain[0] toe, [1] heel, [2] knee, [3] hip, [4] the hip's parent
-            ContactRec& c = cr[ci];
-            const d3 in_pos = gp[0];
-            const bool in_state = contact[(size_t)i * p.n_contact + ci] != 0;
-            // Inertialization.py:300-377
-            const d3 in_vel = (in_pos - c.target) * (1.0 / (dt + 1e-8));
-            c.target = in_pos;
-            {
-                const d3 j1 = c.off_v + c.off_x * ydamp;                                       // :39-54
-                c.off_x = eydt * (c.off_x + j1 * dt);
-                c.off_v = eydt * (c.off_v - j1 * (ydamp * dt));
-            }
-            if (c.lock) { c.position = c.point + c.off_x; c.velocity = c.off_v; }
-            else { c.position = in_pos + c.off_x; c.velocity = in_vel + c.off_v; }
-            const bool unlock = c.lock && len(c.point - in_pos) > p.unlock_radius;
-            if (!c.state && in_state) {
-                c.lock = true;
-                c.point = c.position;
-                c.point.y = p.foot_height;
-                c.off_x = (in_pos + c.off_x) - c.point;
-                c.off_v = in_vel + c.off_v;
-            } else if ((c.lock && c.state && !in_state) || unlock) {
-                c.lock = false;
-                c.off_x = (c.point + c.off_x) - in_pos;
-                c.off_v = c.off_v - in_vel;
-            }
-            c.state = in_state;
-            if (c.position.y < p.foot_height) c.position.y = p.foot_height;                    // test_fullframework.py:581-582
-            // two-bone IK (quat.py:295-343): a hip, b knee, c heel
-            const d3 a = gp[3], b = gp[2], e = gp[1];
-            const d3 target = c.position + (gp[1] - gp[0]);
-            const d3 fwd = qrot(gr[2], d3{0.0, 1.0, 0.0});
-            const double max_ext = len(a - b) + len(b - e) - p.max_length_buffer;
-            d3 t = target;
-            if (len(target - a) > max_ext) t = a + max_ext * normalize(target - a);
-            const d3 axis_rot = normalize(cross(normalize(e - a), fwd));
-            const double lab = len(b - a), lcb = len(b - e), lat = len(t - a);
-            const double ac_ab_0 = acos(clamp1(dot(normalize(e - a), normalize(b - a))));
-            const double ba_bc_0 = acos(clamp1(dot(normalize(a - b), normalize(e - b))));
-            const double ac_ab_1 = acos(clamp1((lab * lab + lat * lat - lcb * lcb) / (2.0 * lab * lat)));
-            const double ba_bc_1 = acos(clamp1((lab * lab + lcb * lcb - lat * lat) / (2.0 * lab * lcb)));
-            const dq r0 = from_angle_axis(ac_ab_1 - ac_ab_0, axis_rot);
-            const dq r1 = from_angle_axis(ba_bc_1 - ba_bc_0, axis_rot);
-            const d3 c_a = normalize(e - a), t_a = normalize(t - a);
-            const dq r2 = from_angle_axis(acos(clamp1(dot(c_a, t_a))), normalize(cross(c_a, t_a)));
-            stq(ikr + chain[3] * 4, qmul(qinv(gr[4]), qmul(r2, qmul(r0, gr[3]))));
-            stq(ikr + chain[2] * 4, qmul(qinv(gr[3]), qmul(r1, gr[2])));
         }
-
-        // the BVH channels of this frame are made by mocha_post_bvh, in parallel over frames and bones, once the loop is through: it
-        // needs the frame's running root, which is not otherwise kept (POS[i][0] is the BLENDED root): parked in bone 1's position slot
-        if (BP && BE) st3(BP + (size_t)i * V * 3, root_pos);
+        __syncthreads();
+        if (is_joint) {
+            // the IK rotations: the bone's own rotation unless a contact replaced it (later contacts win, as in the sequential order)
+            dq q = rj;
+#pragma unroll
+            for (int c = 0; c < MOCHA_MAX_CONTACT; ++c)
+                if (ik_slot[c] >= 0 && sh_ikv[c]) q = ldq(&sh_ikq[c][ik_slot[c]][0]);
+            stq(ikr + lane * 4, q);
+        }
+        __syncthreads();                                        // the LDS exchange is rewritten by the next frame
     }
 }
 
@@ -298,7 +358,8 @@ __global__ __launch_bounds__(256) void mocha_post_bvh(PostParams p) {
 
 hipError_t launch_post_clip(const PostParams& p, hipStream_t s) {
     if (p.n_clips <= 0 || p.n_frames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(mocha_post_clip, dim3((p.n_clips + 63) / 64), dim3(64), 0, s, p);
+    if (p.V + 1 > MOCHA_MAX_BONES || p.n_contact > MOCHA_MAX_CONTACT) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_post_clip, dim3(p.n_clips), dim3(64), 0, s, p);
     if (p.bvh_pos && p.bvh_euler) {
         const long long n = (long long)p.n_clips * p.n_frames * p.V;
         hipLaunchKernelGGL(mocha_post_bvh, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p);
