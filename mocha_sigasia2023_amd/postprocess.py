@@ -158,13 +158,15 @@ def write_bvh(path: str, names: Sequence[str], parents: Sequence[int], positions
         if p == 0:
             joint(j, "\t")
     lines += ["}", "MOTION", "Frames: %i" % len(rot), "Frame Time: %f" % frametime]
-    for i in range(rot.shape[0]):
-        row = []
-        for j in visit:
-            if j == 0:
-                row.append("%f %f %f " % (pos[i, j, 0], pos[i, j, 1], pos[i, j, 2]))
-            row.append("%f %f %f " % (rot[i, j, ax[0]], rot[i, j, ax[1]], rot[i, j, ax[2]]))
-        lines.append("".join(row))
+    # the MOTION block: per frame the root's position, then every visited joint's three angles in channel order, each number as
+    # "%f " - one matrix in that column order and ONE format operation for the whole block (a Python loop over frames and joints
+    # took 20 ms for a 585-frame clip, several times the GPU's share of the demo)
+    n = rot.shape[0]
+    if n:
+        cols = [pos[:, 0, :]] + [rot[:, j][:, ax] for j in visit]
+        M = np.concatenate(cols, axis=1)                            # (n, 3 + 3 * len(visit))
+        row_fmt = "%f " * M.shape[1]
+        lines.append(("\n".join([row_fmt] * n)) % tuple(M.ravel().tolist()))
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
     return visit
