@@ -659,8 +659,11 @@ class OursSession:
         B = f.shape[0]
         if self.prev is None or self.prev.shape[0] != B:
             new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=d)
-            self.prev, self.se, self.sc = new(B, NTOK, DIM), new(B, NTOK, DIM), new(B, NTOK, DIM)
+            self.se, self.sc = new(B, NTOK, DIM), new(B, NTOK, DIM)
             self.cond, self.vae, self.cur, self.dec = new(B, 2 * NTOK, DIM), new(B, NTOK, DIM), new(B, NTOK, DIM), new(B, NTOK, DIM)
+            # prev_cha_encoded IS the previous frame's curr_cha_encoded (test_fullframework.py:452): the condition kernel reads it before
+            # this frame's sample overwrites it, so one buffer serves both (no copy per frame)
+            self.prev = self.cur
             self.eps, self.mu, self.logvar = new(B, DIM), new(B, DIM), new(B, DIM)
             self.Y = new(B, m.cfg["nframes"], m.V, m.cfg["mot_in_dim"])
             self._graphs = {}
@@ -674,7 +677,6 @@ class OursSession:
         c.call("mocha_cvae_sample", _ptr(self.cond), B, _ptr(self.vae), _ptr(self.mu), _ptr(self.logvar),
                _ptr(self.eps) if with_eps else None, st)
         c.call("mocha_scale_shift", _ptr(self.vae), _ptr(self.cm), _ptr(self.cs), B, _ptr(self.cur), st)
-        self.prev.copy_(self.cur)
         m.call("mocha_decoder", _ptr(self.se), _ptr(self.cur), B, _ptr(self.dec), st)
         m.call("mocha_to_mot", _ptr(self.dec), B, _ptr(self.Y), st)
 
