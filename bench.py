@@ -106,11 +106,14 @@ def spawn_ranks(a):
 
 
 def kernel_source_sha16():
-    """Hash of the device sources (csrc/*.hip, *.h): tools/pmc_traffic.sh writes it into the traffic summary it produces, and
-    the bench quotes PMC traffic only from a summary whose hash matches the sources of the library it is running."""
+    """Hash of the library's sources (csrc/*.hip, *.h, the host dispatch in mocha_api.cpp - which kernels and shapes a step launches
+    is decided there - and include/mocha_hip.h): tools/pmc_traffic.sh writes it into the traffic summary it produces, and the bench
+    quotes PMC traffic only from a summary whose hash matches the sources of the library it is running."""
     import glob, hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "mocha_sigasia2023_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "mocha_sigasia2023_amd", "csrc", "*.h"))):
+    csrc = os.path.join(ROOT, "mocha_sigasia2023_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + glob.glob(os.path.join(csrc, "*.cpp"))
+                    + [os.path.join(ROOT, "include", "mocha_hip.h")]):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -488,16 +488,16 @@ static constexpr size_t AX_SPLIT_LDS = (size_t)4 * AX_LDS * sizeof(unsigned shor
 hipError_t attention_x3_init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_attention_x3_split<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)AX_SPLIT_LDS);
 }
-int attention_x3_split_max = 192;                        // (window, head) pairs up to which the twelve-wave variant is launched (head dim 256: the
-                                                         // decoder's four heads, 48 windows; whole decoder 109 vs 116 us at one window, 236 vs 244 at 32,
-                                                         // equal at 64 windows, slower from 96 - tools/attn_split_ab.py)
+// AttnParams::split_max (default 192): (window, head) pairs up to which the twelve-wave variant is launched (head dim 256: the
+// decoder's four heads, 48 windows; whole decoder 109 vs 116 us at one window, 236 vs 244 at 32, equal at 64 windows, slower
+// from 96 - tools/attn_split_ab.py)
 
 hipError_t launch_attention_x3(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;
     if (p.nq < 1 || p.nk < 1 || p.nq > 96 || p.nk > 96 || (p.dh != 128 && p.dh != 256)) return hipErrorInvalidValue;
     dim3 grid((unsigned)(((p.B + 7) / 8) * 8 * p.heads));
     const bool pf2 = (long long)p.B * p.heads <= 256;    // fewer (window, head) workgroups than CUs: latency-bound, prefetch two steps ahead
-    if (p.dh == 256 && (long long)p.B * p.heads <= attention_x3_split_max) {
+    if (p.dh == 256 && (long long)p.B * p.heads <= p.split_max) {
         // head dim 128 (the encoder) has one chunk per group left to split: measured equal to the two-steps-ahead variant, which it keeps
         hipLaunchKernelGGL((mocha_attention_x3_split<256>), grid, dim3(768), AX_SPLIT_LDS, s, p);
         return hipGetLastError();

@@ -63,12 +63,12 @@ struct AttnParams {
     int B, heads, dh, nq, nk;
     float scale;
     int hsk = -1, hsv = -1;       // column offset per head of k / v (default dh; 0 = all heads share the same rows)
+    int split_max = 192;          // (window, head) pairs up to which the twelve-wave head-dim-256 variant is launched (0 = never)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 // the same on the bf16 matrix pipe with exact three-plane operands (attention_x3.hip): nq, nk <= 96, dh = 128 / 256
 hipError_t launch_attention_x3(const AttnParams& p, hipStream_t s);
 hipError_t attention_x3_init();              // one-time function attributes (dynamic LDS of the twelve-wave small-batch variant)
-extern int attention_x3_split_max;           // (window, head) pairs up to which that variant is launched (diagnostics may lower it to 0)
 
 // ---------------------------------------------------------------------------------------
 // Small bandwidth-bound kernels

@@ -381,7 +381,8 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
     __syncthreads();
     const unsigned nmin = (unsigned)(r_key & 0xffffffffull);
     const float d16min = sqrtf(fmaxf(key_value(r_key), 0.f));
-    const float hi = d16min + rho[nmin] + 2e-5f * d16min;              // upper bound of the coarse minimum's exact distance
+    // (no finite coarse key at all - every key NaN or ~0 - leaves nmin out of range: nothing is excluded then)
+    const float hi = (long long)nmin < N ? d16min + rho[nmin] + 2e-5f * d16min : __builtin_inff();      // upper bound of the coarse minimum's exact distance
     auto qualifies = [&](long long n, unsigned long long k, float r) -> bool {
         if ((unsigned)n == nmin) return true;
         const float d = sqrtf(fmaxf(key_value(k), 0.f));
@@ -462,7 +463,8 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
         }
     }
     // ---- 3. the slices' winners: each workgroup publishes its own, the one that arrives last picks the smallest (distance, row) key.
-    // The ticket counts arrivals and is never reset (RF_SPLIT divides 2^32; calls that share a scratch buffer are ordered by their stream).
+    // The ticket counts this launch's arrivals; the last arriver puts it back to zero, so a launch that was cut short (an error between the
+    // scan and this kernel) cannot leave later calls electing the wrong workgroup.  Calls that share a scratch buffer are ordered by their stream.
     __syncthreads();
     if (tid == 0) {
         __atomic_store_n(part + (size_t)q * RF_SPLIT + sl, best, __ATOMIC_RELAXED);
@@ -480,6 +482,7 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
         }
         idx[q] = (int)(bk & 0xffffffffull);
         if (dist) dist[q] = sqrtf(__uint_as_float((unsigned)(bk >> 32)));
+        atomicExch(ticket + q, 0u);
     }
 }
 

@@ -130,6 +130,8 @@ struct mocha_ctx {
     // its own captured graph; `lane` is the set the single-stream pipelines below write to.
     int lanes = 1, lane = 0;
     bool dual_stream = false; int dual_min = 128;     // opt-in: mocha_set_option(ctx, "dual_stream", 1) or MOCHA_DUAL_STREAM=1
+    bool dual_ready = false;                          // ensure_ws allocated set 1 at full chunk size (a lane's set 1 holds 8 windows only)
+    int attn_split_max = 192;                         // (window, head) pairs up to which the twelve-wave decoder attention is launched
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf match_S[MAX_SETS];
     int32_t* idx_ws[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t idx_ws_n = 0;
@@ -368,6 +370,7 @@ int ensure_ws(mocha_ctx* c, int B) {
     }
     c->idx_ws_n = want;
     c->chunk = want;
+    c->dual_ready = dual_sets;
     c->generation++;
     return 0;
 }
@@ -450,10 +453,11 @@ int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
 // the Generator's attention (90 tokens, head dim 128 / 256): plane products on the bf16 pipe unless switched off
 const char* attn_kernel_name(const mocha_ctx* c, int DH, long long pairs = 1 << 30) {
     const bool x3 = c->attn_x3 && (DH == 128 || DH == 256);
-    if (x3 && DH == 256 && pairs <= attention_x3_split_max) return "mocha_attention_x3_split<256>";
+    if (x3 && DH == 256 && pairs <= c->attn_split_max) return "mocha_attention_x3_split<256>";
     return x3 ? (DH == 128 ? "mocha_attention_x3<128>" : "mocha_attention_x3<256>") : (DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>");
 }
-hipError_t attention(const mocha_ctx* c, const AttnParams& a, hipStream_t s) {
+hipError_t attention(const mocha_ctx* c, const AttnParams& a0, hipStream_t s) {
+    AttnParams a = a0; a.split_max = c->attn_split_max;
     return (c->attn_x3 && (a.dh == 128 || a.dh == 256) && a.nq <= 96 && a.nk <= 96) ? launch_attention_x3(a, s) : launch_attention(a, s);
 }
 #define GEMM(c, s, site, p) do { int rc__ = gemm((c), (s), (site), (p)); if (rc__) return rc__; } while (0)
@@ -657,7 +661,8 @@ int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s
 // own workspace set, so two independent kernel chains are in flight and fill each other's bubbles.
 template <class F>
 int for_chunks(mocha_ctx* c, int B, hipStream_t s, F&& fn) {
-    const bool dual = c->dual_stream && B >= c->dual_min && !c->wss[1].empty();
+    // set 1 must be a FULL-size set: with lanes >= 2 it exists at 8 windows whenever dual_sets was false at allocation
+    const bool dual = c->dual_stream && B >= c->dual_min && c->dual_ready && !c->wss[1].empty();
     if (!dual) {
         c->cur = c->lane;
         for (int b0 = 0; b0 < B; b0 += c->chunk) { int rc = fn(b0, std::min(c->chunk, B - b0), s); if (rc) return rc; }
@@ -724,8 +729,7 @@ int match_ksplit(int Q, int64_t N) {
 
 // windows workspace set `set` holds (ensure_ws): the chunk for set 0 and dual_stream's set 1, a handful for a lane's set
 int set_windows(const mocha_ctx* c, int set) {
-    const bool dual_sets = c->dual_stream && c->chunk >= c->dual_min / 2;
-    return (set == 0 || (set == 1 && dual_sets)) ? std::max(c->chunk, 8) : 8;
+    return (set == 0 || (set == 1 && c->dual_ready)) ? std::max(c->chunk, 8) : 8;
 }
 
 // Scratch of do_match for up to Q queries against N bank rows, in workspace set `set`: centred queries, the streaming
@@ -2048,13 +2052,21 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
         c->chunk = 0;                              // workspace sets are re-planned on the next call (generation moves)
         return 0;
     }
-    if (n == "dual_min") { c->dual_min = value < 2 ? 2 : value; return 0; }
-    if (n == "fold_decoder") { c->fold_decoder = value != 0; return 0; }
-    if (n == "fold_joint") { c->fold_joint = value != 0; return 0; }
-    if (n == "scan16") { c->scan16 = value != 0; return 0; }             // takes effect at the next mocha_bank_set
-    if (n == "attention_split_max") { attention_x3_split_max = value < 0 ? 0 : value; return 0; }      // process-wide (diagnostic)
-    if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; return 0; }
-    if (n == "attention_bf16x3") { c->attn_x3 = value != 0; return 0; }
+    if (n == "dual_min") {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipDeviceSynchronize());
+        c->dual_min = value < 2 ? 2 : value;
+        c->chunk = 0;                              // whether set 1 is a full-size set depends on it: re-planned on the next call
+        return 0;
+    }
+    // Path-selecting options change which kernels a step launches: a captured step graph (mocha_step_graph_lane, OursSession)
+    // replays the old path until it is re-captured, so every one of them moves the generation.
+    if (n == "fold_decoder") { c->fold_decoder = value != 0; c->generation++; return 0; }
+    if (n == "fold_joint") { c->fold_joint = value != 0; c->generation++; return 0; }
+    if (n == "scan16") { c->scan16 = value != 0; c->generation++; return 0; }             // bank side takes effect at the next mocha_bank_set
+    if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only
+    if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; c->generation++; return 0; }
+    if (n == "attention_bf16x3") { c->attn_x3 = value != 0; c->generation++; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);
 }
 

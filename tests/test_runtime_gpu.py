@@ -287,3 +287,41 @@ def test_build_provenance_is_recorded(model):
     info = lib.mocha_build_info().decode()
     assert info.startswith("hipcc HIP ") and "gfx950" in info
     assert lib.mocha_runtime_version() > 0
+
+
+def test_dual_stream_with_lane_sets_never_halves_into_a_small_set():
+    """with lanes >= 2 workspace set 1 exists at 8 windows unless the two-stream split needed it whole when the
+    sets were planned.  reserve(32) under the default dual_min of 128 (and a dual_min lowered after allocation) used to send the
+    second half of a 256-window batch, in 32-window chunks, into that 8-window set: out-of-bounds device writes.  Now the split
+    only runs on a full-size set 1, and set_option("dual_min") re-plans the sets."""
+    sd = weights.synthetic_state_dict(11, 1.0)
+    ref_m = Generator(device="cuda:0").load_state_dict(sd).eval()
+    X = torch.from_numpy(synthetic.pose_windows(31, 256)).cuda()
+    ref = ref_m(X, X.flip(0))
+    m = Generator(device="cuda:0").load_state_dict(sd).eval()
+    m.set_option("lanes", 2).set_option("dual_stream", 1)
+    m.reserve(32)                                     # chunk 32 < dual_min / 2: set 1 is a lane's 8-window set
+    guard = torch.full((1 << 22,), 7.0, device="cuda")               # allocated right after the workspaces: a likely landing place
+    Y = m(X, X.flip(0))
+    torch.cuda.synchronize()
+    assert float((Y - ref).abs().max()) < 1e-5
+    assert bool((guard == 7.0).all())
+    g = m._ctx.generation()
+    m.set_option("dual_min", 16)                      # now the split applies at chunk 32: the sets must be re-planned
+    Y2 = m(X, X.flip(0))
+    torch.cuda.synchronize()
+    assert m._ctx.generation() > g
+    assert float((Y2 - ref).abs().max()) < 1e-5
+    m.set_option("dual_stream", 0).set_option("lanes", 1)
+
+
+def test_path_selecting_options_move_the_generation(model):
+    """an option that changes which kernels a step launches must invalidate captured step graphs."""
+    for name, other in (("scan16", 0), ("fold_joint", 0), ("fold_decoder", 0), ("attention_split_max", 0), ("gemm_bf16x3", 0),
+                        ("attention_bf16x3", 0)):
+        g = model._ctx.generation()
+        model.set_option(name, other)
+        assert model._ctx.generation() > g, name
+    for name, dflt in (("scan16", 1), ("fold_joint", 1), ("fold_decoder", 1), ("attention_split_max", 192), ("gemm_bf16x3", 1),
+                       ("attention_bf16x3", 1)):
+        model.set_option(name, dflt)

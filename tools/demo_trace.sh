@@ -1,5 +1,9 @@
+#!/bin/bash
+# rocprofv3 kernel trace of examples/demo_pair.py -> gpurun_out/demo_trace
+set -u
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/demo_trace; rm -rf $out; mkdir -p $out
+R=${GRAFT_REPO_ROOT:-/root/repo}
+out=$R/gpurun_out/demo_trace; rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/raw -o t -- python3 $R/examples/demo_pair.py --frames 585 --out $out/bvh > $out/stdout.txt 2> $out/stderr.txt
 f=$(find $out/raw -name '*kernel_stats.csv' | head -1)
 python3 - "$f" <<'PY'

@@ -1,5 +1,9 @@
+#!/bin/bash
+# TCC request counters of the default bench command -> gpurun_out/tcc
+set -u
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; out=$R/gpurun_out/tcc; mkdir -p $out
+R=${GRAFT_REPO_ROOT:-/root/repo}
+out=$R/gpurun_out/tcc; mkdir -p $out
 rocprofv3 --list-avail 2>/dev/null | grep -o "TCC_EA0_[A-Z0-9_]*\|TCC_HIT[a-z_]*\|TCC_MISS[a-z_]*\|TCC_REQ[a-z_]*\|TCC_READ[a-z_]*\|TCC_WRITE[a-z_]*\|TCC_EA_[A-Z0-9_]*" | sort -u | tr '\n' ' ' > $out/avail.txt
 cat $out/avail.txt; echo
 for set in "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_REQ_sum TCC_READ_sum"; do

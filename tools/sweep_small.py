@@ -1,5 +1,5 @@
 import os, sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, synthetic_state_dict
 dev = torch.device("cuda:0")
 model = Generator(device=dev).load_state_dict(synthetic_state_dict(1777, 1.0)).eval()
