@@ -196,6 +196,17 @@ int mocha_bank_broadcast(mocha_ctx* ctx, void* comm, int root, int64_t N, int fl
  * that the split can be tested without a GPU): out = {offset of this rank's chunk, chunk length, offset of the tail, tail
  * length}.  Chunk r is scattered root -> r and all-gathered; the count % world tail is broadcast whole. */
 int mocha_bcast_plan(int64_t count, int world, int rank, int64_t out[4]);
+/* What the context's communicator really is, for the bench line and for logs (bench.py's `rccl` record): ranks and this rank
+ * as RCCL itself reports them (ncclCommCount / ncclCommUserRank on the communicator mocha_comm_init made - not the caller's
+ * arguments), ncclGetVersion's code (major * 10000 + minor * 100 + patch), the file the RCCL entry points were resolved
+ * from (dladdr on ncclCommInitRank: a stand-in or a second RCCL cannot pass unnoticed), the context's device ordinal and
+ * its PCI bus id (hipDeviceGetPCIBusId).  MOCHA_ERR_STATE without a communicator.  Host-side, no synchronisation. */
+typedef struct {
+    int nranks, rank, rccl_version, device;
+    char pci_bus_id[32];
+    char library[512];
+} mocha_comm_info_t;
+int mocha_comm_info(mocha_ctx* ctx, mocha_comm_info_t* out);
 
 /* Pose normalisation of the demo fused into the path: the four norm.npz
  * arrays of the reference (test_fullframework.py:64-71), HOST fp32, (V+1)*C_in each with the root bone

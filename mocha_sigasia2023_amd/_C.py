@@ -21,6 +21,11 @@ class mocha_cfg(C.Structure):
         "dec_depth", "dec_heads", "dec_dim_head", "dec_mlp", "layout")]
 
 
+class mocha_comm_info_t(C.Structure):
+    _fields_ = [("nranks", C.c_int), ("rank", C.c_int), ("rccl_version", C.c_int), ("device", C.c_int),
+                ("pci_bus_id", C.c_char * 32), ("library", C.c_char * 512)]
+
+
 _vp, _i, _i64 = C.c_void_p, C.c_int, C.c_int64
 
 # name -> (restype, argtypes); every symbol include/mocha_hip.h declares
@@ -72,6 +77,7 @@ SIGNATURES = {
     "mocha_comm_unique_id": (_i, [_vp, _vp]),
     "mocha_comm_init": (_i, [_vp, _vp, _i, _i]),
     "mocha_comm_destroy": (_i, [_vp]),
+    "mocha_comm_info": (_i, [_vp, C.POINTER(mocha_comm_info_t)]),
     "mocha_bank_broadcast": (_i, [_vp, _vp, _i, _i64, _i, _vp]),
     "mocha_bcast_plan": (_i, [_i64, _i, _i, C.POINTER(_i64)]),
     "mocha_build_info": (C.c_char_p, []),

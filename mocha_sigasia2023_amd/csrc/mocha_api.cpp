@@ -1542,6 +1542,7 @@ struct Rccl {
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 Rccl g_rccl;
@@ -1571,6 +1572,7 @@ int rccl_load(mocha_ctx* c) {
     r.Recv = (decltype(r.Recv))sym("ncclRecv");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
     r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+    r.GetVersion = (decltype(r.GetVersion))sym("ncclGetVersion");
     r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     if (!ok) { dlclose(h); return fail(c, MOCHA_ERR_STATE, "librccl lacks an expected entry point"); }
     g_rccl = r;
@@ -1652,6 +1654,24 @@ int mocha_comm_init(mocha_ctx* c, const void* id128, int nranks, int rank) {
     memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
     NCCLCHK(c, g_rccl.CommInitRank(&c->comm, nranks, id, rank));
     c->comm_rank = rank; c->comm_size = nranks;
+    return 0;
+}
+
+int mocha_comm_info(mocha_ctx* c, mocha_comm_info_t* out) {
+    if (!c || !out) return fail(c, MOCHA_ERR_ARG, "null argument");
+    if (!c->comm || !g_rccl.h) return fail(c, MOCHA_ERR_STATE, "no communicator: call mocha_comm_init first");
+    memset(out, 0, sizeof *out);
+    NCCLCHK(c, g_rccl.CommCount(c->comm, &out->nranks));
+    NCCLCHK(c, g_rccl.CommUserRank(c->comm, &out->rank));
+    NCCLCHK(c, g_rccl.GetVersion(&out->rccl_version));
+    out->device = c->device;
+    HIPCHK(c, hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof out->pci_bus_id, c->device));
+    Dl_info di;
+    if (dladdr(reinterpret_cast<const void*>(g_rccl.CommInitRank), &di) && di.dli_fname) {
+        char real[4096];
+        const char* path = realpath(di.dli_fname, real) ? real : di.dli_fname;
+        snprintf(out->library, sizeof out->library, "%s", path);
+    }
     return 0;
 }
 

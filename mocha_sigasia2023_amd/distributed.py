@@ -89,6 +89,19 @@ def init_comm(model) -> None:
     model._comm_ready = True
 
 
+def comm_info(model) -> dict:
+    """``mocha_comm_info``: what the context's communicator really is - ranks as RCCL reports them (ncclCommCount), RCCL's version,
+    the file its entry points were resolved from, the context's device and PCI bus id."""
+    import ctypes as C
+    from ._C import mocha_comm_info_t
+    info = mocha_comm_info_t()
+    model._ctx.call("mocha_comm_info", C.byref(info))
+    v = int(info.rccl_version)
+    return {"nranks": int(info.nranks), "rank": int(info.rank), "rccl_version_code": v,
+            "rccl_version": f"{v // 10000}.{v // 100 % 100}.{v % 100}", "library": info.library.decode(),
+            "device": int(info.device), "pci_bus_id": info.pci_bus_id.decode()}
+
+
 def bank_broadcast(model, bank, n_entries: int, root: int = 0, bf16: bool = False):
     """``mocha_bank_broadcast``: the root's ContextBank becomes every rank's current bank over RCCL / xGMI (scatter +
     all-gather of cnt_nm and encoded; derived data recomputed locally).  Returns the rank's bank handle."""

@@ -474,9 +474,13 @@ class StreamingCharacterizer:
     graph launch.  The library re-captures by itself when the bank or a workspace it baked in has changed; this class
     re-activates its bank when another bank was made current in between."""
 
-    def __init__(self, bank: ContextBank, cnt_mean, cnt_std, use_graph: bool = True, lanes: int = 1):
+    def __init__(self, bank: ContextBank, cnt_mean, cnt_std, use_graph: bool = True, lanes: int = 1, raw: bool = False):
+        """raw=True (after ``Generator.set_pose_norm``): windows come un-normalised with the root bone, (60, V+1, 15), as
+        ``Generator.featurize`` writes them; the z-score of test_fullframework.py:186 and the de-normalisation of :303 run inside the
+        step's kernels, the result is (60, V, 15)."""
         self.bank, self.model = bank, bank.model
         m = self.model
+        self.raw = bool(raw)
         if not 1 <= lanes <= 3:
             raise ValueError("lanes must be 1..3")
         if lanes > 1 and not use_graph:
@@ -485,7 +489,8 @@ class StreamingCharacterizer:
         self.mean = _dev_f32(cnt_mean, m.device, (NTOK, DIM), "cnt_mean")
         self.std = _dev_f32(cnt_std, m.device, (NTOK, DIM), "cnt_std")
         shape = (1, m.cfg["nframes"], m.V, m.cfg["mot_in_dim"])
-        self.xs = [torch.zeros(shape, dtype=torch.float32, device=m.device) for _ in range(lanes)]
+        in_shape = (1, m.cfg["nframes"], m.V + 1, m.cfg["mot_in_dim"]) if self.raw else shape
+        self.xs = [torch.zeros(in_shape, dtype=torch.float32, device=m.device) for _ in range(lanes)]
         self.ys = [torch.empty(shape, dtype=torch.float32, device=m.device) for _ in range(lanes)]
         self.idxs = [torch.zeros((1,), dtype=torch.int32, device=m.device) for _ in range(lanes)]
         self.x, self.y, self.idx = self.xs[0], self.ys[0], self.idxs[0]
@@ -500,9 +505,9 @@ class StreamingCharacterizer:
             self.bank.activate()                           # another bank was made current: ours again (bumps the generation)
         if self.use_graph:
             self.model._ctx.call("mocha_step_graph_lane", lane, _ptr(self.xs[lane]), _ptr(self.mean), _ptr(self.std), _ptr(self.ys[lane]),
-                                 _ptr(self.idxs[lane]), 0, _stream())
+                                 _ptr(self.idxs[lane]), 1 if self.raw else 0, _stream())
         else:
-            self.model._ctx.call("mocha_characterize", _ptr(self.x), 1, _ptr(self.mean), _ptr(self.std), _ptr(self.y),
+            self.model._ctx.call("mocha_characterize_raw" if self.raw else "mocha_characterize", _ptr(self.x), 1, _ptr(self.mean), _ptr(self.std), _ptr(self.y),
                                  _ptr(self.idx), _stream())
 
     @property
@@ -529,7 +534,7 @@ class StreamingCharacterizer:
         m = self.model
         wins = _dev_f32(windows, m.device, tuple(self.x.shape[1:]), "windows")
         W = wins.shape[0]
-        Y = torch.empty((W,) + tuple(self.x.shape[1:]), dtype=torch.float32, device=m.device)
+        Y = torch.empty((W,) + tuple(self.y.shape[1:]), dtype=torch.float32, device=m.device)
         idx = torch.empty((W,), dtype=torch.int32, device=m.device)
         if W == 0:
             return Y, idx
@@ -579,23 +584,30 @@ class CVAE:
         return self
 
     def load_state_dict(self, state_dict: Mapping, strict: bool = True):
+        """The bare ``state_dict`` the demo loads (``torch.load('cvae_020000.pt')``, test_fullframework.py:56-58): tensors or
+        ndarrays by the reference's names.  The training-only posterior ``encoder.*`` entries and the ``pos_encoder.pe`` buffers
+        are accepted; ``module.``-prefixed keys (a DataParallel-wrapped save) too.  ``strict=False`` skips unknown keys and lets a
+        re-load bring only some tensors (a context that never saw a tensor still fails, in ``mocha_cvae_finalize``)."""
         from .weights import cvae_param_shapes
         want = cvae_param_shapes()
         seen = set()
-        for k, v in state_dict.items():
+        has_pe = False
+        for k0, v in state_dict.items():
+            k = k0[len("module."):] if k0.startswith("module.") else k0
             a = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
             a = np.ascontiguousarray(a, dtype=np.float32)
             if k not in want and not k.startswith("encoder.") and not k.endswith("pos_encoder.pe"):
                 if strict:
-                    raise KeyError(f"unexpected key in CVAE state_dict: {k}")
+                    raise KeyError(f"unexpected key in CVAE state_dict: {k0}")
                 continue
             shape = (C.c_int64 * a.ndim)(*a.shape)
             self._ctx.call("mocha_cvae_load_weight", k.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
             seen.add(k)
+            has_pe = has_pe or k == "prior_net.pos_encoder.pe"
         missing = [k for k in want if k not in seen]
-        if missing:
+        if missing and strict:
             raise KeyError(f"missing keys in CVAE state_dict: {missing[:4]}{'...' if len(missing) > 4 else ''}")
-        if "prior_net.pos_encoder.pe" not in state_dict:
+        if not has_pe:
             # regenerate the registered buffer exactly as torch builds it (model_CVAE.py:168-178)
             from .weights import sincos_pe
             pe = np.ascontiguousarray(sincos_pe(192)[None], dtype=np.float32)

@@ -83,3 +83,37 @@ def postprocess_inputs(seed: int, N: int, V: int = 24, T: int = 60):
     phase = (np.arange(N)[:, None] // 9 + np.array([0, 1])[None]) % 2
     phase[N // 3: N // 3 + 30, 0] = 1                     # a long contact: exercised until the unlock radius trips
     return Y, src_rvel, src_rang, src_hipvel, phase.astype(np.uint8)
+
+
+def smooth_bone_clip(seed: int, frames: int = 644, J: int = 25, phase: float = 0.0, gain: float = 1.0):
+    """A smooth synthetic clip of local bone features, frame by frame - the stand-in for a loaded BVH clip
+    (test_fullframework.py:124-139): every bone's rotation swings periodically (a 'gait' of 0.9-2.1 Hz at 60 fps) around its own
+    rest orientation, the root travels forward with a vertical bob, bone offsets are FIXED - so the non-root linear velocities
+    are exactly zero, constant channels as real clips have them - and the angular velocities are the analytic derivatives'
+    size.  `phase` shifts time by a fraction of a frame and `gain` scales the swing: a second clip of the same motion whose
+    windows are near-duplicates of the first one's, never equal.  Returns (rot (F,J,4), pos (F,J,3), vel, ang), float32."""
+    r = _rng(seed)
+    t = (np.arange(frames, dtype=np.float64) + phase)[:, None, None]
+    base = r.standard_normal((J, 4)); base /= np.sqrt((base * base).sum(-1, keepdims=True))
+    amp = gain * 0.35 * r.uniform(0.2, 1.0, (J, 4))
+    om = 2 * np.pi * r.uniform(0.9, 2.1, (J, 1)) / 60.0
+    ph = r.uniform(0, 2 * np.pi, (J, 4))
+    q = base[None] + amp[None] * np.sin(om[None] * t + ph[None])
+    q /= np.sqrt((q * q).sum(-1, keepdims=True))
+    q = np.where(q[..., :1] > 0, q, -q)
+    offs = 0.25 * r.standard_normal((J, 3)); offs[:, 1] -= 0.15
+    pos = np.repeat(offs[None], frames, 0)
+    tt = t[:, 0, 0]
+    root = np.stack([0.05 * np.sin(0.05 * tt), 0.9 + 0.03 * np.sin(0.21 * tt), 1.2 * tt / 60.0], -1)
+    pos[:, 0] = root
+    vel = np.zeros((frames, J, 3))
+    vel[:, 0] = np.stack([0.05 * 0.05 * 60 * np.cos(0.05 * tt), 0.03 * 0.21 * 60 * np.cos(0.21 * tt), np.full_like(tt, 1.2)], -1)
+    ang = gain * 0.35 * 60.0 * om[None] * r.uniform(0.2, 1.0, (J, 3))[None] * np.cos(om[None] * t + ph[None, :, :3])
+    return q.astype(np.float32), pos.astype(np.float32), vel.astype(np.float32), ang.astype(np.float32)
+
+
+def slide_windows(a: np.ndarray, window: int = 60, step: int = 1) -> np.ndarray:
+    """(F, ...) -> (F - window + 1, window, ...) windows slid with `step` (process_data(window=60, window_step=1),
+    test_fullframework.py:128; preprocess/generate_database.py:65-84), as a contiguous copy."""
+    v = np.lib.stride_tricks.sliding_window_view(a, window, axis=0)          # (F - w + 1, ..., w)
+    return np.ascontiguousarray(np.moveaxis(v, -1, 1)[::step])

@@ -395,8 +395,48 @@ def run_bvh():
     print("bvh", len(text), "chars")
 
 
+def run_checkpoint_schema():
+    """The checkpoint FILE schema, from the reference's own writer: Trainer(cfg).save_checkpoint (trainer.py:210-222) into a
+    temporary directory, read back with torch.load as Trainer.load_checkpoint / the demo do (trainer.py:224-247,
+    test_fullframework.py:47-49) -> the top-level keys, and name / shape / dtype of every entry of 'gen' and 'gen_ema', as JSON.
+    The CVAE's file is a bare state_dict (test_fullframework.py:52-58): its key list too.  Data only."""
+    import json
+    import tempfile
+    cwd = os.getcwd(); os.chdir(REF)
+    try:
+        for p in (REF, os.path.join(REF, "net"), os.path.join(REF, "etc"), os.path.join(REF, "motion")):
+            if p not in sys.path:
+                sys.path.append(p)
+        from utils import get_config
+        from trainer import Trainer                       # trainer.py:17
+        from model_CVAE import CVAE                       # model_CVAE.py
+        import torch.nn.functional as F
+        cfg = get_config(os.path.join(REF, "configs/config.yaml"))
+        with tempfile.TemporaryDirectory() as tmp:
+            cfg["model_dir"] = tmp                        # etc/utils.py initialize_path would create it under the reference tree
+            tr = Trainer(cfg)
+            tr.save_checkpoint(125)
+            path = os.path.join(tmp, "gen_125.pt")
+            ck = torch.load(path, map_location="cpu")
+            wrapped = {"module." + k for k in ck["gen_ema"]} == set(torch.nn.DataParallel(tr.gen_ema.module if hasattr(tr.gen_ema, "module") else tr.gen_ema).state_dict())
+        net = CVAE(output_seq=90, latent_dim=256, depth=2, nheads=4, feedforward_dim=512, dropout=0.1, activation=F.relu)   # test_fullframework.py:52-55
+    finally:
+        os.chdir(cwd)
+    desc = lambda sd: {k: [list(v.shape), str(v.dtype).replace("torch.", "")] for k, v in sd.items()}
+    out = {"file": "gen_%03d.pt" % 125, "top_level_keys": list(ck.keys()), "gen": desc(ck["gen"]), "gen_ema": desc(ck["gen_ema"]),
+           "gen_opt_keys": list(ck["gen_opt"].keys()), "dataparallel_prefix": "module.", "dataparallel_prefix_checked": bool(wrapped),
+           "cvae_file": "cvae_020000.pt", "cvae": desc(net.state_dict())}
+    with open(os.path.join(HERE, "checkpoint_schema.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"checkpoint_schema.json: {len(out['gen_ema'])} gen_ema entries, {len(out['cvae'])} cvae entries, top level {out['top_level_keys']}")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if len(sys.argv) > 1:                                 # e.g. `make_golden.py run_checkpoint_schema`: one fixture only
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     run_graph_constants()
     run_variant("mocha24_g1", "mocha", seed=1777, gain=1.0, B=2)
     run_variant("mocha24_g2", "mocha", seed=4242, gain=2.0, B=1)
@@ -408,3 +448,4 @@ if __name__ == "__main__":
     run_database()
     run_postprocess()
     run_bvh()
+    run_checkpoint_schema()

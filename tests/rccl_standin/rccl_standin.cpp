@@ -1,4 +1,4 @@
-// TEST-ONLY stand-in for the twelve RCCL entry points libmocha_hip.so resolves at run time (struct Rccl in
+// TEST-ONLY stand-in for the thirteen RCCL entry points libmocha_hip.so resolves at run time (struct Rccl in
 // mocha_sigasia2023_amd/csrc/mocha_api.cpp), so that the multi-rank C-ABI path - mocha_comm_init, mocha_bank_broadcast's
 // scatter + all-gather + tail broadcast, the receiving side's allocation branch - runs with 2..8 ranks on a box that has ONE
 // GPU.  Real RCCL refuses two ranks on one device; here every rank is an ordinary process on the same GPU and the "wire" is
@@ -254,6 +254,13 @@ ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int
     if (!c || !es || peer < 0 || peer >= c->world || peer == c->rank) return ncclInvalidArgument;
     if (!g_depth) return ncclInvalidUsage;
     g_queue.push_back(P2P{false, recvbuff, count * es, peer, c, stream});
+    return ncclSuccess;
+}
+
+// a version code no real RCCL carries (0.0.1): a bench line that names it ran on the stand-in
+ncclResult_t ncclGetVersion(int* version) {
+    if (!version) return ncclInvalidArgument;
+    *version = 1;
     return ncclSuccess;
 }
 

@@ -2,7 +2,7 @@
 
 mocha_bank_broadcast's scatter + all-gather + tail broadcast, the receiving side's allocation branch, ContextBank.received
 and bench.py's N > 1 branches need several ranks; real RCCL refuses two ranks on one device.  The library resolves RCCL
-through a function table (mocha_set_rccl_library), so these tests load tests/rccl_standin/librccl_standin.so - the twelve
+through a function table (mocha_set_rccl_library), so these tests load tests/rccl_standin/librccl_standin.so - the thirteen
 entry points over POSIX shared memory + hipMemcpy, test infrastructure only - and start every rank as a fresh process on
 GPU 0.  Split being tested: test_fullframework.py:148-158, 440-443, 465-467 (windows are independent; the bank is read-only).
 """
@@ -162,6 +162,70 @@ def test_bench_demo_two_ranks_runs_the_broadcast_and_probe(standin):
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak"
     assert rec.get("bank_broadcast_error") is None and rec["bank_broadcast_ms"] > 0
     assert len(rec["per_rank_frames_per_s"]) == 2 and rec["value"] > 0
+    _check_rccl_record(rec["rccl"], 2, standin)
+    _check_bank4k_subrecord(rec["bank4k"], 2)
+
+
+def _check_rccl_record(r, world, standin):
+    """The `rccl` record says what the communicator REALLY was: ranks from ncclCommCount, the library file, every rank's device -
+    here the stand-in on one GPU, and the line says so (is_test_standin, test_hooks_in_env, distinct_devices == 1)."""
+    assert r["nranks"] == world and r["nranks_agree"] is True
+    assert os.path.realpath(r["library"]) == os.path.realpath(standin)
+    assert r["is_test_standin"] is True and r["rccl_version_code"] == 1
+    assert [p["rank"] for p in r["per_rank"]] == list(range(world))
+    assert all(p["device"] == 0 and p["pci_bus_id"] for p in r["per_rank"]) and r["distinct_devices"] == 1
+    assert r["test_hooks_in_env"].get("MOCHA_RCCL_LIBRARY") == standin and r["test_hooks_in_env"].get("MOCHA_BENCH_ONE_GPU") == "1"
+    assert r["torch_side_channel_backend"] == "gloo"
+
+
+def _check_bank4k_subrecord(b, world):
+    """The configs[3] sub-record of the default N > 1 line: 1024 windows split by shard_bounds, the bank through the C ABI with
+    its time and rate, the index checksum beside the known 1-GPU one."""
+    assert b["n_gpus"] == world and b["scaling"] == "strong"
+    assert sum(b["config"]["windows_per_gpu"]) == 1024 and len(b["config"]["windows_per_gpu"]) == world
+    assert max(b["config"]["windows_per_gpu"]) - min(b["config"]["windows_per_gpu"]) <= 1
+    bc = b["bank_broadcast"]
+    assert bc["bytes_per_rank"] == 2 * 4096 * 23040 * 4 and bc["ms"] > 0 and bc["ms_first_call"] > 0
+    assert abs(bc["GB/s_per_rank"] - bc["bytes_per_rank"] / bc["ms"] / 1e6) < 1e-6 * bc["GB/s_per_rank"]
+    assert bc["xgmi_inbound_peak_GB/s"] == (world - 1) * 153.0 and 0 < bc["frac_of_xgmi_inbound_peak"]
+    assert len(b["per_rank_frames_per_s"]) == world and b["value"] > 0
+    assert "idx_crc32" in b and "idx_crc32_n1_known" in b
+    if b["idx_crc32_n1_known"] is not None:
+        assert b["idx_matches_n1"] is True, (b["idx_crc32"], b["idx_crc32_n1_known"])
+
+
+@pytest.mark.timeout(3000)
+def test_bench_default_line_three_ranks_carries_configs3(standin):
+    """`python bench.py --gpus 3`: the driver's N > 1 line has the weak-scaled headline AND the configs[3] sub-record (1024 windows
+    do not divide by 3: shards of 342 / 341 / 341) with the index checksum of the 1-rank run."""
+    rec = _bench(standin, ["--gpus", "3", "--windows", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+                 MOCHA_BENCH_ONE_GPU="1", MOCHA_BENCH_BACKEND="gloo")
+    assert rec["n_gpus"] == 3 and rec["bank_broadcast_error"] is None
+    _check_rccl_record(rec["rccl"], 3, standin)
+    _check_bank4k_subrecord(rec["bank4k"], 3)
+    assert rec["bank4k"]["config"]["windows_per_gpu"] == [342, 341, 341]
+    one = _bench(standin, ["--workload", "bank4k", "--steps", "1", "--warmup", "1"])
+    assert rec["bank4k"]["idx_crc32"] == one["idx_crc32"]
+    assert np.allclose(rec["bank4k"]["y_fingerprint"], one["y_fingerprint"], rtol=1e-5)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("workload", ["demo", "bank4k"])
+def test_a_dying_rank_ends_the_job_within_seconds(standin, workload):
+    """rank 1 dies right after the rendezvous (MOCHA_BENCH_FAIL_RANK) while rank 0 goes on into its first
+    collective.  The launcher must exit non-zero promptly - not when the collective times out (gloo: 30 minutes) - name the
+    rank and leave no rank behind."""
+    import time
+    t0 = time.monotonic()
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--windows", "32", "--steps", "1", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-extras", "--workload", workload],
+                         env=_env(standin, MOCHA_BENCH_ONE_GPU="1", MOCHA_BENCH_BACKEND="gloo", MOCHA_BENCH_FAIL_RANK="1"),
+                         capture_output=True, text=True, timeout=500)
+    dt = time.monotonic() - t0
+    assert out.returncode == 7, (out.returncode, out.stderr[-2000:])
+    assert "rank 1 exited with status 7" in out.stderr and "injected failure" in out.stderr
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert dt < 240, f"the launcher took {dt:.0f} s to give up"                    # start-up (imports, rendezvous) dominates; no 30-minute wait
 
 
 @pytest.mark.timeout(1500)
