@@ -234,7 +234,7 @@ def cpu_baseline(sd, V, n, mean, std):
 
 # CRC-32 of the 1024 matched bank rows of the bank4k workload on ONE GPU (`python bench.py --workload bank4k`, synthetic seeds 1 / 2 / 7):
 # the search is exact over the rounded bank, so an N-way split must reproduce it - `idx_matches_n1` in the N > 1 record.  Keyed by V.
-BANK4K_IDX_CRC32_N1 = {22: None, 24: None}
+BANK4K_IDX_CRC32_N1 = {22: 4269089464, 24: 2772088534}      # profiles/r04/a_bank4k_v22.json, a_bank4k_v24.json
 XGMI_LINK_GBS = 153.0            # one xGMI link, one direction (MI355X: 7 links per GPU, point-to-point)
 
 

@@ -69,6 +69,18 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 // the same on the bf16 matrix pipe with exact three-plane operands (attention_x3.hip): nq, nk <= 96, dh = 128 / 256
 hipError_t launch_attention_x3(const AttnParams& p, hipStream_t s);
 hipError_t attention_x3_init();              // one-time function attributes (dynamic LDS of the twelve-wave small-batch variant)
+// Cross-attention whose keys and values are the same for every head (the folded decoder: K = IN(cha), V = cha, dh = 256), from the
+// pre-split bf16 plane images mocha_instnorm writes (InormExtra::kvimg; layout: attention_kv.hip).  One workgroup per (window, head pair).
+static constexpr int ATTN_KV_STAGE_BYTES = 3 * 96 * 64;               // three planes x 96 rows x 32 bf16
+static constexpr int ATTN_KV_IMG_BYTES = 16 * ATTN_KV_STAGE_BYTES;    // 8 K stages + 8 V stages per window: 294 912 B
+struct AttnKvParams {
+    const float* q; float* out; const unsigned short* kv;
+    int ldq, ldo;                 // row strides in floats
+    int B, heads, dh, nq, nk;
+    float scale;
+    int pairs = 0;                // 1: a six-wave workgroup per head pair even when the heads come in fours (diagnostic)
+};
+hipError_t launch_attention_x3_kv(const AttnKvParams& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------
 // Small bandwidth-bound kernels
@@ -95,6 +107,9 @@ struct InormExtra {
     const float* centre = nullptr; float* zc = nullptr;      // zc: (z-score - centre), fp32
     unsigned short* zc16 = nullptr;                          // the same as bf16 (round to nearest even): the many-query bf16 pass's query plane
     const float* table = nullptr; const int32_t* row_idx = nullptr; long long table_rows = 0; float* copy_out = nullptr;
+    // kvimg: per window the pre-split key / value images of launch_attention_x3_kv (ATTN_KV_IMG_BYTES each): K = the normalised rows,
+    // V = the input rows, three bf16 planes each, rows n .. 95 zero
+    unsigned short* kvimg = nullptr;
 };
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
                            int B, int n, hipStream_t s, const InormExtra* ex = nullptr);

@@ -132,6 +132,12 @@ struct mocha_ctx {
     bool dual_stream = false; int dual_min = 128;     // opt-in: mocha_set_option(ctx, "dual_stream", 1) or MOCHA_DUAL_STREAM=1
     bool dual_ready = false;                          // ensure_ws allocated set 1 at full chunk size (a lane's set 1 holds 8 windows only)
     int attn_split_max = 192;                         // (window, head) pairs up to which the twelve-wave decoder attention is launched
+    // folded decoder, larger batches: attention from pre-split key / value images (attention_kv.hip).  OFF by default: measured at the demo
+    // step's 585 windows 197 us (twelve waves per window: three rounds of 256 workgroups) / 168 us (six waves per head pair) against 164 us
+    // for mocha_attention_x3<256>, plus 18 us more in the instance norm that writes the images; it wins only where the windows fit one
+    // round of CUs (256 windows: 75 against 89 us) - profiles/r04/b_attn_kv_ab.txt
+    bool attn_kv = false;
+    bool attn_kv_pairs = false;                       // ... with a six-wave workgroup per head pair instead of twelve waves per window (diagnostic)
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevBuf match_S[MAX_SETS];
     int32_t* idx_ws[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t idx_ws_n = 0;
@@ -344,6 +350,7 @@ int ensure_ws(mocha_ctx* c, int B) {
         {"qkv", 90 * 3072}, {"ao", 90 * 1024}, {"hff", 90 * 512}, {"kin", T}, {"xad", T}, {"qin", T},
         {"smean", 256}, {"s1", 512 * 8}, {"gb", 512 * 8}, {"qc", T}, {"g", 90 * 192}, {"y2c", (size_t)15 * V * 64},
         {"z", (size_t)60 * V * 64}, {"enc_s", T}, {"enc_c", T}, {"qnm", T}, {"sel", T}, {"dec", T},
+        {"kvimg", (size_t)ATTN_KV_IMG_BYTES / 4},          // the decoder attention's pre-split key / value images (attention_kv.hip)
     };
     // free old workspaces
     for (int set = 0; set < mocha_ctx::MAX_SETS; ++set) {
@@ -565,12 +572,17 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
                 const float* gather_table = nullptr, const int32_t* gather_idx = nullptr, long long gather_rows = 0) {
     const int M = b * 90, H = c->cfg.dec_heads, DH = c->cfg.dec_dim_head, inner = H * DH, L = c->cfg.dec_depth;
     // IN(cha) feeds every layer's keys; mean over tokens of cha feeds every layer's style MLP
-    if (gather_table) {
-        InormExtra ex; ex.table = gather_table; ex.row_idx = gather_idx; ex.table_rows = gather_rows; ex.copy_out = WS(c, "sel");
-        LAUNCH(c, s, "mocha_instnorm", "dec.in_cha", 0.0, b * 90.0 * 256 * 4 * 3, launch_instnorm(gather_table, WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s, &ex));
-        cha = WS(c, "sel");
-    } else {
-        LAUNCH(c, s, "mocha_instnorm", "dec.in_cha", 0.0, b * 90.0 * 256 * 4 * 2, launch_instnorm(cha, WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s));
+    // Folded decoder at batch size: keys IN(cha) and values cha are the same for every head and layer - the instance norm writes them once
+    // as pre-split bf16 plane images (InormExtra::kvimg) and every layer's attention reads those (attention_kv.hip); no fp32 copies
+    const bool use_kv = c->fold_decoder && DH == 256 && c->attn_x3 && c->attn_kv && H >= 2 && H % 2 == 0 && (long long)b * H > c->attn_split_max;
+    {
+        InormExtra ex;
+        if (gather_table) { ex.table = gather_table; ex.row_idx = gather_idx; ex.table_rows = gather_rows; ex.copy_out = use_kv ? nullptr : WS(c, "sel"); }
+        if (use_kv) ex.kvimg = reinterpret_cast<unsigned short*>(WS(c, "kvimg"));
+        const double wr = use_kv ? (double)ATTN_KV_IMG_BYTES * 90.0 / 96.0 : 90.0 * 256 * 4 * (gather_table ? 2 : 1);
+        LAUNCH(c, s, "mocha_instnorm", "dec.in_cha", 0.0, b * (90.0 * 256 * 4 + wr),
+               launch_instnorm(gather_table ? gather_table : cha, use_kv ? nullptr : WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s, &ex));
+        if (gather_table) cha = use_kv ? nullptr : WS(c, "sel");
     }
     // style MLPs of every layer at once: Linear 256->512, LeakyReLU, Linear 512->512 per layer          net/transformer.py:102-107
     GemmParams s1 = plain(WS(c, "smean"), 256, DW(c, "dec.Ws1_all"), WS(c, "s1"), 512 * L, b, 512 * L, 256);
@@ -602,9 +614,15 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
             // attention reads IN(cha) / cha directly for every head and two of the four projection GEMMs disappear.
             GemmParams gq = plain(WS(c, "qin"), 256, DW(c, p + ".Wqk"), qb, inner, M, inner, 256);
             GEMM(c, s, "dec.q", gq);
+            if (use_kv) {
+                AttnKvParams a{qb, WS(c, "ao"), reinterpret_cast<const unsigned short*>(WS(c, "kvimg")), inner, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5), c->attn_kv_pairs ? 1 : 0};
+                LAUNCH(c, s, "mocha_attention_x3_kv<256>", "dec.attn", 4.0 * b * H * 90.0 * 90 * DH, 4.0 * M * 2 * inner + (double)b * ATTN_KV_IMG_BYTES,
+                       launch_attention_x3_kv(a, s));
+            } else {
             AttnParams a{qb, WS(c, "kin"), cha, WS(c, "ao"), inner, 256, 256, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5), 0, 0};
             LAUNCH(c, s, attn_kernel_name(c, DH, (long long)b * H), "dec.attn", 4.0 * b * H * 90.0 * 90 * DH, 4.0 * M * (2 * inner + 2 * 256),
                    attention(c, a, s));
+            }
             float* out = (l == c->cfg.dec_depth - 1) ? outp : WS(c, "xa");
             int rc = run_out_ff(c, p, WS(c, "ao"), inner, WS(c, "xad"), M, c->cfg.dec_mlp, out, s, ".Wvo");
             if (rc) return rc;
@@ -2085,6 +2103,8 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "fold_joint") { c->fold_joint = value != 0; c->generation++; return 0; }
     if (n == "scan16") { c->scan16 = value != 0; c->generation++; return 0; }             // bank side takes effect at the next mocha_bank_set
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only
+    if (n == "attention_kv") { c->attn_kv = value != 0; c->generation++; return 0; }
+    if (n == "attention_kv_pairs") { c->attn_kv_pairs = value != 0; c->generation++; return 0; }
     if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; c->generation++; return 0; }
     if (n == "attention_bf16x3") { c->attn_x3 = value != 0; c->generation++; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);

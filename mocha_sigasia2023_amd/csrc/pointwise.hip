@@ -471,6 +471,20 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
             const int t = g + IN_NG * i;
             const f32x4 v = (xv[i] - mean) / den;
             if (out) ob[(size_t)t * 64] = v;                   // out == nullptr: only the z-scored copy is wanted (characterize: cnt itself is not an output)
+            if (ex.kvimg) {
+                // the decoder attention's key / value images (attention_kv.hip): this thread's four channels of token t, split into bf16
+                // planes - K from the normalised values, V from the input - 8 bytes per plane; eight neighbouring lanes fill a row's 64 bytes
+                unsigned char* img = reinterpret_cast<unsigned char*>(ex.kvimg) + (size_t)b * ATTN_KV_IMG_BYTES + (q >> 3) * ATTN_KV_STAGE_BYTES + t * 64;
+                u32x2_t pk[3], pv[3];
+                plane_split4(v, pk);
+                plane_split4(xv[i], pv);
+                const int kpos = ((((q & 7) >> 1) ^ ((t >> 2) & 3)) << 4) + ((q & 1) << 3);
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    *reinterpret_cast<u32x2_t*>(img + pl * (ATTN_KV_STAGE_BYTES / 3) + kpos) = pk[pl];
+                    *reinterpret_cast<u32x2_t*>(img + 8 * ATTN_KV_STAGE_BYTES + pl * (ATTN_KV_STAGE_BYTES / 3) + (q & 7) * 8) = pv[pl];
+                }
+            }
             if (zn) {
                 const f32x4 m = EARLY ? zm[EARLY ? i : 0] : reinterpret_cast<const f32x4*>(gm)[t * 64 + q];
                 const f32x4 sd = EARLY ? zs[EARLY ? i : 0] : reinterpret_cast<const f32x4*>(gs)[t * 64 + q];
@@ -486,6 +500,15 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
                 }
             }
         }
+    if (ex.kvimg && g < 96 - n) {                            // rows n .. 95 of both images: zero (a padded key's score is masked, its value row multiplies P = 0)
+        unsigned char* img = reinterpret_cast<unsigned char*>(ex.kvimg) + (size_t)b * ATTN_KV_IMG_BYTES + (q >> 3) * ATTN_KV_STAGE_BYTES + (n + g) * 64 + (q & 7) * 8;
+        const u32x2_t z = {0u, 0u};
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            *reinterpret_cast<u32x2_t*>(img + pl * (ATTN_KV_STAGE_BYTES / 3)) = z;
+            *reinterpret_cast<u32x2_t*>(img + 8 * ATTN_KV_STAGE_BYTES + pl * (ATTN_KV_STAGE_BYTES / 3)) = z;
+        }
+    }
 }
 
 // a handful of windows: four workgroups per window
@@ -497,6 +520,7 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
     if (n > IN_NG * IN_MAXT || n < 2) return hipErrorInvalidValue;
     InormExtra ex = exp ? *exp : InormExtra{};
     if (((ex.zc || ex.zc16) && (!zn || !ex.centre)) || (ex.row_idx && (!ex.table || ex.table_rows < 1))) return hipErrorInvalidValue;
+    if (ex.kvimg && n < 96 - IN_NG) return hipErrorInvalidValue;      // the image's zero rows n .. 95 are written by the first 96 - n token groups
     if (inorm_split(B)) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     else hipLaunchKernelGGL(mocha_instnorm<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     return hipGetLastError();

@@ -163,3 +163,40 @@ def test_twelve_wave_decoder_attention_against_the_three_wave_kernel(B):
     assert float((d_split - d_three).abs().max()) < 2e-6 * scale
     assert float((d_split - d_f32).abs().max()) < 2e-5 * scale
     assert not torch.equal(d_split, d_three) or B == 0           # it IS another kernel (a silent fallback would be bit-identical)
+
+
+@pytest.mark.parametrize("B", [49, 64, 200])
+def test_decoder_attention_from_key_value_images(B):
+    """VERDICT r3 item 4: with the decoder fold the keys IN(cha) and values cha are the same for all heads and layers;
+    mocha_instnorm writes them once as pre-split bf16 plane images and mocha_attention_x3_kv (one workgroup per window and head
+    pair) reads those.  Same arithmetic as mocha_attention_x3<256> on the fp32 rows (set_option("attention_kv", 0)): equal to
+    <= 1e-6 of the output's scale; and both against the exact-f32 MFMA attention.  B = 49 is the first batch past the
+    twelve-wave small-batch kernel (49 x 4 = 196 pairs > 192); 200 leaves a ragged last group of eight windows."""
+    sd = weights.synthetic_state_dict(21, 2.0)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    src = torch.from_numpy(synthetic.token_features(31, B)).to(dev())
+    cha = torch.from_numpy(synthetic.token_features(32, B)).to(dev())
+    out = {}
+    for name, kv, x3 in (("images", 1, 1), ("rows", 0, 1), ("f32", 0, 0)):
+        model.set_option("attention_kv", kv); model.set_option("attention_bf16x3", x3)
+        model.profile_start()
+        out[name] = model.decoder(src, cha).clone()
+        kern = model.profile_stop()["kernels"]
+        assert ("mocha_attention_x3_kv<256>" in kern) == (name == "images"), (name, sorted(kern))
+    model.set_option("attention_kv", 1); model.set_option("attention_bf16x3", 1)
+    scale = float(out["f32"].abs().max())
+    e_ir = float((out["images"] - out["rows"]).abs().max()); e_if = float((out["images"] - out["f32"]).abs().max())
+    print(f"[attention_kv] B = {B}: |images - rows| = {e_ir:.2e}, |images - exact f32| = {e_if:.2e}, max |out| = {scale:.3g}")
+    assert e_ir <= 1e-6 * scale and e_if <= 2e-6 * scale
+    # and through the gathered path (cha = bank rows picked by index, read by the instance norm itself)
+    mean, std = synthetic.cnt_norm(7)
+    X = torch.from_numpy(synthetic.pose_windows(33, B)).to(dev())
+    bank_X = torch.from_numpy(synthetic.pose_windows(34, 40)).to(dev())
+    e, _, nm = model.encode(bank_X, mean, std)
+    from mocha_sigasia2023_amd import ContextBank
+    bank = ContextBank(model, nm, e)
+    Y1, i1 = bank.characterize(X, mean, std, return_index=True)
+    model.set_option("attention_kv", 0)
+    Y0, i0 = bank.characterize(X, mean, std, return_index=True)
+    model.set_option("attention_kv", 1)
+    assert torch.equal(i0, i1) and float((Y1 - Y0).abs().max()) <= 1e-6 * max(1.0, float(Y0.abs().max()))
