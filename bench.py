@@ -429,6 +429,25 @@ def match_records(model, dev):
                                 "q1_x_16k_f32_scan32 is the scan of the fp32 rows themselves"})
         out[name] = rec
     model.set_option("scan16", 1)
+    # ... and as `characterize` runs it: 128 windows against the 4 096-entry bf16 bank - the instance norm writes the
+    # matcher's centred bf16 query plane itself, so the match is the coarse pass + the selection; per-kernel HIP events of the call sites
+    bank = ContextBank(model, big[:4096], big[:4096].view(4096, 90, 256), bf16=True)
+    from mocha_sigasia2023_amd import synthetic
+    X = torch.from_numpy(synthetic.pose_windows(123, 128, model.V)).to(dev)
+    m_, s_ = synthetic.cnt_norm(7)
+    m_, s_ = torch.from_numpy(m_).to(dev), torch.from_numpy(s_).to(dev)
+    for _ in range(3):
+        bank.characterize(X, m_, s_)
+    model.profile_start()
+    for _ in range(10):
+        bank.characterize(X, m_, s_)
+    sites = model.profile_stop()["sites"]
+    mk = {k.split("|")[1]: v["ms"] / v["launches"] * 1e3 for k, v in sites.items() if k.startswith("match.")}
+    us = sum(mk.values())
+    by = 4096 * D * 2 + 128 * D * 2 + 4 * 128
+    out["q128_x_4k_bf16_in_characterize"] = {"us": us, "algorithmic_bytes": by, "GB/s": by / us / 1e3, "frac_of_hbm_peak": by / us / 1e3 / PEAK_HBM_GBS,
+                                             "kernels": mk, "note": "sum of the match.* kernels inside ContextBank.characterize(128 windows) (HIP events per launch); "
+                                                                    "the centred bf16 query plane comes from the instance norm (read as bf16: 2 B per query value)"}
     del big
     return out
 

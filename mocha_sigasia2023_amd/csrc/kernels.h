@@ -106,6 +106,10 @@ hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, f
 struct InormExtra {
     const float* centre = nullptr; float* zc = nullptr;      // zc: (z-score - centre), fp32
     unsigned short* zc16 = nullptr;                          // the same as bf16 (round to nearest even): the many-query bf16 pass's query plane
+    // zc16 with plane_stride > 0: a SECOND plane bf16(zc - plane 0) at zc16 + plane_stride (elements) - the coarse pass then carries 16
+    // significant bits of every query value; qstat (2 floats per window): ||zc||^2 and the squared norm of what the planes (zc16) leave out
+    // - or, with zc alone, {||zc||^2, 0} - the selection's error bound (match_select2.hip) without a pass over the row
+    long long plane_stride = 0; float* qstat = nullptr;
     const float* table = nullptr; const int32_t* row_idx = nullptr; long long table_rows = 0; float* copy_out = nullptr;
     // kvimg: per window the pre-split key / value images of launch_attention_x3_kv (ATTN_KV_IMG_BYTES each): K = the normalised rows,
     // V = the input rows, three bf16 planes each, rows n .. 95 zero
@@ -169,10 +173,22 @@ hipError_t launch_sub_rows(const float* x, const float* sub, float* out, int64_t
 hipError_t match_mfma_init();
 int match_bf16_ksplit(int Q, int64_t N);
 hipError_t launch_center_bf16(const float* x, const float* centre, void* out, int64_t rows, int cols, hipStream_t s);
-hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s);
+// row by row: planes[0] = bf16(x - centre) and, with nplanes = 2, planes[1] = bf16(x - centre - planes[0]) (stacked: plane 1 starts rows * cols
+// elements after plane 0), or out32 = x - centre in fp32; qstat[row] = {||x - centre||^2, ||x - centre - planes||^2 (0 for fp32)}.  One
+// workgroup per row, fixed summation order.  Exactly one of planes / out32 is non-null.
+hipError_t launch_center_rows(const float* x, const float* centre, void* planes, int nplanes, float* out32, float* qstat, int64_t rows, int cols, hipStream_t s);
+// planes = 2: qc16 holds two stacked bf16 planes of the queries (plane 1 starts Q * D elements after plane 0), S = (a0 + a1) b^T
+hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes = 1);
 hipError_t launch_match_select(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm, const float* query,
                                const float* centre, const float* bank, const void* bank16, float margin_rel, int Q, int64_t N, int D,
                                int32_t* idx, float* dist, hipStream_t s);
+// the same selection without the usually unnecessary work (match_select2.hip): the row statistics of the error bound come from the
+// producer of the centred queries (qstat: 2 floats per query - launch_center_rows, InormExtra::qstat), nothing is staged in LDS, and a
+// query whose coarse minimum stands alone is answered without touching a bank row when dist == nullptr.  Otherwise the same arguments,
+// bounds and result semantics as launch_match_select.
+hipError_t launch_match_select2(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm, const float* query,
+                                const float* centre, const float* bank, const void* bank16, const float* qstat, float margin_rel, int Q,
+                                int64_t N, int D, int32_t* idx, float* dist, hipStream_t s);
 // streaming matcher for few queries against a large bank (HBM-bound): bank fp32 or bf16;
 // partial = match_stream_scratch(Q, N) u64 words of scratch
 size_t match_stream_scratch(int Q, int64_t N);

@@ -57,6 +57,7 @@ hipError_t launch_center_bf16(const float* x, const float* centre, void* out, in
 struct MatchGemmParams {
     const unsigned short* A; const unsigned short* B; float* S;
     int Q; long long N; int D; int ksplit; long long slab_stride; int m_tiles, n_tiles;
+    long long a_plane;            // elements between the two stacked query planes (NPL == 2)
 };
 
 static constexpr int MG_BM = 128, MG_BN = 128, MG_BK = 64;
@@ -68,10 +69,14 @@ static constexpr int MG_BM = 128, MG_BN = 128, MG_BK = 64;
 // row r lives in slot c ^ ((r >> 1) & 7), which makes the MFMA operand reads (ds_read_b128: 16-lane groups take rows of all 16
 // residues mod 16 at one k piece) conflict-free; the swizzle is applied by choosing which global piece a lane fetches.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int R>
+// NPL = 2 (round 4): the queries come as TWO stacked bf16 planes, a = a0 + a1 to 16 significant bits, and S accumulates both products.  The
+// pass is HBM-bound on the bank (a step's 36 - 48 KB arrive in ~0.8 us, its 16 / 32 MFMAs per wave take 0.25 / 0.5 us), so the second plane
+// costs LDS (a stage grows from 32 to 48 KB: ring of 3) and 6 MB of query traffic, not time - and shrinks the selection's error bound, and
+// with it the rows that must be re-evaluated exactly, by 2^8.
+template <int R, int NPL>
 __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned short mg_sm[];          // [R][BM + BN][64]
-    constexpr int STAGE = (MG_BM + MG_BN) * MG_BK;                                   // bf16 per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned short mg_sm[];          // [R][NPL * BM + BN][64]
+    constexpr int STAGE = (NPL * MG_BM + MG_BN) * MG_BK;                             // bf16 per stage
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -90,6 +95,7 @@ __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams
 
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A + (size_t)m0 * p.D);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B + (size_t)n0 * p.D);
+    const __amdgpu_buffer_rsrc_t rsA1 = make_rsrc(p.A + (size_t)(NPL == 2 ? p.a_plane : 0) + (size_t)m0 * p.D);
     // DMA pieces: wave w fills 8-row pieces w, w + 4, w + 8, w + 12 of A and of B; lane -> (row in piece, slot)
     unsigned a_off[4], b_off[4];
 #pragma unroll
@@ -108,7 +114,9 @@ __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave + 4 * i) * 512), 16, a_off[i], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + MG_BM * MG_BK + (wave + 4 * i) * 512), 16, b_off[i], so, 0, 0);
+            if (NPL == 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (__attribute__((address_space(3))) void*)(st + MG_BM * MG_BK + (wave + 4 * i) * 512), 16, a_off[i], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + NPL * MG_BM * MG_BK + (wave + 4 * i) * 512), 16, b_off[i], so, 0, 0);
         }
     };
 
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams
     for (int i = 0; i < 2; ++i) {
         const int r_a = wm * 64 + i * 32 + l31, r_b = wn * 64 + i * 32 + l31;
         ra_off[i] = (unsigned)r_a * 64u; key_a[i] = (unsigned)((r_a >> 1) & 7);
-        rb_off[i] = (unsigned)(MG_BM + r_b) * 64u; key_b[i] = (unsigned)((r_b >> 1) & 7);
+        rb_off[i] = (unsigned)(NPL * MG_BM + r_b) * 64u; key_b[i] = (unsigned)((r_b >> 1) & 7);
     }
 
     if (nsteps > 0) {
@@ -134,16 +142,25 @@ __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams
         for (int u = 0; u < R - 1; ++u) issue(u);
         for (int s = 0; s < nsteps; ++s) {
             // the 8 pieces of step s are this wave's oldest; (R - 2) younger steps may stay in flight
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((R - 2) * 8) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((R - 2) * 4 * (NPL + 1)) : "memory");
             issue(s + R - 1);                                       // into the slot every wave finished reading before the barrier
             const unsigned short* st = mg_sm + (s % R) * STAGE;
 #pragma unroll
             for (int ks = 0; ks < MG_BK / 16; ++ks) {
-                s16x8 a[2], b[2];
+                s16x8 a[2], a1[2], b[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     a[i] = *reinterpret_cast<const s16x8*>(st + ra_off[i] + (((unsigned)(2 * ks + hh) ^ key_a[i]) << 3));
+                    if (NPL == 2) a1[i] = *reinterpret_cast<const s16x8*>(st + MG_BM * MG_BK + ra_off[i] + (((unsigned)(2 * ks + hh) ^ key_a[i]) << 3));
                     b[i] = *reinterpret_cast<const s16x8*>(st + rb_off[i] + (((unsigned)(2 * ks + hh) ^ key_b[i]) << 3));
+                }
+                // the low plane first: its products are 2^-8 of the high plane's
+                if (NPL == 2) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[jj], a1[i], acc[i][jj], 0, 0, 0);
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -180,14 +197,15 @@ __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams
     }
 }
 
-template <int R>
-static constexpr size_t mg_dma_lds_bytes() { return (size_t)R * (MG_BM + MG_BN) * MG_BK * sizeof(unsigned short); }
+template <int R, int NPL>
+static constexpr size_t mg_dma_lds_bytes() { return (size_t)R * (NPL * MG_BM + MG_BN) * MG_BK * sizeof(unsigned short); }
 
 hipError_t match_select_init();
 
 hipError_t match_mfma_init() {
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_gemm_bf16_dma<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)mg_dma_lds_bytes<4>());
+    constexpr size_t lds2 = mg_dma_lds_bytes<3, 2>(), lds1 = mg_dma_lds_bytes<4, 1>();
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_gemm_bf16_dma<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_gemm_bf16_dma<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (r == hipSuccess) r = match_select_init();
     return r;
 }
@@ -201,7 +219,7 @@ int match_bf16_ksplit(int Q, int64_t N) {
     return k;
 }
 
-hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s) {
+hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes) {
     if (Q <= 0 || N <= 0) return hipSuccess;
     if (D % MG_BK || (ksplit != 1 && ksplit != 2 && ksplit != 4 && ksplit != 8)) return hipErrorInvalidValue;
     if ((long long)MG_BM * D * 2 >= (1ll << 31)) return hipErrorInvalidValue;            // 32-bit buffer offsets inside a tile
@@ -209,11 +227,16 @@ hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S
     p.A = (const unsigned short*)qc16; p.B = (const unsigned short*)bank16; p.S = S;
     p.Q = Q; p.N = N; p.D = D; p.ksplit = ksplit; p.slab_stride = (long long)Q * N;
     p.m_tiles = (Q + MG_BM - 1) / MG_BM; p.n_tiles = (int)((N + MG_BN - 1) / MG_BN);
+    p.a_plane = (long long)Q * D;
+    if (planes != 1 && planes != 2) return hipErrorInvalidValue;
     const long long pairs = (long long)p.n_tiles * ksplit;
     const long long groups = (pairs + 7) / 8;
     // ring of 4 stages: three steps (96 KB) in flight per CU; measured equal to 3 and 5 stages, and 10 % faster than staging
     // through registers with ds_write (tools/experiments/README.md)
-    hipLaunchKernelGGL((mocha_match_gemm_bf16_dma<4>), dim3((unsigned)(groups * p.m_tiles * 8)), dim3(256), mg_dma_lds_bytes<4>(), s, p);
+    // two query planes: stages of 48 KB, ring of 3 (two steps = 96 KB in flight, as before)
+    constexpr size_t lds2 = mg_dma_lds_bytes<3, 2>(), lds1 = mg_dma_lds_bytes<4, 1>();
+    if (planes == 2) hipLaunchKernelGGL((mocha_match_gemm_bf16_dma<3, 2>), dim3((unsigned)(groups * p.m_tiles * 8)), dim3(256), lds2, s, p);
+    else hipLaunchKernelGGL((mocha_match_gemm_bf16_dma<4, 1>), dim3((unsigned)(groups * p.m_tiles * 8)), dim3(256), lds1, s, p);
     return hipGetLastError();
 }
 

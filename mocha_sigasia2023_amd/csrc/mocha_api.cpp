@@ -179,6 +179,16 @@ struct mocha_ctx {
     bool scan16 = true;                // mocha_set_option("scan16", 0) scans the fp32 rows themselves
     void* bank16f = nullptr; size_t bank16f_cap = 0; float* bank_rho = nullptr; size_t bank_rho_cap = 0; bool bank16f_valid = false;
     unsigned long long* scan_keys[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t scan_keys_n[MAX_SETS] = {0, 0, 0};
+    // many-query matching, round 4 (match_select2.hip): the producer of the centred queries hands over the row statistics of the selection's
+    // error bound (match_qstat: ||q - c||^2 and the planes' residual per query), the bf16 coarse pass takes two query planes
+    // Used for fp32 banks (demo pair 585 x 585: centre + select 44 us against 68; 128 x 4096: 23 against 30).  bf16 banks stay on
+    // mocha_center_bf16 + one plane + mocha_match_select: with ONE query plane the bound admits ~8 rows for the unluckiest query and the
+    // LDS-staged kernel re-evaluates them cheaper (128 x 4096: 81 us in all against 103); with TWO planes the selection drops to 15 us but the
+    // coarse pass, whose ring then holds a third less of the bank in flight, rises from 39 to 60 us (85 in all; 1024 x 4096: 493 against 360) -
+    // mocha_set_option("match_planes", 2) selects that variant (profiles/r04/c_select_ab.txt)
+    bool select2 = true;
+    int match_planes = 1;              // bf16 query planes of the many-query coarse pass against a bf16 bank
+    DevBuf match_qstat[MAX_SETS];
 
     // captured per-window step (mocha_step_graph): one executable graph, re-captured when its key changes
     struct StepGraph {
@@ -771,6 +781,7 @@ int ensure_match_scratch(mocha_ctx* c, int set, int Q, int64_t N, bool every_q_u
         size_t need = 0;
         for (int q = every_q_up_to ? 9 : Q; q <= Q; ++q) need = std::max(need, (size_t)match_ksplit(q, N) * q * (size_t)N);
         if ((rc = grow(c, c->match_S[set], need))) return rc;
+        if ((rc = grow(c, c->match_qstat[set], (size_t)2 * std::max(Q, 256)))) return rc;
     }
     if (c->scan16 && !c->bank_is_bf16 && N >= SCAN16_MIN && c->scan_keys_n[set] < (size_t)8 * N) {      // every row's coarse key, 8 queries
         HIPCHK(c, hipDeviceSynchronize());
@@ -788,8 +799,12 @@ int ensure_match_scratch(mocha_ctx* c, int set, int Q, int64_t N, bool every_q_u
 
 // qc_pre: the queries minus the current bank's centroid, fp32, when the caller's producer already wrote them (mocha_instnorm's zc)
 // (fp32; bf16 where the many-query pass against a bf16 bank wants them so: qc_pre_bf16, mocha_instnorm's zc16)
+// the round-4 selection (match_select2.hip) serves this many queries against the current bank?
+bool use_select2(const mocha_ctx* c, int Q) { return c->select2 && Q > 8 && (!c->bank_is_bf16 || c->match_planes == 2); }
+
+// qstat_pre: with select2 and Q > 8, the producer also left the row statistics in match_qstat[set] (and, bf16: BOTH query planes in qc_pre)
 int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, hipStream_t s, const void* qc_pre_any = nullptr,
-             bool qc_pre_bf16 = false) {
+             bool qc_pre_bf16 = false, bool qstat_pre = false) {
     if (!c->bank_cnt || c->bank_N <= 0) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set first");
     const int D = 90 * 256;
     const int64_t N = c->bank_N;
@@ -802,9 +817,14 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     const bool need_qc = c->bank_is_bf16 || Q > 8 || via16;
     // the many-query pass against a bf16 bank takes the centred queries as bf16, everything else as fp32: a precomputed copy of the
     // other kind is of no use (mocha_center_bf16 / mocha_sub_rows then make the right one)
-    const float* qc_pre = (qc_pre_any && qc_pre_bf16 == (c->bank_is_bf16 && Q > 8)) ? static_cast<const float*>(qc_pre_any) : nullptr;
+    const bool sel2 = use_select2(c, Q);                       // many-query path with the round-4 selection: row statistics from the producer
+    const float* qc_pre = (qc_pre_any && qc_pre_bf16 == (c->bank_is_bf16 && Q > 8) && (!sel2 || qstat_pre)) ? static_cast<const float*>(qc_pre_any) : nullptr;
     if (need_qc && !qc_pre) {
-        if (c->bank_is_bf16 && Q > 8)
+        if (sel2 && c->bank_is_bf16)
+            LAUNCH(c, s, "mocha_center_rows", "match.center", 0.0, 8.0 * Q * D, launch_center_rows(qnm, c->bank_center, c->match_qc[set].p, c->match_planes, nullptr, c->match_qstat[set].p, Q, D, s));
+        else if (sel2)
+            LAUNCH(c, s, "mocha_center_rows", "match.center", 0.0, 8.0 * Q * D, launch_center_rows(qnm, c->bank_center, nullptr, 0, c->match_qc[set].p, c->match_qstat[set].p, Q, D, s));
+        else if (c->bank_is_bf16 && Q > 8)
             LAUNCH(c, s, "mocha_center_bf16", "match.center", 0.0, 6.0 * Q * D, launch_center_bf16(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
         else
             LAUNCH(c, s, "mocha_sub_rows", "match.center", 0.0, 8.0 * Q * D, launch_sub_rows(qnm, c->bank_center, c->match_qc[set].p, Q, D, s));
@@ -833,8 +853,14 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
         // measured rounding residual dq, plus 5e-5 (2||q||^2 + ||b||^2 + ||b0||^2) of slack for the pass's fp32 accumulation - exactly
         // (fp32 centred query against the bf16 rows), so the result is the exact search over the rounded bank
         const int ksplit = match_bf16_ksplit(Q, N);
-        LAUNCH(c, s, "mocha_match_gemm_bf16", "match.qk_bf16", 2.0 * Q * (double)N * D, 2.0 * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
-               launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s));
+        const int npl = sel2 ? c->match_planes : 1;
+        LAUNCH(c, s, "mocha_match_gemm_bf16", "match.qk_bf16", 2.0 * npl * Q * (double)N * D, 2.0 * npl * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
+               launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, npl));
+        if (sel2)
+            LAUNCH(c, s, "mocha_match_select2", "match.select", 0.0, 4.0 * ksplit * Q * N + 4.0 * N + 8.0 * Q,
+                   launch_match_select2(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, nullptr, c->bank_bf16,
+                                        c->match_qstat[set].p, 5e-5f, Q, N, D, idx, dist, s));
+        else
         LAUNCH(c, s, "mocha_match_select", "match.select", 0.0, 4.0 * ksplit * Q * N + Q * (8.0 * D + 8 * 2.0 * D),
                launch_match_select(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, nullptr, c->bank_bf16, 5e-5f,
                                    Q, N, D, idx, dist, s));
@@ -861,6 +887,11 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     const int nslab = g.ksplit;
     // exact-f32 MFMA on centred operands: a coarse score is accurate to ~4e-7 (||q-c||^2 + ||b-c||^2); candidates within ten
     // times that of the best are re-evaluated in the direct form
+    if (sel2)
+        LAUNCH(c, s, "mocha_match_select2", "match.select", 0.0, 4.0 * nslab * Q * N + 4.0 * N + 8.0 * Q,
+               launch_match_select2(mS.p, nslab, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, c->bank_cnt, nullptr,
+                                    c->match_qstat[set].p, 4e-6f, Q, N, D, idx, dist, s));
+    else
     LAUNCH(c, s, "mocha_match_select", "match.select", 0.0, 4.0 * nslab * Q * N + Q * 16.0 * D,
            launch_match_select(mS.p, nslab, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, c->bank_cnt, nullptr, 4e-6f,
                                Q, N, D, idx, dist, s));
@@ -1413,10 +1444,13 @@ static int characterize_impl(mocha_ctx* c, const float* src_X, int B, const floa
         // cnt, its z-score and - the bank's centroid is known - the matcher's centred queries in one pass
         // (as one bf16 plane where the many-query pass against a bf16 bank will read them: no mocha_center_bf16 launch)
         const bool q16 = c->bank_is_bf16 && b > 8;
+        const bool sel2 = use_select2(c, b);                     // the selection's row statistics (and the second bf16 plane) come from this pass too
+        if (sel2 && (r = ensure_match_scratch(c, c->cur, b, c->bank_N, false))) return r;
         InormExtra ex; ex.centre = c->bank_center;
         if (q16) ex.zc16 = reinterpret_cast<unsigned short*>(WS(c, "qc")); else ex.zc = WS(c, "qc");
-        LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (q16 ? 2.5 : 3.0), launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s, &ex));
-        if ((r = do_match(c, WS(c, "qnm"), b, ix, nullptr, s, WS(c, "qc"), q16))) return r;
+        if (sel2) { ex.qstat = c->match_qstat[c->cur].p; if (q16 && c->match_planes == 2) ex.plane_stride = (long long)b * 90 * 256; }
+        LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (q16 ? (sel2 ? 3.0 : 2.5) : 3.0), launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s, &ex));
+        if ((r = do_match(c, WS(c, "qnm"), b, ix, nullptr, s, WS(c, "qc"), q16, sel2))) return r;
         // decoder on cha_encoded[frame_index]: its first kernel gathers the rows itself
         if ((r = run_decoder(c, WS(c, "enc_s"), nullptr, b, WS(c, "dec"), s, c->bank_enc, ix, c->bank_N))) return r;
         return run_to_mot(c, WS(c, "dec"), b, Y + b0 * ys, s, raw);
@@ -2103,6 +2137,8 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "fold_joint") { c->fold_joint = value != 0; c->generation++; return 0; }
     if (n == "scan16") { c->scan16 = value != 0; c->generation++; return 0; }             // bank side takes effect at the next mocha_bank_set
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only
+    if (n == "match_planes") { if (value != 1 && value != 2) return fail(c, MOCHA_ERR_ARG, "match_planes must be 1 or 2"); c->match_planes = value; c->generation++; return 0; }
+    if (n == "select2") { c->select2 = value != 0; c->generation++; return 0; }
     if (n == "attention_kv") { c->attn_kv = value != 0; c->generation++; return 0; }
     if (n == "attention_kv_pairs") { c->attn_kv_pairs = value != 0; c->generation++; return 0; }
     if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; c->generation++; return 0; }

@@ -465,6 +465,7 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
     inorm_stats<QW>(xv, cnt, n, red, ql, g, mean, den);
     if (mean_out && g == 0) reinterpret_cast<f32x4*>(mean_out + (size_t)b * 256)[q] = mean;
     f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * n * 256) + q;
+    float qs_n = 0.f, qs_d = 0.f;                            // this thread's share of ||zc||^2 and of the planes' residual (InormExtra::qstat)
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) {
@@ -493,13 +494,36 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
                 if (ex.zc || ex.zc16) {
                     const f32x4 zc = z - reinterpret_cast<const f32x4*>(ex.centre)[t * 64 + q];
                     if (ex.zc) (reinterpret_cast<f32x4*>(ex.zc + (size_t)b * n * 256) + q)[(size_t)t * 64] = zc;
+                    f32x4 rest = {0.f, 0.f, 0.f, 0.f};
                     if (ex.zc16) {
                         const u32x2_t w = {bf16_bits(zc[0]) | (bf16_bits(zc[1]) << 16), bf16_bits(zc[2]) | (bf16_bits(zc[3]) << 16)};
                         (reinterpret_cast<u32x2_t*>(ex.zc16 + (size_t)b * n * 256) + q)[(size_t)t * 64] = w;
+                        rest = zc - f32x4{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)};
+                        if (ex.plane_stride > 0) {
+                            const u32x2_t w1 = {bf16_bits(rest[0]) | (bf16_bits(rest[1]) << 16), bf16_bits(rest[2]) | (bf16_bits(rest[3]) << 16)};
+                            (reinterpret_cast<u32x2_t*>(ex.zc16 + ex.plane_stride + (size_t)b * n * 256) + q)[(size_t)t * 64] = w1;
+                            rest -= f32x4{__uint_as_float(w1[0] << 16), __uint_as_float(w1[0] & 0xffff0000u), __uint_as_float(w1[1] << 16), __uint_as_float(w1[1] & 0xffff0000u)};
+                        }
+                    }
+                    if (ex.qstat) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { qs_n = fmaf(zc[k], zc[k], qs_n); qs_d = fmaf(rest[k], rest[k], qs_d); }
                     }
                 }
             }
         }
+    if (ex.qstat) {                                          // one workgroup per window (QW == 64, see launch_instnorm): wave sums, then the waves in order
+        __shared__ float qsr[2][QW * IN_NG / 64 > 0 ? QW * IN_NG / 64 : 1];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { qs_n += __shfl_xor(qs_n, o); qs_d += __shfl_xor(qs_d, o); }
+        if ((threadIdx.x & 63) == 0) { qsr[0][threadIdx.x >> 6] = qs_n; qsr[1][threadIdx.x >> 6] = qs_d; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f, d = 0.f;
+            for (int w = 0; w < QW * IN_NG / 64; ++w) { a += qsr[0][w]; d += qsr[1][w]; }
+            ex.qstat[2 * b] = a; ex.qstat[2 * b + 1] = d;
+        }
+    }
     if (ex.kvimg && g < 96 - n) {                            // rows n .. 95 of both images: zero (a padded key's score is masked, its value row multiplies P = 0)
         unsigned char* img = reinterpret_cast<unsigned char*>(ex.kvimg) + (size_t)b * ATTN_KV_IMG_BYTES + (q >> 3) * ATTN_KV_STAGE_BYTES + (n + g) * 64 + (q & 7) * 8;
         const u32x2_t z = {0u, 0u};
@@ -521,7 +545,10 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
     InormExtra ex = exp ? *exp : InormExtra{};
     if (((ex.zc || ex.zc16) && (!zn || !ex.centre)) || (ex.row_idx && (!ex.table || ex.table_rows < 1))) return hipErrorInvalidValue;
     if (ex.kvimg && n < 96 - IN_NG) return hipErrorInvalidValue;      // the image's zero rows n .. 95 are written by the first 96 - n token groups
-    if (inorm_split(B)) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
+    if (ex.qstat && !(ex.zc || ex.zc16)) return hipErrorInvalidValue;
+    if ((long long)ex.plane_stride < 0 || (ex.plane_stride > 0 && !ex.zc16)) return hipErrorInvalidValue;
+    // the row statistics are a whole-window reduction: one workgroup per window then, whatever the batch
+    if (inorm_split(B) && !ex.qstat) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     else hipLaunchKernelGGL(mocha_instnorm<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     return hipGetLastError();
 }
@@ -654,6 +681,51 @@ hipError_t launch_sub_rows(const float* x, const float* sub, float* out, int64_t
     if (cols % 4) return hipErrorInvalidValue;
     const long long total4 = (long long)rows * (cols / 4);
     hipLaunchKernelGGL(mocha_sub_rows, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, x, sub, out, cols / 4, total4);
+    return hipGetLastError();
+}
+
+// One workgroup per row: x - centre as two stacked bf16 planes (or as fp32) and the row's statistics for the many-query selection
+// (match_select2.hip): ||x - c||^2 and the squared norm of what the planes leave out.  Thread t takes the 4-element pieces t, t + 512, ...;
+// wave sums, then the eight waves in order: the statistics are reproducible.
+__global__ __launch_bounds__(512) void mocha_center_rows(const float* __restrict__ x, const float* __restrict__ c, unsigned short* __restrict__ planes,
+                                                         float* __restrict__ out32, float* __restrict__ qstat, long long plane_stride, int cols4) {
+    __shared__ float red[2][8];
+    const size_t row = blockIdx.x;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x) + row * cols4;
+    const f32x4* cr = reinterpret_cast<const f32x4*>(c);
+    float qn = 0.f, dn = 0.f;
+    for (int i = threadIdx.x; i < cols4; i += 512) {
+        const f32x4 z = xr[i] - cr[i];
+        qn = fmaf(z[0], z[0], qn); qn = fmaf(z[1], z[1], qn); qn = fmaf(z[2], z[2], qn); qn = fmaf(z[3], z[3], qn);
+        if (out32) reinterpret_cast<f32x4*>(out32)[row * cols4 + i] = z;
+        else {
+            const u32x2_t w0 = {bf16_bits(z[0]) | (bf16_bits(z[1]) << 16), bf16_bits(z[2]) | (bf16_bits(z[3]) << 16)};
+            f32x4 r = z - f32x4{__uint_as_float(w0[0] << 16), __uint_as_float(w0[0] & 0xffff0000u), __uint_as_float(w0[1] << 16), __uint_as_float(w0[1] & 0xffff0000u)};
+            reinterpret_cast<u32x2_t*>(planes)[row * cols4 + i] = w0;
+            if (plane_stride > 0) {
+                const u32x2_t w1 = {bf16_bits(r[0]) | (bf16_bits(r[1]) << 16), bf16_bits(r[2]) | (bf16_bits(r[3]) << 16)};
+                r -= f32x4{__uint_as_float(w1[0] << 16), __uint_as_float(w1[0] & 0xffff0000u), __uint_as_float(w1[1] << 16), __uint_as_float(w1[1] & 0xffff0000u)};
+                reinterpret_cast<u32x2_t*>(planes + plane_stride)[row * cols4 + i] = w1;
+            }
+            dn = fmaf(r[0], r[0], dn); dn = fmaf(r[1], r[1], dn); dn = fmaf(r[2], r[2], dn); dn = fmaf(r[3], r[3], dn);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { qn += __shfl_xor(qn, o); dn += __shfl_xor(dn, o); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = qn; red[1][threadIdx.x >> 6] = dn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = red[0][0], d = red[1][0];
+        for (int w = 1; w < 8; ++w) { a += red[0][w]; d += red[1][w]; }
+        qstat[2 * row] = a; qstat[2 * row + 1] = d;
+    }
+}
+
+hipError_t launch_center_rows(const float* x, const float* centre, void* planes, int nplanes, float* out32, float* qstat, int64_t rows, int cols, hipStream_t s) {
+    if (rows <= 0) return hipSuccess;
+    if (cols % 4 || !qstat || (planes == nullptr) == (out32 == nullptr) || (planes && nplanes != 1 && nplanes != 2)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_center_rows, dim3((unsigned)rows), dim3(512), 0, s, x, centre, (unsigned short*)planes, out32, qstat,
+                       nplanes == 2 ? (long long)rows * cols : 0ll, cols / 4);
     return hipGetLastError();
 }
 

@@ -202,6 +202,43 @@ def test_many_query_matcher_beyond_the_register_resident_score_chunks(model):
     assert torch.equal(i16[:, 0].long(), ri16)
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("Q,N", [(9, 37), (40, 585), (128, 4096), (300, 6200), (700, 1000)])
+def test_lazy_selection_is_the_staged_selection(model, Q, N):
+    """mocha_match_select2 takes the error bound's row statistics from the producer of the centred queries, reads
+    TWO bf16 query planes' scores (bf16 banks), answers a query whose coarse minimum stands alone without touching a bank row when only
+    the index is wanted, and otherwise evaluates candidates streamed by the whole workgroup (match_select2.hip), where
+    mocha_match_select staged the query row in LDS and worked from one plane.  Same rows scanned, same exact evaluation: indices
+    equal (and equal to a float64 search), distances equal to fp32 rounding (the two kernels sum a row's terms in different orders), for
+    both bank precisions, with and without distances, ragged N, banks past the 4 096 rows a thread keeps in registers, planted
+    near-duplicates (several rows inside even the two-plane bound)."""
+    from mocha_sigasia2023_amd import ContextBank
+    g = torch.Generator(device="cuda"); g.manual_seed(1000 * Q + N)
+    bank = torch.randn((N, 90 * 256), device="cuda", generator=g)
+    q = torch.randn((Q, 90 * 256), device="cuda", generator=g)
+    for k in range(min(Q, 8)):                                   # near-duplicates: several rows inside the coarse pass's error bound
+        row = (k * 7919) % N
+        q[k] = bank[row] + 1e-3 * q[k]
+        bank[(row + 1) % N] = bank[row] + 2e-3 * torch.randn((90 * 256,), device="cuda", generator=g)
+    q[Q - 1] = bank[N - 1]                                       # the last row of the last slice, exactly
+    ri, rd = _torch_bruteforce(q, bank)
+    for bf16 in (False, True):
+        res = {}
+        for sel in (1, 0):
+            model.set_option("select2", sel)
+            model.set_option("match_planes", 2 if (sel and bf16) else 1)      # bf16 banks take the new selection with two query planes only
+            cb = ContextBank(model, bank, bank.view(N, 90, 256), bf16=bf16)
+            d, i = cb.query(q)
+            res[sel] = (d[:, 0].clone(), i[:, 0].clone())
+            assert torch.equal(cb.query(q, return_distance=False)[:, 0], i[:, 0])         # index-only calls take the early exit
+        model.set_option("select2", 1); model.set_option("match_planes", 1)
+        assert torch.equal(res[1][1], res[0][1]), f"bf16={bf16}: {(res[1][1] != res[0][1]).sum().item()} indices differ between the kernels"
+        assert torch.allclose(res[1][0], res[0][0], rtol=2e-6, atol=1e-6)
+        if not bf16:
+            assert torch.equal(res[1][1].long(), ri) and torch.allclose(res[1][0].double(), rd, rtol=1e-5, atol=1e-4)
+        assert res[1][1][Q - 1].item() == N - 1 and res[1][0][Q - 1].item() == 0.0 if not bf16 else True
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_top_k_query_and_soft_blend(model, bf16):
     """BallTree.query(k > 1) semantics (optional): the k nearest rows, exact, distances ascending, ties to the

@@ -169,8 +169,22 @@ def test_config4_streamed_clip_x_16k_bank():
                 assert torch.equal(y2, Ys[i]) and int(idx2.item()) == idx_stream[i]
         # streamed (scan kernel) and batched (GEMM + re-rank) matchers pick the same rows; outputs equal up to the kernel
         # choice of a 1-window batch (fp32 summation order)
-        assert np.array_equal(idx_stream, ib.cpu().numpy())
-        assert float((Ys - Yb).abs().max()) < 2e-5
+        # (two rows whose fp32 distances are EQUAL are a tie whatever float64 says: the two matchers sum a row's terms in different orders
+        # and may then name different rows - the planted copies differ by 1e-3 of a noise vector and collapse to one distance on the
+        # bf16-rounded bank now and then; such a pair must be a float64 near-tie, and its window is left out of the pose comparison)
+        ib_np = ib.cpu().numpy().astype(np.int64)
+        diff = np.nonzero(idx_stream != ib_np)[0]
+        if len(diff):
+            qs = model.encode(src[diff], mean, std)[2].reshape(len(diff), -1).double()
+            rows_s, rows_b = bank.cnt_nm[idx_stream[diff]].double(), bank.cnt_nm[ib_np[diff]].double()
+            if bf16:
+                cen = bank.cnt_nm.double().mean(0)
+                rnd = lambda t: torch.from_numpy(_bf16_round((t - cen).float().cpu().numpy())).to(t.device).double()
+                rows_s, rows_b, qs = rnd(rows_s), rnd(rows_b), qs - cen
+            ds, db = (qs - rows_s).norm(dim=1), (qs - rows_b).norm(dim=1)
+            assert len(diff) <= 3 and bool(((ds - db).abs() <= 2e-6 * ds).all()), (diff, ds, db)
+        keep = np.setdiff1d(np.arange(W), diff)
+        assert float((Ys[keep] - Yb[keep]).abs().max()) < 2e-5
         # indices against the float64 search on the HIP features, outputs against the oracle on a sample
         _, _, nm_s = model.encode(src, mean, std)
         q = nm_s.cpu().numpy().reshape(W, -1)
@@ -182,6 +196,7 @@ def test_config4_streamed_clip_x_16k_bank():
             ridx, _ = O.match_bruteforce(q, bank_np)
         assert np.array_equal(idx_stream, ridx)
         assert len(set(idx_stream.tolist())) == W and (bf16 or np.array_equal(idx_stream, planted))
+        assert len(diff) == 0 or bf16                     # fp32 rows: the copies stay 1e-3 apart, no ties
         sel = np.arange(0, W, 19)
         with torch.no_grad():
             eo, _ = O.encode(ost, src.cpu()[sel])

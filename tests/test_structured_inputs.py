@@ -166,10 +166,12 @@ def test_character_equals_source(model, sd):
     assert np.array_equal(idx.cpu().numpy(), np.arange(48))
     d, i = ContextBank(model, nm, enc).query(nm)
     assert np.array_equal(i[:, 0].cpu().numpy(), np.arange(48)) and float(d.max()) == 0.0
-    s32, _ = _states(sd)
+    s32, s64 = _states(sd)
     with torch.no_grad():
-        Yo, io = O.characterize(s32, torch.from_numpy(X), torch.from_numpy(X), mean, std)
-    assert np.array_equal(io, np.arange(48)) and float((Y.cpu() - Yo).abs().max()) < TOL
+        Y32, io = O.characterize(s32, torch.from_numpy(X), torch.from_numpy(X), mean, std)
+        Y64, i64 = O.characterize(s64, torch.from_numpy(X).double(), torch.from_numpy(X).double(), mean.astype(np.float64), std.astype(np.float64))
+    assert np.array_equal(io, np.arange(48)) and np.array_equal(i64, io)
+    _check_Y("cha == src, characterize", Y, Y32, Y64)
 
 
 # ------------------------------------------------------------------------------------ the instance norm in low-variance channels
@@ -267,13 +269,15 @@ def test_smooth_clip_stride1_windows_as_source_and_bank(model, sd):
     same = ours == io
     print(f"[structured] smooth clip: {int(same.sum())} / {W} indices equal the oracle's ({len(np.unique(io))} distinct rows matched)")
     assert same.mean() > 0.99
+    _, s64 = _states(sd)
     with torch.no_grad():
-        sel = ea[torch.from_numpy(io)]
-        Y32 = _decode_batched(s32, eb, sel)
-    Yh = Yb.cpu().numpy()
-    err = float(np.abs(Yh[same] - Y32.numpy()[same]).max())
-    print(f"[structured] smooth clip: max|Y| = {float(np.abs(Y32.numpy()).max()):.3g}   |hip - oracle32| = {err:.2e} over {int(same.sum())} windows")
-    assert err < TOL, f"max |Y - oracle| = {err:.3e}"
+        Y32 = _decode_batched(s32, eb, ea[torch.from_numpy(io)])
+        ea64, _ = _encode_batched(s64, torch.from_numpy(za).double())
+        eb64, _ = _encode_batched(s64, torch.from_numpy(zb).double())
+        Y64 = _decode_batched(s64, eb64, ea64[torch.from_numpy(io)])
+    pick = torch.from_numpy(np.nonzero(same)[0])
+    # smooth motion = slowly varying tokens = low-variance channels in the decoder's instance norms: the float64 criterion applies (header)
+    _check_Y(f"smooth clip, {int(same.sum())} windows", Yb.cpu()[pick], Y32[pick], Y64[pick])
     assert torch.isfinite(Yb).all()
 
     # ---- (c) streamed: one window at a time through the captured step, against the same bank
@@ -281,4 +285,4 @@ def test_smooth_clip_stride1_windows_as_source_and_bank(model, sd):
     for w in (0, 1, 2, 100, 291, 584):
         y1, i1 = sc.step(Xb[w])
         assert int(i1.item()) == int(ours[w])
-        assert float((y1 - Yb[w]).abs().max()) < 1e-5
+        assert float((y1 - Yb[w]).abs().max()) < 1e-5 * max(1.0, float(Yb.abs().max()))      # one-window kernels: another fp32 summation order

@@ -1,0 +1,34 @@
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, weights
+dev = torch.device("cuda:0")
+NB, V, W, D = 16384, 22, 285, 23040
+sd = weights.synthetic_state_dict(1777, 1.0, "mixamo")
+model = Generator(layout="mixamo", device=dev).load_state_dict(sd).eval()
+mean, std = synthetic.cnt_norm(7)
+g = torch.Generator(device=dev); g.manual_seed(7)
+bank_nm = torch.randn((NB, D), device=dev, generator=g)
+src = torch.from_numpy(synthetic.pose_windows(5, W, V)).to(dev)
+_, _, nm0 = model.encode(src, mean, std)
+rows = torch.randperm(NB, device=dev, generator=g)[: 2 * W]
+nm0 = nm0.reshape(W, D)
+gap = (torch.cdist(nm0, nm0) + 1e30 * torch.eye(W, device=dev)).min().item()
+noise = (0.1 * gap / D ** 0.5) * torch.randn((W, D), device=dev, generator=g)
+bank_nm[rows[:W]] = nm0 + noise
+bank_nm[rows[W:]] = nm0 + noise * 1.001
+for bf16 in (False, True):
+    bank = ContextBank(model, bank_nm, bank_nm.view(NB, 90, 256), bf16=bf16)
+    out = {}
+    for sel in (0, 1):
+        model.set_option("select2", sel)
+        d, i = bank.query(nm0)
+        i2 = bank.query(nm0, return_distance=False)
+        Y, ic = bank.characterize(src, mean, std, return_index=True)
+        out[sel] = (i[:, 0].clone(), i2[:, 0].clone(), ic.clone(), d[:, 0].clone())
+    model.set_option("select2", 1)
+    a, b = out[0], out[1]
+    print(f"bf16={bf16}: query idx differ {(a[0] != b[0]).sum().item()}, index-only differ {(a[0] != b[1]).sum().item()}, characterize differ {(a[2] != b[2]).sum().item()} (old characterize vs old query {(a[2] != a[0]).sum().item()})")
+    bad = torch.nonzero(a[2] != b[2])[:, 0].tolist()
+    for k in bad[:5]:
+        print("   window", k, "old", int(a[2][k]), "new", int(b[2][k]), "planted", int(rows[k]), int(rows[W + k]), "dist old", float(a[3][k]), "new", float(b[3][k]))
