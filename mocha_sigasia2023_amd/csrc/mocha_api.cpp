@@ -357,7 +357,7 @@ int ensure_ws(mocha_ctx* c, int B) {
     const size_t T = 90 * 256;
     const std::pair<const char*, size_t> plan[] = {
         {"hbar", 360 * 192}, {"ybar", 360 * 256}, {"u", 90 * 1280}, {"x5", T}, {"xA", 90 * 512}, {"t1", T}, {"xa", T}, {"xb", T},
-        {"qkv", 90 * 3072}, {"ao", 90 * 1024}, {"hff", 90 * 512}, {"kin", T}, {"xad", T}, {"qin", T},
+        {"qkv", 90 * 3072}, {"ao", 90 * 1024}, {"hff", (size_t)90 * std::max(512, std::max(c->cfg.enc_mlp, c->cfg.dec_mlp))}, {"kin", T}, {"xad", T}, {"qin", T},
         {"smean", 256}, {"s1", 512 * 8}, {"gb", 512 * 8}, {"qc", T}, {"g", 90 * 192}, {"y2c", (size_t)15 * V * 64},
         {"z", (size_t)60 * V * 64}, {"enc_s", T}, {"enc_c", T}, {"qnm", T}, {"sel", T}, {"dec", T},
         {"kvimg", (size_t)ATTN_KV_IMG_BYTES / 4},          // the decoder attention's pre-split key / value images (attention_kv.hip)
@@ -471,7 +471,8 @@ int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
 const char* attn_kernel_name(const mocha_ctx* c, int DH, long long pairs = 1 << 30) {
     const bool x3 = c->attn_x3 && (DH == 128 || DH == 256);
     if (x3 && DH == 256 && pairs <= c->attn_split_max) return "mocha_attention_x3_split<256>";
-    return x3 ? (DH == 128 ? "mocha_attention_x3<128>" : "mocha_attention_x3<256>") : (DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>");
+    return x3 ? (DH == 128 ? "mocha_attention_x3<128>" : "mocha_attention_x3<256>")
+              : (DH == 64 ? "mocha_attention_f32<64>" : DH == 128 ? "mocha_attention_f32<128>" : "mocha_attention_f32<256>");
 }
 hipError_t attention(const mocha_ctx* c, const AttnParams& a0, hipStream_t s) {
     AttnParams a = a0; a.split_max = c->attn_split_max;
@@ -925,11 +926,13 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     // the kernels are specialised for the shipped architecture (configs/config.yaml:13-31)
     if (cfg->T != 60 || cfg->patch != 4 || cfg->dim != 256 || cfg->C_in != 15)
         return fail(nullptr, MOCHA_ERR_ARG, "unsupported T/patch/dim/C_in (%d/%d/%d/%d), need 60/4/256/15", cfg->T, cfg->patch, cfg->dim, cfg->C_in);
-    if (cfg->enc_dim_head != 128 && cfg->enc_dim_head != 256) return fail(nullptr, MOCHA_ERR_ARG, "enc_dim_head must be 128 or 256");
-    if (cfg->dec_dim_head != 128 && cfg->dec_dim_head != 256) return fail(nullptr, MOCHA_ERR_ARG, "dec_dim_head must be 128 or 256");
+    // head dims: 64 (the reference Attention's own default, net/transformer.py:38: exact-f32 MFMA attention), 128 and 256 (also the plane engine)
+    for (int dh : {cfg->enc_dim_head, cfg->dec_dim_head})
+        if (dh != 64 && dh != 128 && dh != 256) return fail(nullptr, MOCHA_ERR_ARG, "dim_head must be 64, 128 or 256 (got %d)", dh);
     if (cfg->enc_heads * cfg->enc_dim_head > 1024 || cfg->dec_heads * cfg->dec_dim_head > 1024 || cfg->enc_heads < 1 || cfg->dec_heads < 1)
-        return fail(nullptr, MOCHA_ERR_ARG, "heads*dim_head must be in [128, 1024]");
-    if (cfg->enc_mlp != 512 || cfg->dec_mlp != 512) return fail(nullptr, MOCHA_ERR_ARG, "mlp_dim must be 512");
+        return fail(nullptr, MOCHA_ERR_ARG, "heads*dim_head must be in [64, 1024]");
+    for (int mlp : {cfg->enc_mlp, cfg->dec_mlp})
+        if (mlp < 64 || mlp > 2048 || mlp % 64) return fail(nullptr, MOCHA_ERR_ARG, "mlp_dim must be a multiple of 64 in [64, 2048] (got %d)", mlp);
     if (cfg->enc_depth < 1 || cfg->enc_depth > 8 || cfg->dec_depth < 1 || cfg->dec_depth > 8) return fail(nullptr, MOCHA_ERR_ARG, "depth must be in [1, 8]");
     mocha_ctx* c = new mocha_ctx();
     c->cfg = *cfg; c->device = device;

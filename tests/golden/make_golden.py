@@ -111,6 +111,9 @@ CONFIG_VARIANTS = {
     "e2h4d256_d2h4d128": dict(encoder_dim_head=256, decoder_dim_head=128),
     "e3h8d128_d1h2d256": dict(encoder_depth=3, encoder_heads=8, decoder_depth=1, decoder_heads=2),
     "e2h1d128_d4h3d256": dict(encoder_heads=1, decoder_depth=4, decoder_heads=3),
+    # the reference Attention's own default head dim (net/transformer.py:38) and other feed-forward widths (model.py:18-33 reads them from YAML)
+    "e2h4d64_d2h8d64_mlp256_1024": dict(encoder_dim_head=64, decoder_heads=8, decoder_dim_head=64, encoder_mlp_dim=256, decoder_mlp_dim=1024),
+    "e2h4d128_d2h4d256_mlp768_320": dict(encoder_mlp_dim=768, decoder_mlp_dim=320),
 }
 
 

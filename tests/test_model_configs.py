@@ -1,6 +1,7 @@
 """Model configurations other than the shipped one (run with -m gpu).  The reference builds its Generator from configs/config.yaml
-(model.py:16-80): depths, head counts and head dims are free there; mocha_create accepts depth 1..8, dim_head 128 / 256 on either
-side and heads x dim_head <= 1024 (everything else fails loudly, tests/test_cabi.py).  Every accepted variation must still be the
+(model.py:16-80): depths, head counts, head dims and feed-forward widths are free there; mocha_create accepts depth 1..8, dim_head
+64 / 128 / 256 on either side, heads x dim_head <= 1024 and mlp_dim a multiple of 64 up to 2048 (everything else fails loudly,
+tests/test_cabi.py; INTEGRATION.md lists what is rejected and why).  Every accepted variation must still be the
 reference's arithmetic: compared with the oracle on seeded weights of those shapes, through forward, the demo's characterize sequence,
 and at batch sizes that select the small-batch kernels (skinny GEMMs, twelve-wave attention for head dim 256 on EITHER side) and the
 tiled / plane engines."""
@@ -21,6 +22,11 @@ CONFIGS = {
     "enc 2 x (1 x 128), dec 4 x (3 x 256)": dict(encoder_heads=1, decoder_depth=4, decoder_heads=3),
     "enc 8 x (2 x 256), dec 8 x (8 x 128)": dict(encoder_depth=8, encoder_heads=2, encoder_dim_head=256, decoder_depth=8, decoder_heads=8,
                                                  decoder_dim_head=128),
+    # the reference Attention's default head dim 64 (net/transformer.py:38) and feed-forward widths other than 512
+    "enc 2 x (4 x 64) mlp 256, dec 2 x (8 x 64) mlp 1024": dict(encoder_dim_head=64, decoder_heads=8, decoder_dim_head=64, encoder_mlp_dim=256,
+                                                                decoder_mlp_dim=1024),
+    "enc 2 x (16 x 64) mlp 2048, dec 2 x (4 x 256) mlp 64": dict(encoder_heads=16, encoder_dim_head=64, encoder_mlp_dim=2048, decoder_mlp_dim=64),
+    "enc 2 x (4 x 128) mlp 768, dec 2 x (4 x 256) mlp 320": dict(encoder_mlp_dim=768, decoder_mlp_dim=320),
 }
 
 
@@ -75,3 +81,22 @@ def test_other_model_configurations_against_the_reference_fixture():
             Y = model(src, cha)
         assert np.abs(enc.cpu().numpy() - z[f"{name}_cha_encoded"]).max() < TOL * max(1.0, float(np.abs(z[f"{name}_cha_encoded"]).max())), name
         assert np.abs(Y.cpu().numpy() - z[f"{name}_Y_forward"]).max() < TOL, name
+
+
+@pytest.mark.parametrize("override,message", [
+    (dict(encoder_dim_head=96), "dim_head must be 64, 128 or 256"),
+    (dict(decoder_dim_head=32), "dim_head must be 64, 128 or 256"),
+    (dict(encoder_heads=16, encoder_dim_head=128), "heads\\*dim_head"),
+    (dict(encoder_mlp_dim=100), "mlp_dim must be a multiple of 64"),
+    (dict(decoder_mlp_dim=4096), "mlp_dim must be a multiple of 64"),
+    (dict(encoder_depth=9), "depth must be in"),
+    (dict(nframes=64), "unsupported T/patch/dim/C_in"),
+    (dict(temporal_patch_size=2), "unsupported T/patch/dim/C_in"),
+    (dict(encoder_dim=512, decoder_dim=512), "unsupported T/patch/dim/C_in"),
+    (dict(mot_in_dim=12), "unsupported T/patch/dim/C_in"),
+])
+def test_rejected_configurations_fail_loudly_in_mocha_create(override, message):
+    """What the library does NOT accept is refused by mocha_create with a message that names the dimension ('Accepted
+    configurations'): the kernels are specialised for T = 60, patch 4, dim 256, 15 input channels (configs/config.yaml:13-31)."""
+    with pytest.raises(RuntimeError, match=message):
+        Generator(dict(weights.DEFAULT_CFG, **override), layout="mocha", device="cuda:0")
