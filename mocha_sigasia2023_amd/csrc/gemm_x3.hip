@@ -30,6 +30,7 @@
 #include "kernels.h"
 #include "device_utils.h"
 #include <type_traits>
+#include <algorithm>
 
 namespace mocha {
 
@@ -415,6 +416,290 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     }
 }
 
+
+// -----------------------------------------------------------------------------------------------------------------------------------
+// Persistent instance (round 4): the K loop runs ACROSS tiles.  A workgroup walks tiles t = bid, bid + gridDim.x, ...;
+// the last two steps of a tile do for the next tile's steps 0 and 1 exactly what every step does for its successors - fetch its
+// activations two steps ahead, copy its weights and split its activations into the other LDS stage one step ahead - so a tile has no
+// prologue: when its epilogue is over, step 0's operands are in LDS and step 1's activations in registers.  The epilogue stages the
+// accumulators through the ONE stage the last step read from (32 rows per pass instead of 64), the other stage holds the next tile's step 0.
+// Same arithmetic, same order per output element: results are bit-identical to mocha_gemm_x3.  128 x 128 tiles, ksplit = 1 only.
+// -----------------------------------------------------------------------------------------------------------------------------------
+template <bool LRELU, bool GATHER>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void mocha_gemm_x3p(GemmParams p) {
+    constexpr int TM = 2, TN = 2;
+    constexpr int TILE_M = 128, TILE_N = 128, B_HALF = XT<2>::B_HALF, B_PLANE = XT<2>::B_PLANE, STAGE = XT<2>::STAGE;
+    extern __shared__ __attribute__((aligned(16))) unsigned short x3_sm[];          // [2][STAGE]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_tiles = (p.N + TILE_N - 1) / TILE_N;
+    const int m_tiles = (p.M + TILE_M - 1) / TILE_M;
+    const int m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
+    const int total = m_pad * n_tiles;
+    const int nsteps = p.K / XK;
+    const int lrow = tid >> 2, lc = tid & 3;
+
+    // a tile's loader state: base pointers stay uniform (SGPRs), per-lane offsets in a few VGPRs
+    struct Tile { int m0, n0; bool valid; int a_rb[TM], a_t[TM]; unsigned a_off[TM]; };
+    auto make_tile = [&](int t) __attribute__((always_inline)) -> Tile {
+        Tile T;
+        int mt, nt;
+        if (m_tiles >= 8) {                 // XCD-aware order as in mocha_gemm_x3: the n-tiles of one m-tile share an XCD (t % 8; gridDim.x % 8 == 0)
+            const int grp = t / (8 * n_tiles);
+            const int rem = t - grp * 8 * n_tiles;
+            mt = grp * 8 + (rem & 7);
+            nt = rem >> 3;
+        } else {
+            mt = t / n_tiles;
+            nt = t - mt * n_tiles;
+        }
+        T.valid = mt < m_tiles;
+        T.m0 = (T.valid ? mt : 0) * TILE_M; T.n0 = nt * TILE_N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            int m = T.m0 + lrow + 64 * i;
+            m = m < p.M ? m : p.M - 1;
+            if (GATHER) {
+                const int v = m % p.V;
+                const int bt = m / p.V;
+                T.a_t[i] = bt % p.T_out;
+                T.a_rb[i] = (bt / p.T_out) * p.T_src * p.V + v;
+                T.a_off[i] = 0;
+            } else {
+                T.a_rb[i] = m; T.a_t[i] = 0;
+                T.a_off[i] = ((unsigned)(m - T.m0) * (unsigned)p.lda + lc * 4) * 4u;
+            }
+        }
+        return T;
+    };
+    f32x4 rset[2][TM];
+    auto load_a = [&](const Tile& T, int s, f32x4 (&ra)[TM]) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rsA = make_rsrc(GATHER ? p.A : p.A + (size_t)T.m0 * p.lda);
+        const int k0 = s * XK;
+        if (!GATHER) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) ra[i] = bload(rsA, T.a_off[i], (unsigned)k0 * 4u);
+        } else {
+            const int tap = k0 / p.Cc;
+            const int cin = k0 - tap * p.Cc;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                int tf = T.a_t[i] * p.stride + tap - p.pad;
+                tf = tf < 0 ? -tf : tf;
+                tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
+                const unsigned off = ((unsigned)(T.a_rb[i] + (tf >> p.tshift) * p.V) * (unsigned)p.lda + lc * 4) * 4u;
+                ra[i] = bload(rsA, off, (unsigned)cin * 4u);
+            }
+        }
+    };
+    const int a_wr = (lc >> 1) * XA_HALF + lrow * 8 + (lc & 1) * 4;
+    auto split_store = [&](const f32x4 (&ra)[TM], unsigned short* st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            f32x4 v = ra[i];
+            if (LRELU) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
+            u32x2 pl[3];
+            plane_split4(v, pl);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<u32x2*>(st + q * XA_PLANE + a_wr + i * 64 * 8) = pl[q];
+        }
+    };
+    auto dma_w = [&](const Tile& T, int s, unsigned short* st) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.Wsplit + ((size_t)(T.n0 / TILE_N) * nsteps) * XW_BLOCK);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(st + XB_OFF + ((j * 4 + wave) >> 2) * B_PLANE +
+                                                     (((j * 4 + wave) >> 1) & 1) * B_HALF + ((j * 4 + wave) & 1) * 512), 16,
+                                                     (unsigned)(j * 256 + tid) * 16u, (unsigned)s * (XW_BLOCK * 2u), 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+    const int fa = hh * XA_HALF + (wm * TM * 32 + l31) * 8;
+    const int fb = XB_OFF + hh * B_HALF + (wn * 32 * TN + l31) * 8;
+
+    // One K step of tile `cur`.  FETCH_W: the step after this one exists - step s + 1 of this tile, or step 0 of the next tile (wt / ws) - its
+    // weights are copied and its activations (waiting in rset[P ^ 1]) split into the other stage; FETCH_A: the step after that exists
+    // (at / as) - its activations are fetched into rset[P].
+    auto step = [&](auto parity, auto fetch_w, auto fetch_a, const Tile& wt, int ws, const Tile& at, int as) __attribute__((always_inline)) {
+        constexpr bool FETCH_W = decltype(fetch_w)::value, FETCH_A = decltype(fetch_a)::value;
+        constexpr int P = decltype(parity)::value;
+        unsigned short* cur = x3_sm + P * STAGE;
+        unsigned short* nxt = x3_sm + (P ^ 1) * STAGE;
+        if (FETCH_W) dma_w(wt, ws, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        if (FETCH_A) load_a(at, as, rset[P]);
+        __builtin_amdgcn_sched_barrier(0);
+        s16x8 a[3][TM], b[3][TN];
+        auto rd_a = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[q][i] = *reinterpret_cast<const s16x8*>(cur + q * XA_PLANE + fa + i * 32 * 8);
+        };
+        auto rd_b = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < TN; ++i) b[q][i] = *reinterpret_cast<const s16x8*>(cur + q * B_PLANE + fb + i * 32 * 8);
+        };
+        rd_a(0); rd_b(2); rd_a(1); rd_b(1); rd_a(2); rd_b(0);
+        float x[4 * TM];
+        unsigned pk[2 * TM][3], hi[2 * TM][2];
+        if (FETCH_W) {
+#pragma unroll
+            for (int e = 0; e < 4 * TM; ++e) { x[e] = rset[P ^ 1][e >> 2][e & 3]; if (LRELU) x[e] = fmaxf(x[e], 0.2f * x[e]); }
+        }
+        auto split_op = [&](int k) __attribute__((always_inline)) {
+            const int pr = k / 11, o = k % 11, lvl = o / 5;
+            float& x0 = x[2 * pr]; float& x1 = x[2 * pr + 1];
+            if (o == 10) { pk[pr][2] = cvt_pk_bf16(x0, x1); return; }
+            switch (o % 5) {
+                case 0: pk[pr][lvl] = cvt_pk_bf16(x0, x1); break;
+                case 1: hi[pr][0] = pk[pr][lvl] << 16; break;
+                case 2: hi[pr][1] = pk[pr][lvl] & 0xffff0000u; break;
+                case 3: x0 -= __uint_as_float(hi[pr][0]); break;
+                default: x1 -= __uint_as_float(hi[pr][1]); break;
+            }
+        };
+        auto write_row = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const u32x2 v = {pk[2 * i][q], pk[2 * i + 1][q]};
+                *reinterpret_cast<u32x2*>(nxt + q * XA_PLANE + a_wr + i * 64 * 8) = v;
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 6 * TM * TN; ++m) {
+            const int pr = m / (TM * TN), pa = PLANE_PA[pr], pb = PLANE_PB[pr], i = (m % (TM * TN)) / TN, j = m % TN;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[pb][j], a[pa][i], acc[i][j], 0, 0, 0);
+            if (FETCH_W && m < 11 * TM) { split_op(2 * m); split_op(2 * m + 1); }
+            if (FETCH_W && m == 10) write_row(0);
+            if (FETCH_W && m == 21) write_row(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (FETCH_A) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TM) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    using TT = std::true_type;
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, 1>;
+
+    int t = blockIdx.x;
+    if (t >= total) return;
+    Tile cur = make_tile(t);
+    while (!cur.valid) { t += gridDim.x; if (t >= total) return; cur = make_tile(t); }          // padded m-tiles of the XCD-aware order
+    // the first tile's prologue (as in mocha_gemm_x3)
+    load_a(cur, 0, rset[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    dma_w(cur, 0, x3_sm);
+    __builtin_amdgcn_sched_barrier(0);
+    split_store(rset[0], x3_sm);
+    load_a(cur, 1, rset[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(TM) : "memory");
+
+    const bool vec_ok = ((p.ldc & 3) == 0) && (!p.residual || (p.ldr & 3) == 0) && ((p.N & 3) == 0);
+    for (;;) {
+        int tn = t + gridDim.x;
+        Tile nxt = cur;
+        bool has_next = false;
+        while (tn < total) { nxt = make_tile(tn); if (nxt.valid) { has_next = true; break; } tn += gridDim.x; }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int s = 0; s + 2 < nsteps; s += 2) {
+            step(P0{}, TT{}, TT{}, cur, s + 1, cur, s + 2);
+            step(P1{}, TT{}, TT{}, cur, s + 2, cur, s + 3);
+        }
+        // (the last tile of a workgroup prepares `cur` once more: the fetches stay inside the tile's buffers and nobody reads them)
+        step(P0{}, TT{}, TT{}, cur, nsteps - 1, nxt, 0);              // next tile's step 0 activations into rset[0]
+        step(P1{}, TT{}, TT{}, nxt, 0, nxt, 1);                       // its step 0 into stage 0, its step 1 activations into rset[1]
+
+        // ---- epilogue of `cur` through stage 1 (the last step's operands are dead; stage 0 may hold the next tile's step 0): 32 rows per pass
+        const int m0 = cur.m0, n0 = cur.n0;
+        float* Cz = p.C;
+        const __amdgpu_buffer_rsrc_t rsC = make_rsrc(Cz + (size_t)m0 * p.ldc + n0);
+        const __amdgpu_buffer_rsrc_t rsBias = make_rsrc(p.bias ? p.bias + n0 : p.A);
+        const __amdgpu_buffer_rsrc_t rsRb = make_rsrc(p.rowbias ? p.rowbias + n0 : p.A);
+        const __amdgpu_buffer_rsrc_t rsRes = make_rsrc(p.residual ? p.residual + (size_t)m0 * p.ldr + n0 : p.A);
+        if (vec_ok && n0 + TILE_N <= p.N) {
+            constexpr int LDP = TILE_N + 4;
+            constexpr int C4 = TILE_N / 4;
+            static_assert(32 * LDP * 4 <= STAGE * 2, "a 32-row pass fits one stage");
+            float* stage = reinterpret_cast<float*>(x3_sm + STAGE);
+            // the epilogue's per-thread offsets do not depend on the tile: left alone, the compiler hoists all of them out of the tile loop and
+            // keeps ~70 registers alive through the K steps (227 instead of 156 VGPRs: two waves per SIMD).  Derive them from a laundered
+            // thread id so that they are recomputed here.
+            int te = tid, l31e = l31, hhe = hh;
+            asm volatile("" : "+v"(te), "+v"(l31e), "+v"(hhe));
+#pragma unroll
+            for (int h = 0; h < 2 * TM; ++h) {            // 32 rows of the tile per pass: MFMA row block h
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (wm * TM + i != h) continue;         // wave-uniform: the two waves that own row block h
+                    float* srow = stage + l31e * LDP + wn * (32 * TN) + 4 * hhe;
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            *reinterpret_cast<f32x4*>(srow + j * 32 + 8 * g) = v;
+                        }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int it = 0; it < 32 * C4 / 256; ++it) {
+                    const int e = te + 256 * it;
+                    const int r = e / C4, c4 = e - r * C4;
+                    const int rloc = 32 * h + r;
+                    const int row = m0 + rloc;
+                    if (row < p.M) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4);
+                        const unsigned cb = (unsigned)c4 * 16u;
+                        if (p.bias) v += bload(rsBias, cb, 0u);
+                        if (p.rowbias) v += bload(rsRb, (unsigned)(row % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);
+                        if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
+                        else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
+                        else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                        if (p.residual) v += bload(rsRes, (unsigned)rloc * (unsigned)p.ldr * 4u + cb, 0u);
+                        bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
+                    }
+                }
+                __syncthreads();                          // the stage is rewritten by the next pass - or by the next tile's step 0
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = m0 + (wm * TM + i) * 32 + l31;
+                if (row >= p.M) continue;
+                const float* rbrow = p.rowbias ? p.rowbias + (size_t)(row % p.rb_mod) * p.N : nullptr;
+                const float* rsrow = p.residual ? p.residual + (size_t)row * p.ldr : nullptr;
+                float* crow = Cz + (size_t)row * p.ldc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int c1 = n0 + wn * (32 * TN) + j * 32 + 8 * g + 4 * hh + e;
+                            if (c1 >= p.N) continue;
+                            float x = acc[i][j][4 * g + e];
+                            if (p.bias) x += p.bias[c1];
+                            if (rbrow) x += rbrow[c1];
+                            if (p.act == 1) x = x3_gelu(x);
+                            else if (p.act == 2) x = x3_lrelu(x);
+                            else if (p.act == 3) x = fmaxf(x, 0.f);
+                            if (rsrow) x += rsrow[c1];
+                            crow[c1] = x;
+                        }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt; t = tn;
+    }
+}
+
 template <int TN> static constexpr size_t x3_lds_bytes() { return (size_t)2 * XT<TN>::STAGE * sizeof(unsigned short); }
 
 template <bool L, bool G, int TM, int TN>
@@ -435,6 +720,10 @@ hipError_t gemm_x3_init() {
     if (e == hipSuccess) e = x3_attr<true, false, 2, 1>();
     if (e == hipSuccess) e = x3_attr<false, true, 2, 1>();
     if (e == hipSuccess) e = x3_attr<true, true, 2, 1>();
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
     return e;
 }
 
@@ -472,6 +761,8 @@ static void x3_launch(const GemmParams& p, hipStream_t s) {
     }
 }
 
+int gemm_x3_persistent = 0;         // > 0: workgroups of the persistent instance (diagnostic / option "gemm_persistent"; a multiple of 8)
+
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
     if (!p.Wsplit || !gemm_x3_supports(p)) return hipErrorInvalidValue;
@@ -479,6 +770,20 @@ hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
     if (128ll * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     // mid-size launches (fewer than 768 tiles of 128 x 64: a few dozen to a few hundred windows) take 64-row tiles, twice the workgroups;
     // N = 64 / 192 the 64-wide tile
+    if (gemm_x3_persistent > 0 && p.ksplit <= 1 && p.N % XN == 0 && !gemm_is_small(p)) {
+        // the persistent instance: `gemm_x3_persistent` workgroups (a multiple of 8) walk the 128 x 128 tiles
+        const int m_tiles = (p.M + 127) / 128, m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
+        const long long total = (long long)m_pad * (p.N / XN);
+        const unsigned grid = (unsigned)std::min<long long>(total, gemm_x3_persistent);
+        if (p.a_lrelu) {
+            if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3p<true, true>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);
+            else hipLaunchKernelGGL((mocha_gemm_x3p<true, false>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);
+        } else {
+            if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3p<false, true>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);
+            else hipLaunchKernelGGL((mocha_gemm_x3p<false, false>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);
+        }
+        return hipGetLastError();
+    }
     if (p.ksplit <= 1 && p.N % XN != 0) x3_launch<2, 1>(p, s);
     else if (p.ksplit <= 1 && gemm_is_small(p)) x3_launch<1, 2>(p, s);
     else x3_launch<2, 2>(p, s);

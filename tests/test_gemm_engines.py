@@ -200,3 +200,27 @@ def test_decoder_attention_from_key_value_images(B):
     Y0, i0 = bank.characterize(X, mean, std, return_index=True)
     model.set_option("attention_kv", 1)
     assert torch.equal(i0, i1) and float((Y1 - Y0).abs().max()) <= 1e-6 * max(1.0, float(Y0.abs().max()))
+
+
+@pytest.mark.parametrize("persistent", [768, 256, 8])
+def test_persistent_plane_gemm_is_bit_identical(persistent):
+    """mocha_gemm_x3p runs the K loop ACROSS tiles - a workgroup's last two steps of a tile prepare the next tile's first
+    two (no prologue), the epilogue goes through the one LDS stage the last step read from.  Same products in the same order per output
+    element: the network's output and every mocha_linear shape (plain / bias; M with ragged last tile; more and fewer tiles than
+    workgroups) are bit-identical to mocha_gemm_x3.  `persistent` = workgroups: 768 (three per CU), 256, 8 (every workgroup walks many tiles)."""
+    sd = weights.synthetic_state_dict(23, 1.5)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    g = torch.Generator(device=dev()); g.manual_seed(5)
+    src = torch.from_numpy(synthetic.pose_windows(41, 70)).to(dev()); cha = torch.from_numpy(synthetic.pose_windows(42, 70)).to(dev())
+    shapes = [(6300, 256, 256), (6300, 512, 256), (12345, 256, 512), (1000, 1536, 256), (20000, 128, 128)]
+    ops = [(torch.randn((M, K), device=dev(), generator=g), torch.randn((N, K), device=dev(), generator=g), torch.randn((N,), device=dev(), generator=g)) for M, N, K in shapes]
+    out = {}
+    for pers in (0, persistent):
+        model.set_option("gemm_persistent", pers)
+        model.profile_start()
+        Y = model(src, cha)
+        kern = model.profile_stop()["kernels"]
+        out[pers] = [Y.clone()] + [model.linear(x, w, b, engine=2).clone() for x, w, b in ops] + [model.linear(x, w, None, engine=2).clone() for x, w, b in ops]
+    model.set_option("gemm_persistent", 0)
+    for a, b in zip(out[0], out[persistent]):
+        assert torch.equal(a, b), float((a - b).abs().max())
