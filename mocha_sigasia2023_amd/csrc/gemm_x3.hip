@@ -761,7 +761,11 @@ static void x3_launch(const GemmParams& p, hipStream_t s) {
     }
 }
 
-int gemm_x3_persistent = 0;         // > 0: workgroups of the persistent instance (diagnostic / option "gemm_persistent"; a multiple of 8)
+// Default: 768 workgroups (three per CU) walk the tiles of launches up to 512 columns wide - out_proj / ff1 / ff2 / the embedding and to_mot
+// GEMMs 2-3 % faster, demo step 5.59 against 5.62 ms; the 1536-wide qkv projection is 5 % SLOWER that way and stays on mocha_gemm_x3
+// (profiles/r04/d_persist_ab.txt, d_persist_selective_ab.txt)
+int gemm_x3_persistent_max_n = 512;          // ... for launches of at most this many columns
+int gemm_x3_persistent = 768;         // > 0: workgroups of the persistent instance (diagnostic / option "gemm_persistent"; a multiple of 8)
 
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
@@ -770,7 +774,7 @@ hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
     if (128ll * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     // mid-size launches (fewer than 768 tiles of 128 x 64: a few dozen to a few hundred windows) take 64-row tiles, twice the workgroups;
     // N = 64 / 192 the 64-wide tile
-    if (gemm_x3_persistent > 0 && p.ksplit <= 1 && p.N % XN == 0 && !gemm_is_small(p)) {
+    if (gemm_x3_persistent > 0 && p.ksplit <= 1 && p.N % XN == 0 && p.N <= gemm_x3_persistent_max_n && !gemm_is_small(p)) {
         // the persistent instance: `gemm_x3_persistent` workgroups (a multiple of 8) walk the 128 x 128 tiles
         const int m_tiles = (p.M + 127) / 128, m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
         const long long total = (long long)m_pad * (p.N / XN);

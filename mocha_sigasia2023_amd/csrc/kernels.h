@@ -50,6 +50,7 @@ bool gemm_x3_supports(const GemmParams& p);
 size_t gemm_x3_packed_elems(int N, int K);
 hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s, const float* wsub = nullptr);   // wsub: K values subtracted from every row
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s);
+extern int gemm_x3_persistent_max_n;
 extern int gemm_x3_persistent;       // > 0: the persistent instance (K loop across tiles) with that many workgroups for the 128 x 128-tile launches
 
 

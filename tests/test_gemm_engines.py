@@ -216,11 +216,12 @@ def test_persistent_plane_gemm_is_bit_identical(persistent):
     ops = [(torch.randn((M, K), device=dev(), generator=g), torch.randn((N, K), device=dev(), generator=g), torch.randn((N,), device=dev(), generator=g)) for M, N, K in shapes]
     out = {}
     for pers in (0, persistent):
+        model.set_option("gemm_persistent_max_n", 1 << 30)
         model.set_option("gemm_persistent", pers)
         model.profile_start()
         Y = model(src, cha)
         kern = model.profile_stop()["kernels"]
         out[pers] = [Y.clone()] + [model.linear(x, w, b, engine=2).clone() for x, w, b in ops] + [model.linear(x, w, None, engine=2).clone() for x, w, b in ops]
-    model.set_option("gemm_persistent", 0)
+    model.set_option("gemm_persistent", 768); model.set_option("gemm_persistent_max_n", 512)        # the library's defaults (process-wide)
     for a, b in zip(out[0], out[persistent]):
         assert torch.equal(a, b), float((a - b).abs().max())

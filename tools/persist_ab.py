@@ -14,8 +14,8 @@ def run(n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): model.characterize_pair(src, cha, mean, std)
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-for pers in (0, 768, 512, 1024, 0, 768, 512, 1024, 0, 768):
-    model.set_option("gemm_persistent", pers)
+for pers, maxn in ((0, 1 << 30), (768, 1 << 30), (768, 512), (768, 256), (0, 1 << 30), (768, 1 << 30), (768, 512), (768, 256), (0, 1 << 30), (768, 512)):
+    model.set_option("gemm_persistent", pers); model.set_option("gemm_persistent_max_n", maxn)
     ms = run(40)
     model.profile_start()
     for _ in range(3): model.characterize_pair(src, cha, mean, std)
@@ -24,5 +24,5 @@ for pers in (0, 768, 512, 1024, 0, 768, 512, 1024, 0, 768):
     g = sum(v["ms"] for v in k.values()) / 3
     sites = {s.split("|")[0]: v["ms"] / 3 * 1e3 for s, v in p["sites"].items() if "gemm_x3" in s}
     top = "  ".join(f"{a} {b:6.1f}" for a, b in sorted(sites.items(), key=lambda kv: -kv[1])[:8])
-    print(f"gemm_persistent={pers:5d}: step {ms:6.3f} ms  {W / ms:7.1f} k frames/s   plane GEMMs {g:6.3f} ms per step   {top}", flush=True)
-model.set_option("gemm_persistent", 0)
+    print(f"gemm_persistent={pers:5d} max_n={maxn if maxn < 1 << 30 else 0:5d}: step {ms:6.3f} ms  {W / ms:7.1f} k frames/s   plane GEMMs {g:6.3f} ms per step   {top}", flush=True)
+model.set_option("gemm_persistent", 768); model.set_option("gemm_persistent_max_n", 512)
