@@ -4,7 +4,7 @@
 // contractions with no normalisation layers in between; v_mfma_f32_32x32x2_f32 is a k-ordered
 // fmaf chain (bit-for-bit f32) at the full f32 rate (157 TFLOP/s dense peak on MI355X).
 //
-// Structure (measured reasons in DESIGN.md §GEMM):
+// Structure (measured reasons in DESIGN_HISTORY.md §5):
 //   * 128 x BN x 32 tile per 256-thread workgroup (4 waves, each TM x TN MFMA tiles of 32x32).  One
 //     LDS stage (36.9 KB for BN = 128) so that three workgroups share a CU: the K loops of this path
 //     are short (6-40 slabs), and a third co-resident workgroup hides more of the prologue /

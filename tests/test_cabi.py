@@ -74,7 +74,7 @@ def test_bench_launcher_refuses_more_ranks_than_gpus():
 
 def test_device_code_has_no_packed_fp32_op_sel_pattern():
     """tools/isa_lint.py over the built library: no kernel outside its allow-list contains ``v_pk_*_f32`` with ``op_sel`` on a high
-    register - the pattern that, fed from LDS, made mocha_body_front depend on what shared its CU (Concurrency)."""
+    register - the pattern that, fed from LDS, made mocha_body_front depend on what shared its CU (DESIGN_HISTORY.md §8, Concurrency)."""
     import importlib.util
     if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
         pytest.skip("llvm-objdump not available")
