@@ -306,7 +306,7 @@ def bank4k_record(a, model, dev, V, rank, world, backend):
         gbs = moved / (times[1] * 1e-3) / 1e9
         inbound = (world - 1) * XGMI_LINK_GBS            # what a rank's xGMI links to its peers can take in at once
         bcast = {"ms_first_call": times[0], "ms": times[1], "bytes_per_rank": moved, "GB/s_per_rank": gbs,
-                 "xgmi_inbound_peak_GB/s": inbound, "frac_of_xgmi_inbound_peak": gbs / inbound,
+                 "xgmi_inbound_peak_GB/s": inbound, "frac_of_xgmi_inbound_peak": (gbs / inbound) if inbound > 0 else None,
                  "xgmi_links_per_gpu_peak_GB/s": 7 * XGMI_LINK_GBS,
                  "algorithm_bound_GB/s": world * XGMI_LINK_GBS / 2,
                  "note": "scatter (root -> rank r: bytes / N over its own link) + all-gather (every rank takes bytes / N from each peer); with "
