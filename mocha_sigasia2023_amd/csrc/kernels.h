@@ -180,7 +180,11 @@ hipError_t launch_center_bf16(const float* x, const float* centre, void* out, in
 // workgroup per row, fixed summation order.  Exactly one of planes / out32 is non-null.
 hipError_t launch_center_rows(const float* x, const float* centre, void* planes, int nplanes, float* out32, float* qstat, int64_t rows, int cols, hipStream_t s);
 // planes = 2: qc16 holds two stacked bf16 planes of the queries (plane 1 starts Q * D elements after plane 0), S = (a0 + a1) b^T
-hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes = 1);
+// tiled: the bank as launch_tile_bf16 wrote it (match_tiled_elems(N, D) bf16), or null to read the row-major bank16
+hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes = 1,
+                                  const void* tiled = nullptr);
+size_t match_tiled_elems(int64_t N, int D);
+hipError_t launch_tile_bf16(const void* bank16, void* out, int64_t N, int D, hipStream_t s);
 hipError_t launch_match_select(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm, const float* query,
                                const float* centre, const float* bank, const void* bank16, float margin_rel, int Q, int64_t N, int D,
                                int32_t* idx, float* dist, hipStream_t s);

@@ -58,6 +58,7 @@ struct MatchGemmParams {
     const unsigned short* A; const unsigned short* B; float* S;
     int Q; long long N; int D; int ksplit; long long slab_stride; int m_tiles, n_tiles;
     long long a_plane;            // elements between the two stacked query planes (NPL == 2)
+    const unsigned short* Bt;     // the bank as the kernel's own LDS image, [n tile][k step][128 rows][64] with the swizzle applied (mocha_tile_bf16), or null
 };
 
 static constexpr int MG_BM = 128, MG_BN = 128, MG_BK = 64;
@@ -94,7 +95,10 @@ __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams
     const int nsteps = s_end > s_begin ? s_end - s_begin : 0;
 
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A + (size_t)m0 * p.D);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B + (size_t)n0 * p.D);
+    // tiled bank image: a (tile, step) block is 16 KB of contiguous memory in LDS order - every DMA instruction copies 1 KB linearly and a
+    // workgroup walks one contiguous 16 KB x steps region (row-major rows give 128-byte pieces 46 KB apart: 0.45 of the HBM peak when the
+    // bank is not already in the Infinity Cache, measured inside characterize)
+    const __amdgpu_buffer_rsrc_t rsB = p.Bt ? make_rsrc(p.Bt + (size_t)nt * (size_t)steps_total * (MG_BN * MG_BK)) : make_rsrc(p.B + (size_t)n0 * p.D);
     const __amdgpu_buffer_rsrc_t rsA1 = make_rsrc(p.A + (size_t)(NPL == 2 ? p.a_plane : 0) + (size_t)m0 * p.D);
     // DMA pieces: wave w fills 8-row pieces w, w + 4, w + 8, w + 12 of A and of B; lane -> (row in piece, slot)
     unsigned a_off[4], b_off[4];
@@ -105,18 +109,19 @@ __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams
         int ra = m0 + r; ra = ra < p.Q ? ra : p.Q - 1;
         long long rb = n0 + r; rb = rb < p.N ? rb : p.N - 1;
         a_off[i] = ((unsigned)(ra - m0) * (unsigned)p.D + c * 8u) * 2u;
-        b_off[i] = ((unsigned)(rb - n0) * (unsigned)p.D + c * 8u) * 2u;
+        b_off[i] = p.Bt ? (unsigned)((wave + 4 * i) * 512 + lane * 8) * 2u : ((unsigned)(rb - n0) * (unsigned)p.D + c * 8u) * 2u;
     }
     auto issue = [&](int s) __attribute__((always_inline)) {        // step s (relative) -> ring slot s % R; past the end: re-fetch the last step into a dead slot
         const int sc = s < nsteps ? s : nsteps - 1;
         const unsigned so = (unsigned)((s_begin + sc) * MG_BK) * 2u;
+        const unsigned sob = p.Bt ? (unsigned)(s_begin + sc) * (unsigned)(MG_BN * MG_BK * 2) : so;
         unsigned short* st = mg_sm + (s % R) * STAGE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave + 4 * i) * 512), 16, a_off[i], so, 0, 0);
             if (NPL == 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (__attribute__((address_space(3))) void*)(st + MG_BM * MG_BK + (wave + 4 * i) * 512), 16, a_off[i], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + NPL * MG_BM * MG_BK + (wave + 4 * i) * 512), 16, b_off[i], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + NPL * MG_BM * MG_BK + (wave + 4 * i) * 512), 16, b_off[i], sob, 0, 0);
         }
     };
 
@@ -219,7 +224,36 @@ int match_bf16_ksplit(int Q, int64_t N) {
     return k;
 }
 
-hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes) {
+// bank16 (N, D) bf16 row-major -> the coarse pass's own image: block (n tile, k step) = 128 rows x 64 k in LDS order, 16-byte piece c of row r
+// at slot c ^ ((r >> 1) & 7); rows past N are zero.  One 256-thread workgroup per block.
+__global__ __launch_bounds__(256) void mocha_tile_bf16(const unsigned short* __restrict__ bank16, unsigned short* __restrict__ out, long long N, int D) {
+    const int steps = D / MG_BK;
+    const int nt = blockIdx.x / steps, st = blockIdx.x - nt * steps;
+    unsigned short* blk = out + (size_t)blockIdx.x * (MG_BN * MG_BK);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int pc = threadIdx.x + 256 * i;                  // piece of the block: row r, slot
+        const int r = pc >> 3, slot = pc & 7;
+        const int c = slot ^ ((r >> 1) & 7);
+        const long long row = (long long)nt * MG_BN + r;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < N) v = *reinterpret_cast<const u32x4*>(bank16 + (size_t)row * D + st * MG_BK + c * 8);
+        *reinterpret_cast<u32x4*>(blk + pc * 8) = v;
+    }
+}
+
+size_t match_tiled_elems(int64_t N, int D) { return (size_t)((N + MG_BN - 1) / MG_BN) * MG_BN * (size_t)D; }
+
+hipError_t launch_tile_bf16(const void* bank16, void* out, int64_t N, int D, hipStream_t s) {
+    if (N <= 0) return hipSuccess;
+    if (D % MG_BK) return hipErrorInvalidValue;
+    const long long blocks = (long long)((N + MG_BN - 1) / MG_BN) * (D / MG_BK);
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_tile_bf16, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)bank16, (unsigned short*)out, (long long)N, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes, const void* tiled) {
     if (Q <= 0 || N <= 0) return hipSuccess;
     if (D % MG_BK || (ksplit != 1 && ksplit != 2 && ksplit != 4 && ksplit != 8)) return hipErrorInvalidValue;
     if ((long long)MG_BM * D * 2 >= (1ll << 31)) return hipErrorInvalidValue;            // 32-bit buffer offsets inside a tile
@@ -228,7 +262,9 @@ hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S
     p.Q = Q; p.N = N; p.D = D; p.ksplit = ksplit; p.slab_stride = (long long)Q * N;
     p.m_tiles = (Q + MG_BM - 1) / MG_BM; p.n_tiles = (int)((N + MG_BN - 1) / MG_BN);
     p.a_plane = (long long)Q * D;
+    p.Bt = (const unsigned short*)tiled;
     if (planes != 1 && planes != 2) return hipErrorInvalidValue;
+    if (tiled && (long long)(D / MG_BK) * MG_BN * MG_BK * 2 >= (1ll << 31)) return hipErrorInvalidValue;      // 32-bit offsets inside a tile's block row
     const long long pairs = (long long)p.n_tiles * ksplit;
     const long long groups = (pairs + 7) / 8;
     // ring of 4 stages: three steps (96 KB) in flight per CU; measured equal to 3 and 5 stages, and 10 % faster than staging

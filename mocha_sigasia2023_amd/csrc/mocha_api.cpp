@@ -170,6 +170,9 @@ struct mocha_ctx {
     int* bone_parents = nullptr;       // device: parents of the (V+1)-bone skeleton with the root bone in front
     float* pose_norm = nullptr;        // [x_mean | x_std | y_mean | y_std], (V+1)*C_in each (norm.npz of the reference)
     void* bank_bf16 = nullptr; size_t bank_bf16_cap = 0; bool bank_is_bf16 = false;
+    // the bf16 bank once more as the many-query coarse pass's own tiled image (contiguous 16 KB blocks), made at the first such match
+    void* bank_tiled = nullptr; size_t bank_tiled_cap = 0; bool bank_tiled_valid = false;
+    bool use_tiled = false;            // option "bank_tiled": -4 % on the cold pass for 2 x the bf16 copy's memory (profiles/r04/c_tiled_loader_ab.txt): off
     // fp32 banks of up to X3_BANK_MAX rows also keep the plane engine's packed image of the centred bank (many-query matching)
     unsigned short* bank_x3 = nullptr; size_t bank_x3_cap = 0; bool bank_x3_valid = false;
     unsigned long long* best_ws[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t best_ws_n[MAX_SETS] = {0, 0, 0};
@@ -855,8 +858,24 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
         // (fp32 centred query against the bf16 rows), so the result is the exact search over the rounded bank
         const int ksplit = match_bf16_ksplit(Q, N);
         const int npl = sel2 ? c->match_planes : 1;
+        const void* tiled = nullptr;
+        if (c->use_tiled && (size_t)N * D * 2 <= ((size_t)4 << 30)) {          // up to 4 GB of image (N = 93 k rows)
+            const size_t need = match_tiled_elems(N, D);
+            if (!c->bank_tiled_valid) {
+                if (c->bank_tiled_cap < need) {
+                    HIPCHK(c, hipDeviceSynchronize());
+                    if (c->bank_tiled) (void)hipFree(c->bank_tiled);
+                    c->bank_tiled = nullptr; c->bank_tiled_cap = 0;
+                    HIPCHK(c, hipMalloc(&c->bank_tiled, need * 2));
+                    c->bank_tiled_cap = need;
+                }
+                LAUNCH(c, s, "mocha_tile_bf16", "bank.tile", 0.0, 4.0 * N * D, launch_tile_bf16(c->bank_bf16, c->bank_tiled, N, D, s));
+                c->bank_tiled_valid = true;
+            }
+            tiled = c->bank_tiled;
+        }
         LAUNCH(c, s, "mocha_match_gemm_bf16", "match.qk_bf16", 2.0 * npl * Q * (double)N * D, 2.0 * npl * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
-               launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, npl));
+               launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, npl, tiled));
         if (sel2)
             LAUNCH(c, s, "mocha_match_select2", "match.select", 0.0, 4.0 * ksplit * Q * N + 4.0 * N + 8.0 * Q,
                    launch_match_select2(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, nullptr, c->bank_bf16,
@@ -962,6 +981,7 @@ void mocha_destroy(mocha_ctx* c) {
     for (float* p : c->owned) (void)hipFree(p);
     for (int set = 0; set < mocha_ctx::MAX_SETS; ++set) { if (c->idx_ws[set]) (void)hipFree(c->idx_ws[set]); if (c->best_ws[set]) (void)hipFree(c->best_ws[set]); }
     if (c->bank_bf16) (void)hipFree(c->bank_bf16);
+    if (c->bank_tiled) (void)hipFree(c->bank_tiled);
     if (c->bank_x3) (void)hipFree(c->bank_x3);
     if (c->pair_x3) (void)hipFree(c->pair_x3);
     if (c->bank16f) (void)hipFree(c->bank16f);
@@ -1313,6 +1333,7 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
     }
     c->bank_N = N;
     c->bank_is_bf16 = (flags & MOCHA_BANK_BF16) != 0;
+    c->bank_tiled_valid = false;
     if (current) c->generation++;                         // a captured step has the previous bank's pointers and row count baked in
     // match scratch for every query count the workspace admits: a later match never allocates (capture-safe)
     for (int set = 0; set < mocha_ctx::MAX_SETS; ++set)
@@ -2142,6 +2163,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only
     if (n == "gemm_persistent_max_n") { gemm_x3_persistent_max_n = value < 128 ? 128 : value; c->generation++; return 0; }      // process-wide (diagnostic)
     if (n == "gemm_persistent") { gemm_x3_persistent = value < 0 ? 0 : (value + 7) / 8 * 8; c->generation++; return 0; }      // process-wide (diagnostic)
+    if (n == "bank_tiled") { c->use_tiled = value != 0; c->generation++; return 0; }
     if (n == "match_planes") { if (value != 1 && value != 2) return fail(c, MOCHA_ERR_ARG, "match_planes must be 1 or 2"); c->match_planes = value; c->generation++; return 0; }
     if (n == "select2") { c->select2 = value != 0; c->generation++; return 0; }
     if (n == "attention_kv") { c->attn_kv = value != 0; c->generation++; return 0; }
