@@ -395,8 +395,8 @@ hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, f
 static constexpr int IN_NG = 8;             // token groups per window
 static constexpr int IN_MAXT = 12;          // tokens per thread (n <= 96)
 
-// QW = channel quads per workgroup: 64 (one workgroup per window; large batches) or 16 (a window's 256 channels over four workgroups:
-// a handful of windows would otherwise sit on a handful of CUs, each moving a window's 0.3-0.5 MB alone).  A channel's tokens are
+// QW = channel quads per workgroup: 16 (a window's 256 channels over four workgroups; the default for every batch since round 4) or 64 (one
+// workgroup per window: needed when the row statistics of the whole window are wanted, InormExtra::qstat).  A channel's tokens are
 // partitioned and summed in the same order either way: results are bit-identical.
 template <int QW>
 __device__ __forceinline__ f32x4 group_sum4(f32x4 v, f32x4* red, int q, int g) {
@@ -536,7 +536,11 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
 }
 
 // a handful of windows: four workgroups per window
-static inline bool inorm_split(int B) { return B <= 32; }
+// Windows up to which a window's 256 channels go over four workgroups (option "inorm_split_max").  Round 4: EVERY batch - the variant built
+// for a handful of windows is also the faster one at 585 / 1 170 (mvn 77 -> 59 us, adain 43 -> 40, in_cha 43 -> 40; eight workgroups
+// per window: no further gain; tools/inorm_ab.py): four times the workgroups overlap each other's load -> reduce -> store phases.
+int inorm_split_max = 1 << 30;
+static inline bool inorm_split(int B) { return B <= inorm_split_max; }
 
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
                            int B, int n, hipStream_t s, const InormExtra* exp) {
