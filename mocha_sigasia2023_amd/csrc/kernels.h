@@ -122,6 +122,7 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
 // AdaIN + the attention's mapping norm (net/transformer.py:108-113, 49-56):
 //   xad = (1+gamma)*IN(x)+beta ; qin = IN(xad) ; gb (B,512) = [gamma | beta]
 extern int inorm_split_max;
+extern int embed_front_max_wgs;
 hipError_t launch_adain(const float* x, const float* gb, int gb_stride /*floats between windows*/, float* xad, float* qin, int B, int n, hipStream_t s);
 // u rows (b,t',p) x (dt*256+c) = 1/4 sum of the 4 reflect-indexed frames of tap dt (conv k=5 fused with AvgPool(4))
 hipError_t launch_window_sums(const float* y, float* u, int rows, int channels /*256 or 192*/, hipStream_t s);

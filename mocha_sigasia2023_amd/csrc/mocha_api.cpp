@@ -2163,6 +2163,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only
     if (n == "gemm_persistent_max_n") { gemm_x3_persistent_max_n = value < 128 ? 128 : value; c->generation++; return 0; }      // process-wide (diagnostic)
     if (n == "gemm_persistent") { gemm_x3_persistent = value < 0 ? 0 : (value + 7) / 8 * 8; c->generation++; return 0; }      // process-wide (diagnostic)
+    if (n == "embed_front_max_wgs") { embed_front_max_wgs = value; c->generation++; return 0; }              // process-wide (diagnostic)
     if (n == "inorm_split_max") { inorm_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // process-wide (diagnostic)
     if (n == "bank_tiled") { c->use_tiled = value != 0; c->generation++; return 0; }
     if (n == "match_planes") { if (value != 1 && value != 2) return fail(c, MOCHA_ERR_ARG, "match_planes must be 1 or 2"); c->match_planes = value; c->generation++; return 0; }

@@ -10,6 +10,14 @@ namespace mocha {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * x; }
+// the same value for every x (max(x, 0.2 x): x for x >= 0, 0.2 x below) in two instructions; the instruction is written out because fmaxf
+// brings a canonicalising v_max_f32 x, x per operand with it
+__device__ __forceinline__ float lrelu02_max(float x) {
+    const float y = 0.2f * x;
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -137,10 +145,10 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
 // ---------------------------------------------------------------------------------------
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restrict__ X, const float* __restrict__ W1,
-                                                            const float* __restrict__ b1, const float* __restrict__ AP,
-                                                            float* __restrict__ out, int nframes, int V, int Cin,
-                                                            const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
+__device__ __forceinline__ void embed_front_x3_body(const float* __restrict__ X, const float* __restrict__ W1,
+                                                    const float* __restrict__ b1, const float* __restrict__ AP,
+                                                    float* __restrict__ out, int nframes, int V, int Cin,
+                                                    const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
     __shared__ __attribute__((aligned(16))) float xs_all[4][32 * 20];       // rows of 20 floats: conflict-free b128 row reads
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
@@ -213,9 +221,9 @@ __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restr
         float* of = out + (size_t)frame * 18 * 64;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x16 h;
+            f32x16 h;                                              // the bias is the accumulator's initial value
 #pragma unroll
-            for (int r = 0; r < 16; ++r) h[r] = 0.f;
+            for (int r = 0; r < 16; ++r) h[r] = bias[t];
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xpl[PLANE_PA[pr]], wpl[t][PLANE_PB[pr]], h, 0, 0, 0);
             f32x16 o;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restr
             for (int j = 0; j < 2; ++j) {
                 float h8[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) h8[e] = lrelu02(h[8 * j + e] + bias[t]);
+                for (int e = 0; e < 8; ++e) h8[e] = lrelu02_max(h[8 * j + e]);
                 s16x8 hpl[3];
                 plane_split8(h8, hpl);
 #pragma unroll
@@ -241,13 +249,25 @@ __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restr
     }
 }
 
+__global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restrict__ X, const float* __restrict__ W1,
+                                                            const float* __restrict__ b1, const float* __restrict__ AP,
+                                                            float* __restrict__ out, int nframes, int V, int Cin,
+                                                            const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
+    embed_front_x3_body(X, W1, b1, AP, out, nframes, V, Cin, xmean, xstd, raw_root);
+}
+// Workgroups of the plane build: every workgroup pays the per-lane plane constants (W1, AP', the staging map) before its first frame, so the
+// grid is what the chip holds at once (2 workgroups of 4 waves per CU at 158 + 32 registers) and each wave takes ~17 frames of the demo
+// step: 78 -> 65 us per launch (profiles/r04/h_embed_front_ab.txt; 256: 79, 1024: 69, uncapped: 122).  Option "embed_front_max_wgs".
+int embed_front_max_wgs = 512;
+
 hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP, float* out,
                               int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root, hipStream_t s, bool planes) {
     if (nframes <= 0) return hipSuccess;
     if (V > 32 || Cin > 16 || V * Cin > 512) return hipErrorInvalidValue;
     const int wgs = (nframes + 3) / 4;
+    const int cap = !planes ? 2048 : embed_front_max_wgs > 0 ? embed_front_max_wgs : 512;
     if (planes)
-        hipLaunchKernelGGL(mocha_embed_front_x3, dim3(wgs < 2048 ? wgs : 2048), dim3(256), 0, s, X, W1, b1, AP, out,
+        hipLaunchKernelGGL(mocha_embed_front_x3, dim3(wgs < cap ? wgs : cap), dim3(256), 0, s, X, W1, b1, AP, out,
                            nframes, V, Cin, xmean, xstd, raw_root);
     else
         hipLaunchKernelGGL(mocha_embed_front, dim3(wgs < 2048 ? wgs : 2048), dim3(256), 0, s, X, W1, b1, AP, out,
