@@ -92,7 +92,9 @@ hipError_t launch_attention_x3_kv(const AttnKvParams& p, hipStream_t s);
 // raw_root = 1: X frames are (V+1, Cin) with the root bone first and are z-scored with xmean/xstd ((V+1)*Cin) on load
 hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP /*3*V*6*/,
                               float* out, int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root,
-                              hipStream_t s, bool planes = false);      // planes: both contractions as plane products on the bf16 pipe
+                              hipStream_t s, bool planes = false);
+hipError_t launch_embed_sums(const float* X, const float* W1, const float* b1, const float* AP, float* u, int nwin, int V, int Cin,
+                             const float* xmean, const float* xstd, int raw_root, hipStream_t s);      // planes: both contractions as plane products on the bf16 pipe
 // rows (b,t,p) x 256 -> LeakyReLU -> body-part adjacency (2 hops) -> rows (b,t,w) x (k*256+c)
 hipError_t launch_body_front(const float* x, const float* A_b /*2*6*6*/, float* out, int rows6 /*B*15*/, hipStream_t s);
 // g rows (b,t',p) x (k*64+c) -> y2c rows (b,t',w) x 64 : sum_k sum_p AU[k][p][w] g[...]
@@ -122,7 +124,7 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
 // AdaIN + the attention's mapping norm (net/transformer.py:108-113, 49-56):
 //   xad = (1+gamma)*IN(x)+beta ; qin = IN(xad) ; gb (B,512) = [gamma | beta]
 extern int inorm_split_max;
-extern int embed_front_max_wgs;
+extern int embed_front_max_wgs, embed_sums;
 hipError_t launch_adain(const float* x, const float* gb, int gb_stride /*floats between windows*/, float* xad, float* qin, int B, int n, hipStream_t s);
 // u rows (b,t',p) x (dt*256+c) = 1/4 sum of the 4 reflect-indexed frames of tap dt (conv k=5 fused with AvgPool(4))
 hipError_t launch_window_sums(const float* y, float* u, int rows, int channels /*256 or 192*/, hipStream_t s);

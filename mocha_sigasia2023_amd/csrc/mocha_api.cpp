@@ -498,6 +498,23 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     const int V = c->cfg.V;
     const int nn = (V + 1) * c->cfg.C_in;
     if (raw && !c->pose_norm) return fail(c, MOCHA_ERR_STATE, "raw input needs mocha_set_pose_norm first");
+    if (c->fold_joint && c->gemm_x3 && embed_sums) {
+        // conv1 + lrelu + adjacency + joint->part pool, and the 4-frame sums of the five taps, in one kernel: the frame rows stay in LDS
+        LAUNCH(c, s, "mocha_embed_sums_x3", "emb.front_sums", b * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18) + b * 90.0 * 960 * 4,
+               b * 4.0 * (60.0 * V * 15 + 90.0 * 960),
+               launch_embed_sums(X, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "u"), b, V, c->cfg.C_in,
+                                 raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s));
+        if (X2 && b2 > 0) {
+            LAUNCH(c, s, "mocha_embed_sums_x3", "emb.front_sums", b2 * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18) + b2 * 90.0 * 960 * 4,
+                   b2 * 4.0 * (60.0 * V * 15 + 90.0 * 960),
+                   launch_embed_sums(X2, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "u") + (size_t)b * 90 * 960, b2, V, c->cfg.C_in,
+                                     raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s));
+            b += b2;
+        }
+        GemmParams gf = plain(WS(c, "u"), 960, DW(c, "emb.Wc"), WS(c, "x5"), 256, b * 90, 256, 960);
+        gf.rowbias = DW(c, "emb.rbc"); gf.rb_mod = 6;
+        GEMM(c, s, "emb.joint_block", gf);
+    } else {
     // conv1 + lrelu + adjacency + joint->part pool (commuted)                  model.py:44-46
     const char* efk = c->gemm_x3 ? "mocha_embed_front_x3" : "mocha_embed_front";
     LAUNCH(c, s, efk, "emb.front", b * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b * 60.0 * (V * 15 + 6 * 192) * 4,
@@ -530,6 +547,7 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
                launch_window_sums(WS(c, "ybar"), WS(c, "u"), b * 90, 256, s));
     }
     GEMM(c, s, "emb.tcn_joint_pool", g2);
+    }
     }
     // body block                                                               model.py:48,137-162
     LAUNCH(c, s, "mocha_body_front", "emb.body_front", b * 90.0 * 512 * 12, b * 90.0 * (256 + 512) * 4, launch_body_front(WS(c, "x5"), DW(c, "A_b"), WS(c, "xA"), b * 15, s));
@@ -2163,6 +2181,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only
     if (n == "gemm_persistent_max_n") { gemm_x3_persistent_max_n = value < 128 ? 128 : value; c->generation++; return 0; }      // process-wide (diagnostic)
     if (n == "gemm_persistent") { gemm_x3_persistent = value < 0 ? 0 : (value + 7) / 8 * 8; c->generation++; return 0; }      // process-wide (diagnostic)
+    if (n == "embed_sums") { embed_sums = value != 0; c->generation++; return 0; }                          // process-wide (diagnostic)
     if (n == "embed_front_max_wgs") { embed_front_max_wgs = value; c->generation++; return 0; }              // process-wide (diagnostic)
     if (n == "inorm_split_max") { inorm_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // process-wide (diagnostic)
     if (n == "bank_tiled") { c->use_tiled = value != 0; c->generation++; return 0; }

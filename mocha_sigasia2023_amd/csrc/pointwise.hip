@@ -145,26 +145,24 @@ __global__ __launch_bounds__(256) void mocha_embed_front(const float* __restrict
 // ---------------------------------------------------------------------------------------
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void embed_front_x3_body(const float* __restrict__ X, const float* __restrict__ W1,
-                                                    const float* __restrict__ b1, const float* __restrict__ AP,
-                                                    float* __restrict__ out, int nframes, int V, int Cin,
-                                                    const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
-    __shared__ __attribute__((aligned(16))) float xs_all[4][32 * 20];       // rows of 20 floats: conflict-free b128 row reads
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, hh = lane >> 5;
-    float* xs = xs_all[wave];
-
-    // ---- per-lane plane constants
-    s16x8 wpl[2][3], apl[2][3];
+struct EmbedConsts {
+    s16x8 wpl[2][3], apl[2][3];       // W1 (this lane's channel of either half, its 8 features) and AP' (row pk = lane & 31) as planes
     float bias[2];
+    int slot[8];                      // staging map of this lane's (at most 8) elements of a frame: e = lane + 64 i -> joint e / Cin, feature e % Cin
+    float zm[8], zs[8];               // z-score of raw poses (mocha_set_pose_norm)
+};
+__device__ __forceinline__ void embed_consts(EmbedConsts& k, const float* __restrict__ W1, const float* __restrict__ b1,
+                                             const float* __restrict__ AP, int V, int Cin, const float* __restrict__ xmean,
+                                             const float* __restrict__ xstd, int raw_root, int lane) {
+    const int l31 = lane & 31, hh = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int c = t * 32 + l31;
-        bias[t] = b1[c];
+        k.bias[t] = b1[c];
         float w8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const int feat = 8 * hh + e; w8[e] = feat < Cin ? W1[c * Cin + feat] : 0.f; }
-        plane_split8(w8, wpl[t]);
+        plane_split8(w8, k.wpl[t]);
     }
     {
         const int pk = l31, pp = pk / 3, kk = pk - pp * 3;
@@ -176,21 +174,69 @@ __device__ __forceinline__ void embed_front_x3_body(const float* __restrict__ X,
                 const int joint = 16 * j + 8 * (e >> 2) + 4 * hh + (e & 3);
                 a8[e] = (pk < 18 && joint < V) ? AP[(kk * V + joint) * 6 + pp] : 0.f;
             }
-            plane_split8(a8, apl[j]);
+            plane_split8(a8, k.apl[j]);
         }
     }
-    // staging map of this lane's (at most 8) elements of a frame: element e = lane + 64 i -> joint e / Cin, feature e % Cin
     const int nelem = V * Cin;
-    int slot[8];
-    float zm[8], zs[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int e = lane + 64 * i;
         const int v = e / Cin, ci = e - v * Cin;
-        slot[i] = e < nelem ? v * 20 + ci : -1;
-        zm[i] = (xmean && e < nelem) ? xmean[raw_root * Cin + e] : 0.f;
-        zs[i] = (xmean && e < nelem) ? xstd[raw_root * Cin + e] : 1.f;
+        k.slot[i] = e < nelem ? v * 20 + ci : -1;
+        k.zm[i] = (xmean && e < nelem) ? xmean[raw_root * Cin + e] : 0.f;
+        k.zs[i] = (xmean && e < nelem) ? xstd[raw_root * Cin + e] : 1.f;
     }
+}
+// one frame: the staged (and z-scored) features go through this wave's LDS rows into MFMA operand order; both contractions.
+// o[t][r] = out[pk = (r&3) + 8 (r>>2) + 4 hh][channel t*32 + l31]; rows 18..31 are padding
+__device__ __forceinline__ void embed_stage_x3(const EmbedConsts& k, float* xs, const float (&xr)[8], bool zscore, float (&xa)[8], int lane) {
+    const int l31 = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (k.slot[i] >= 0) xs[k.slot[i]] = zscore ? (xr[i] - k.zm[i]) / k.zs[i] : xr[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xs + l31 * 20 + hh * 8);
+    const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xs + l31 * 20 + hh * 8 + 4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    xa[0] = xa0[0]; xa[1] = xa0[1]; xa[2] = xa0[2]; xa[3] = xa0[3]; xa[4] = xa1[0]; xa[5] = xa1[1]; xa[6] = xa1[2]; xa[7] = xa1[3];
+}
+__device__ __forceinline__ void embed_frame_x3(const EmbedConsts& k, const float (&xa)[8], f32x16 (&o)[2]) {
+    s16x8 xpl[3];
+    plane_split8(xa, xpl);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x16 h;                                                  // the bias is the accumulator's initial value
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[r] = k.bias[t];
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xpl[PLANE_PA[pr]], k.wpl[t][PLANE_PB[pr]], h, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float h8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h8[e] = lrelu02_max(h[8 * j + e]);
+            s16x8 hpl[3];
+            plane_split8(h8, hpl);
+#pragma unroll
+            for (int pr = 0; pr < 6; ++pr) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k.apl[j][PLANE_PA[pr]], hpl[PLANE_PB[pr]], o[t], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restrict__ X, const float* __restrict__ W1,
+                                                            const float* __restrict__ b1, const float* __restrict__ AP,
+                                                            float* __restrict__ out, int nframes, int V, int Cin,
+                                                            const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
+    __shared__ __attribute__((aligned(16))) float xs_all[4][32 * 20];       // rows of 20 floats: conflict-free b128 row reads
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    float* xs = xs_all[wave];
+    EmbedConsts k;
+    embed_consts(k, W1, b1, AP, V, Cin, xmean, xstd, raw_root, lane);
     for (int i = lane; i < 32 * 20; i += 64) xs[i] = 0.f;          // padding joints / the padding feature stay zero
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -201,60 +247,114 @@ __device__ __forceinline__ void embed_front_x3_body(const float* __restrict__ X,
     auto fetch = [&](int f) __attribute__((always_inline)) {
         const float* xf = X + (size_t)f * (V + raw_root) * Cin + raw_root * Cin;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) xr[i] = slot[i] >= 0 ? xf[lane + 64 * i] : 0.f;
+        for (int i = 0; i < 8; ++i) xr[i] = k.slot[i] >= 0 ? xf[lane + 64 * i] : 0.f;
     };
     if (frame < nframes) fetch(frame);
     for (; frame < nframes; frame += stride) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (slot[i] >= 0) xs[slot[i]] = xmean ? (xr[i] - zm[i]) / zs[i] : xr[i];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const f32x4 xa0 = *reinterpret_cast<const f32x4*>(xs + l31 * 20 + hh * 8);
-        const f32x4 xa1 = *reinterpret_cast<const f32x4*>(xs + l31 * 20 + hh * 8 + 4);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        float xa[8];
+        embed_stage_x3(k, xs, xr, xmean != nullptr, xa, lane);
         if (frame + stride < nframes) fetch(frame + stride);       // next frame's loads fly under this frame's MFMAs
-        const float xa[8] = {xa0[0], xa0[1], xa0[2], xa0[3], xa1[0], xa1[1], xa1[2], xa1[3]};
-        s16x8 xpl[3];
-        plane_split8(xa, xpl);
+        f32x16 o[2];
+        embed_frame_x3(k, xa, o);
         float* of = out + (size_t)frame * 18 * 64;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x16 h;                                              // the bias is the accumulator's initial value
-#pragma unroll
-            for (int r = 0; r < 16; ++r) h[r] = bias[t];
-#pragma unroll
-            for (int pr = 0; pr < 6; ++pr) h = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xpl[PLANE_PA[pr]], wpl[t][PLANE_PB[pr]], h, 0, 0, 0);
-            f32x16 o;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] = 0.f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float h8[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) h8[e] = lrelu02_max(h[8 * j + e]);
-                s16x8 hpl[3];
-                plane_split8(h8, hpl);
-#pragma unroll
-                for (int pr = 0; pr < 6; ++pr) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apl[j][PLANE_PA[pr]], hpl[PLANE_PB[pr]], o, 0, 0, 0);
-            }
-            // o[r] = out[pk = (r&3) + 8 (r>>2) + 4 hh][channel t*32 + l31]; rows 18..31 are padding
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 10; ++r) {
                 const int pk = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (pk < 18) of[pk * 64 + t * 32 + l31] = o[r];
+                if (pk < 18) of[pk * 64 + t * 32 + l31] = o[t][r];
             }
-        }
     }
 }
 
-__global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restrict__ X, const float* __restrict__ W1,
-                                                            const float* __restrict__ b1, const float* __restrict__ AP,
-                                                            float* __restrict__ out, int nframes, int V, int Cin,
-                                                            const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
-    embed_front_x3_body(X, W1, b1, AP, out, nframes, V, Cin, xmean, xstd, raw_root);
+// ---------------------------------------------------------------------------------------
+// embed_sums: embed_front and window_sums<48> in one kernel (the folded joint block's operand, mocha_api.cpp: fold_joint) - the
+// 192-channel frame rows never go to HBM (323 MB written and read again per demo step).  A workgroup's four waves take four
+// consecutive frames per step into an LDS ring of 12 frames; after step s of a run of pooled frames t' = a .. a + n - 1 of one
+// window (frames 4a - 2 + 4s + wave, reflected; n + 1 steps) the ring holds the 8 frames of t' = a + s - 1, whose five 4-frame sums the
+// whole workgroup writes - the same additions in the same order as mocha_window_sums.  The pooled frames of all windows are cut into
+// gridDim.x equal contiguous ranges (a range crosses windows; each piece of a window costs one extra step), one barrier per step.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mocha_embed_sums_x3(const float* __restrict__ X, const float* __restrict__ W1,
+                                                           const float* __restrict__ b1, const float* __restrict__ AP,
+                                                           float* __restrict__ u, int nwin, int V, int Cin,
+                                                           const float* __restrict__ xmean, const float* __restrict__ xstd, int raw_root) {
+    __shared__ __attribute__((aligned(16))) float xs_all[4][32 * 20];
+    __shared__ __attribute__((aligned(16))) float ring[12][18 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hh = lane >> 5;
+    float* xs = xs_all[wave];
+    EmbedConsts k;
+    embed_consts(k, W1, b1, AP, V, Cin, xmean, xstd, raw_root, lane);
+    for (int i = lane; i < 32 * 20; i += 64) xs[i] = 0.f;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const long long T = (long long)nwin * 15;
+    const int tp_begin = (int)(T * blockIdx.x / gridDim.x), tp_end = (int)(T * (blockIdx.x + 1) / gridDim.x);
+    if (tp_begin >= tp_end) return;
+    float xr[8];
+    auto fetch = [&](int w, int a, int s) __attribute__((always_inline)) {
+        int r = 4 * a - 2 + 4 * s + wave;
+        r = r < 0 ? -r : r;
+        r = r > 59 ? 118 - r : r;                                   // reflect padding (blocks.py:112-118)
+        const float* xf = X + ((size_t)w * 60 + r) * (V + raw_root) * Cin + raw_root * Cin;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xr[i] = k.slot[i] >= 0 ? xf[lane + 64 * i] : 0.f;
+    };
+    int tp0 = tp_begin;
+    int w = tp0 / 15, a = tp0 - w * 15, n = min(15 - a, tp_end - tp0), s = 0;
+    fetch(w, a, 0);
+    const f32x4* ring4 = reinterpret_cast<const f32x4*>(&ring[0][0]);
+    for (bool more = true; more;) {
+        float xa[8];
+        embed_stage_x3(k, xs, xr, xmean != nullptr, xa, lane);
+        // the step after this one: the next four frames of this run, or the first four of the next run
+        int w2 = w, a2 = a, n2 = n, s2 = s + 1;
+        if (s2 > n) {
+            tp0 += n;
+            if (tp0 >= tp_end) more = false;
+            else { w2 = tp0 / 15; a2 = tp0 - w2 * 15; n2 = min(15 - a2, tp_end - tp0); s2 = 0; }
+        }
+        if (more) fetch(w2, a2, s2);
+        f32x16 o[2];
+        embed_frame_x3(k, xa, o);
+        if (s == 0) __syncthreads();                                // the previous run's last sums are read before ring group 0 is rewritten
+        float* of = ring[4 * (s % 3) + wave];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 10; ++r) {
+                const int pk = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (pk < 18) of[pk * 64 + t * 32 + l31] = o[t][r];
+            }
+        __syncthreads();
+        if (s >= 1) {
+            // pooled frame a + s - 1: ring frames (relative) 4 (s - 1) .. 4 (s - 1) + 7; item = (body part, channel quad) = float4 index of a frame
+            const int g0 = 4 * ((s - 1) % 3), g1 = 4 * (s % 3);
+            f32x4* ur = reinterpret_cast<f32x4*>(u) + ((size_t)w * 15 + a + s - 1) * 6 * 240;
+            {
+                f32x4 f[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { f[i] = ring4[(g0 + i) * 288 + tid]; f[4 + i] = ring4[(g1 + i) * 288 + tid]; }
+                const int part = tid / 48, q = tid - part * 48;
+#pragma unroll
+                for (int dt = 0; dt < 5; ++dt) ur[part * 240 + dt * 48 + q] = (((f[dt] + f[dt + 1]) + f[dt + 2]) + f[dt + 3]) * 0.25f;
+            }
+            if (tid < 160) {                                        // the last 32 items, one (item, tap) pair per thread
+                const int it = 256 + tid / 5, dt = tid - (tid / 5) * 5;
+                f32x4 f[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int rel = dt + i; f[i] = ring4[((rel < 4 ? g0 : g1) + (rel & 3)) * 288 + it]; }
+                const int part = it / 48, q = it - part * 48;
+                ur[part * 240 + dt * 48 + q] = (((f[0] + f[1]) + f[2]) + f[3]) * 0.25f;
+            }
+        }
+        w = w2; a = a2; n = n2; s = s2;
+    }
 }
+int embed_sums = 1;                   // option "embed_sums": the fused kernel where the folded joint block and the plane engine are on
+
 // Workgroups of the plane build: every workgroup pays the per-lane plane constants (W1, AP', the staging map) before its first frame, so the
 // grid is what the chip holds at once (2 workgroups of 4 waves per CU at 158 + 32 registers) and each wave takes ~17 frames of the demo
 // step: 78 -> 65 us per launch (profiles/r04/h_embed_front_ab.txt; 256: 79, 1024: 69, uncapped: 122).  Option "embed_front_max_wgs".
@@ -272,6 +372,16 @@ hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, 
     else
         hipLaunchKernelGGL(mocha_embed_front, dim3(wgs < 2048 ? wgs : 2048), dim3(256), 0, s, X, W1, b1, AP, out,
                            nframes, V, Cin, xmean, xstd, raw_root);
+    return hipGetLastError();
+}
+
+hipError_t launch_embed_sums(const float* X, const float* W1, const float* b1, const float* AP, float* u, int nwin, int V, int Cin,
+                             const float* xmean, const float* xstd, int raw_root, hipStream_t s) {
+    if (nwin <= 0) return hipSuccess;
+    if (V > 32 || Cin > 16 || V * Cin > 512) return hipErrorInvalidValue;
+    const long long T = (long long)nwin * 15;
+    const int cap = embed_front_max_wgs > 0 ? embed_front_max_wgs : 512;
+    hipLaunchKernelGGL(mocha_embed_sums_x3, dim3((unsigned)(T < cap ? T : cap)), dim3(256), 0, s, X, W1, b1, AP, u, nwin, V, Cin, xmean, xstd, raw_root);
     return hipGetLastError();
 }
 

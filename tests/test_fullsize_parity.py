@@ -191,10 +191,15 @@ def test_config4_streamed_clip_x_16k_bank():
         bank_np = bank_nm.cpu().numpy()
         if bf16:
             c = bank_np.astype(np.float64).mean(0).astype(np.float32)
-            ridx, _ = O.match_bruteforce(q - c, _bf16_round(bank_np - c))
+            qs_np, searched = q - c, _bf16_round(bank_np - c)
         else:
-            ridx, _ = O.match_bruteforce(q, bank_np)
-        assert np.array_equal(idx_stream, ridx)
+            qs_np, searched = q, bank_np
+        ridx, _ = O.match_bruteforce(qs_np, searched)
+        mm = np.nonzero(idx_stream != ridx)[0]
+        if len(mm):                                       # as above: only fp32-level ties of the planted copies on the rounded bank
+            d_hip = np.linalg.norm(qs_np[mm].astype(np.float64) - searched[idx_stream[mm]].astype(np.float64), axis=1)
+            d_ref = np.linalg.norm(qs_np[mm].astype(np.float64) - searched[ridx[mm]].astype(np.float64), axis=1)
+            assert bf16 and len(mm) <= 3 and bool((np.abs(d_hip - d_ref) <= 2e-6 * d_ref).all()), (mm, d_hip, d_ref)
         assert len(set(idx_stream.tolist())) == W and (bf16 or np.array_equal(idx_stream, planted))
         assert len(diff) == 0 or bf16                     # fp32 rows: the copies stay 1e-3 apart, no ties
         sel = np.arange(0, W, 19)

@@ -225,3 +225,35 @@ def test_persistent_plane_gemm_is_bit_identical(persistent):
     model.set_option("gemm_persistent", 768); model.set_option("gemm_persistent_max_n", 512)        # the library's defaults (process-wide)
     for a, b in zip(out[0], out[persistent]):
         assert torch.equal(a, b), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("windows,cap", [(1, 512), (2, 512), (7, 3), (37, 512), (150, 64), (300, 512)])
+def test_embed_sums_is_the_two_kernel_path(windows, cap):
+    """Round 4: mocha_embed_sums_x3 = mocha_embed_front_x3 + mocha_window_sums<48> with the 192-channel frame rows kept in an LDS ring.
+    A workgroup takes a contiguous range of pooled frames that may start and end inside a window (every piece pays one extra step and
+    reflects at the window's ends): the same per-frame products and the same four additions in the same order, so the embedding is
+    bit-identical - for one window, ranges shorter than a window (more workgroups than windows), ranges of many windows (cap = 3 / 64
+    workgroups), z-scored raw poses included."""
+    sd = weights.synthetic_state_dict(29, 1.5)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    X = torch.from_numpy(synthetic.pose_windows(77 + windows, windows)).to(dev())
+    V = X.shape[2]
+    g = torch.Generator(device="cpu"); g.manual_seed(windows)
+    nn = (V + 1) * 15
+    model.set_pose_norm(torch.randn(nn, generator=g).numpy(), (0.5 + torch.rand(nn, generator=g)).numpy(),
+                        torch.randn(nn, generator=g).numpy(), (0.5 + torch.rand(nn, generator=g)).numpy())
+    Xraw = torch.randn((windows, 60, V + 1, 15), generator=g).to(dev())
+    out = {}
+    try:
+        for fused in (0, 1):
+            model.set_option("embed_sums", fused); model.set_option("embed_front_max_wgs", cap)
+            model.profile_start()
+            tok = model.mot_embedding(X).clone()
+            kern = model.profile_stop()["kernels"]
+            assert ("mocha_embed_sums_x3" in kern) == bool(fused) and ("mocha_window_sums" in kern) != bool(fused), kern.keys()
+            enc, cnt = model.encode(Xraw, raw=True)[:2]
+            out[fused] = (tok, enc.clone(), cnt.clone())
+    finally:
+        model.set_option("embed_sums", 1); model.set_option("embed_front_max_wgs", 512)            # the library's defaults (process-wide)
+    for a, b in zip(out[0], out[1]):
+        assert torch.equal(a, b), float((a - b).abs().max())

@@ -10,8 +10,8 @@ model = Generator(layout="mixamo", device=dev).load_state_dict(synthetic_state_d
 src = torch.from_numpy(synthetic.pose_windows(1777, W, V)).to(dev); cha = torch.from_numpy(synthetic.pose_windows(4242, W, V)).to(dev)
 m_, s_ = synthetic.cnt_norm(7); mean, std = torch.from_numpy(m_).to(dev), torch.from_numpy(s_).to(dev)
 ref = None
-for var, cap in [(0, 2048), (0, 512), (0, 640), (0, 512)]:
-    model.set_option("embed_front_max_wgs", cap)
+for var, cap in [(0, 512), (1, 512), (1, 768), (1, 384), (0, 512), (1, 512)]:
+    model.set_option("embed_sums", var); model.set_option("embed_front_max_wgs", cap)
     for _ in range(3): Y = model.characterize_pair(src, cha, mean, std)
     Y = Y[0] if isinstance(Y, (tuple, list)) else Y
     if ref is None: ref = Y.clone()
@@ -22,5 +22,5 @@ for var, cap in [(0, 2048), (0, 512), (0, 640), (0, 512)]:
     model.profile_start()
     for _ in range(3): model.characterize_pair(src, cha, mean, std)
     p = model.profile_stop()["sites"]
-    pick = {s.split("|")[0]: v["ms"] / v["launches"] * 1e3 for s, v in p.items() if "embed_front" in s}
-    print(f"variant={var} cap={cap:>8}: step {ms:6.3f} ms  same={same}  " + "  ".join(f"{a} {b:6.1f}" for a, b in sorted(pick.items())), flush=True)
+    pick = {s.split("|")[0]: v["ms"] / v["launches"] * 1e3 for s, v in p.items() if "emb.front" in s or "window_sums" in s}
+    print(f"embed_sums={var} cap={cap:>8}: step {ms:6.3f} ms  same={same}  " + "  ".join(f"{a} {b:6.1f}" for a, b in sorted(pick.items())), flush=True)
