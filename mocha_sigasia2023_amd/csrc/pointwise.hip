@@ -202,7 +202,9 @@ __device__ __forceinline__ void embed_stage_x3(const EmbedConsts& k, float* xs, 
     __builtin_amdgcn_wave_barrier();
     xa[0] = xa0[0]; xa[1] = xa0[1]; xa[2] = xa0[2]; xa[3] = xa0[3]; xa[4] = xa1[0]; xa[5] = xa1[1]; xa[6] = xa1[2]; xa[7] = xa1[3];
 }
-__device__ __forceinline__ void embed_frame_x3(const EmbedConsts& k, const float (&xa)[8], f32x16 (&o)[2]) {
+// `narrow` (V <= 24, wave-uniform): the joints 24..31 of the second contraction are padding - AP' is zero there - so their half of the
+// accumulator is neither activated nor split (a quarter of the frame's split instructions)
+__device__ __forceinline__ void embed_frame_x3(const EmbedConsts& k, const float (&xa)[8], f32x16 (&o)[2], bool narrow) {
     s16x8 xpl[3];
     plane_split8(xa, xpl);
 #pragma unroll
@@ -216,11 +218,19 @@ __device__ __forceinline__ void embed_frame_x3(const EmbedConsts& k, const float
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            float h8[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) h8[e] = lrelu02_max(h[8 * j + e]);
             s16x8 hpl[3];
-            plane_split8(h8, hpl);
+            if (j == 1 && narrow) {
+                const f32x4 h4 = {lrelu02_max(h[8]), lrelu02_max(h[9]), lrelu02_max(h[10]), lrelu02_max(h[11])};
+                u32x2_t a[3];
+                plane_split4(h4, a);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const u32x4_t v = {a[q][0], a[q][1], 0u, 0u}; hpl[q] = __builtin_bit_cast(s16x8, v); }
+            } else {
+                float h8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) h8[e] = lrelu02_max(h[8 * j + e]);
+                plane_split8(h8, hpl);
+            }
 #pragma unroll
             for (int pr = 0; pr < 6; ++pr) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k.apl[j][PLANE_PA[pr]], hpl[PLANE_PB[pr]], o[t], 0, 0, 0);
         }
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(256) void mocha_embed_front_x3(const float* __restr
         embed_stage_x3(k, xs, xr, xmean != nullptr, xa, lane);
         if (frame + stride < nframes) fetch(frame + stride);       // next frame's loads fly under this frame's MFMAs
         f32x16 o[2];
-        embed_frame_x3(k, xa, o);
+        embed_frame_x3(k, xa, o, V <= 24);
         float* of = out + (size_t)frame * 18 * 64;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -318,7 +328,7 @@ __global__ __launch_bounds__(256) void mocha_embed_sums_x3(const float* __restri
         }
         if (more) fetch(w2, a2, s2);
         f32x16 o[2];
-        embed_frame_x3(k, xa, o);
+        embed_frame_x3(k, xa, o, V <= 24);
         if (s == 0) __syncthreads();                                // the previous run's last sums are read before ring group 0 is rewritten
         float* of = ring[4 * (s % 3) + wave];
 #pragma unroll
