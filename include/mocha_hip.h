@@ -312,7 +312,17 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * 0 runs the two convolutions as two GEMMs.  Differences are fp32 rounding only.
  * "lanes" (default 1, 1..3): workspace sets / captured graphs for mocha_step_graph_lane; changing it re-plans the workspaces.
  * "scan16" (default 1): see MOCHA_BANK_BF16 above - fp32 banks of >= 4096 rows are scanned through a centred bf16 copy with an
- * exact fp32 re-rank when at most 8 queries are matched; takes effect at the next mocha_bank_set; 0 scans the fp32 rows. */
+ * exact fp32 re-rank when at most 8 queries are matched; takes effect at the next mocha_bank_set; 0 scans the fp32 rows.
+ * Round 4 (INTEGRATION.md section 6 has the table): "embed_sums" (default 1; process-wide): mot_embedding's first stage and the joint
+ * block's five-tap 4-frame sums in one kernel whose frame rows stay in LDS (0: two kernels, bit-identical); "embed_front_max_wgs"
+ * (default 512; process-wide): that kernel's persistent grid; "inorm_split_max" (default: every batch; process-wide): windows up to
+ * which the instance norms spread a window's channels over four workgroups (bit-identical either way); "gemm_persistent" (default 768
+ * workgroups; 0 = off) and "gemm_persistent_max_n" (default 512): the plane GEMM's persistent instance, bit-identical; "select2"
+ * (default 1) / "match_planes" (default 1; 2 = two bf16 query planes in the bf16 coarse pass): the many-query selection with
+ * producer-side row statistics - the same exact result; "attention_kv", "attention_kv_pairs" (default 0): decoder attention from
+ * pre-split key / value images, bit-identical; "bank_tiled" (default 0): bf16 banks, a tiled image for the many-query coarse pass;
+ * "dual_min" (default 128): smallest batch that "dual_stream" splits over two streams (re-plans the workspaces).
+ * Every option that changes which kernels a step launches bumps mocha_generation(ctx). */
 int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
 
 /* y (M,N) = x (M,K) · w (N,K)^T + bias (N, may be NULL): nn.Linear (net/transformer.py:28-32, 57-61) as a stand-alone
