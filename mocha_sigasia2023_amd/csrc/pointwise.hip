@@ -440,30 +440,55 @@ hipError_t launch_body_front(const float* x, const float* A_b, float* out, int r
 // nearest x4 upsampling, model.py:74, repeats frames and is folded into the next GEMM's gather):
 //   out[(f,w)][c] = sum_k sum_p AU[k][p][w] g[(f,p)][k*64+c],   AU[k][p][w] = sum_{v in part p} A_j[k][v][w]
 // ---------------------------------------------------------------------------------------
+// Round 4: a wave owns a frame and a lane a channel - the 18 inputs of that channel (6 parts x 3 gcn slices) are fetched straight into
+// registers (coalesced 256-byte runs); per input the V coefficients of its row of AU are wave-uniform and contiguous (scalar loads), one
+// accumulator per joint; no LDS, no barrier.  The first build staged a frame in LDS and read two LDS words per FMA: LDS-bound at 0.33 of
+// the HBM peak.  Same products in the same order per output.  VT = joints at compile time (22, 24) or 0: any V <= 32, a loop over joints.
+template <int VT>
 __global__ __launch_bounds__(256) void mocha_joint_expand(const float* __restrict__ g, const float* __restrict__ AU,
                                                           float* __restrict__ out, int frames, int V) {
-    __shared__ float gs[6 * 192];
-    __shared__ float au[3 * 6 * 32];
-    const int tid = threadIdx.x;
-    const int f = blockIdx.x;
-    for (int i = tid; i < 3 * 6 * V; i += 256) au[i] = AU[i];
-    for (int i = tid; i < 6 * 192; i += 256) gs[i] = g[(size_t)f * 6 * 192 + i];
-    __syncthreads();
-    const int c = tid & 63;
-    for (int w = tid >> 6; w < V; w += 4) {
-        float a = 0.f;
+    const int c = threadIdx.x & 63;
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (f >= frames) return;
+    const float* gf = g + (size_t)f * 6 * 192 + c;
+    float gv[3][6];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int p = 0; p < 6; ++p) gv[k][p] = gf[p * 192 + k * 64];
+    if (VT > 0) {
+        float* of = out + (size_t)f * VT * 64 + c;
+        float acc[VT > 0 ? VT : 1];
+#pragma unroll
+        for (int w = 0; w < VT; ++w) acc[w] = 0.f;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int p = 0; p < 6; ++p) a = fmaf(au[(k * 6 + p) * V + w], gs[p * 192 + k * 64 + c], a);
-        out[((size_t)f * V + w) * 64 + c] = a;
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int w = 0; w < VT; ++w) acc[w] = fmaf(AU[(k * 6 + p) * VT + w], gv[k][p], acc[w]);
+#pragma unroll
+        for (int w = 0; w < VT; ++w) of[w * 64] = acc[w];
+    } else {
+        float* of = out + (size_t)f * V * 64 + c;
+        for (int w = 0; w < V; ++w) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int p = 0; p < 6; ++p) a = fmaf(AU[(k * 6 + p) * V + w], gv[k][p], a);
+            of[w * 64] = a;
+        }
     }
 }
 
 hipError_t launch_joint_expand(const float* g, const float* AU, float* out, int nframes15, int V, hipStream_t s) {
     if (nframes15 <= 0) return hipSuccess;
     if (V > 32) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_joint_expand, dim3(nframes15), dim3(256), 0, s, g, AU, out, nframes15, V);
+    const dim3 grid((nframes15 + 3) / 4);
+    if (V == 22) hipLaunchKernelGGL(mocha_joint_expand<22>, grid, dim3(256), 0, s, g, AU, out, nframes15, V);
+    else if (V == 24) hipLaunchKernelGGL(mocha_joint_expand<24>, grid, dim3(256), 0, s, g, AU, out, nframes15, V);
+    else hipLaunchKernelGGL(mocha_joint_expand<0>, grid, dim3(256), 0, s, g, AU, out, nframes15, V);
     return hipGetLastError();
 }
 
