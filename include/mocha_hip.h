@@ -322,6 +322,9 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * producer-side row statistics - the same exact result; "attention_kv", "attention_kv_pairs" (default 0): decoder attention from
  * pre-split key / value images, bit-identical; "bank_tiled" (default 0): bf16 banks, a tiled image for the many-query coarse pass;
  * "dual_min" (default 128): smallest batch that "dual_stream" splits over two streams (re-plans the workspaces).
+ * "fold_upsample" (default 1): to_mot's k = 5 temporal conv over the nearest-x4-upsampled frames (model.py:74, net/blocks.py:112-118) as a
+ * 3-tap conv over the 15 source frames with per-phase summed weights (exact algebra; differences are fp32 rounding of the weight sums);
+ * "upsample_split_min" (default 256): windows from which it runs as two 2-tap launches.
  * Every option that changes which kernels a step launches bumps mocha_generation(ctx). */
 int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
 

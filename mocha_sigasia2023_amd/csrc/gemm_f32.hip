@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 64 ? 
             if (cin == 0 || s == s_begin) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    int tf = a_t[i] * p.stride + tap - p.pad;
+                    int tf = a_t[i] * p.stride + tap * p.tstep - p.pad;
                     tf = tf < 0 ? -tf : tf;
                     tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
                     a_off[i] = ((unsigned)(a_rb[i] + (tf >> p.tshift) * p.V) * (unsigned)p.lda + lcol) * 4u;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 64 ? 
             for (int i = 0; i < NA; ++i) {
                 f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
                 for (int j = 0; j < p.R; ++j) {
-                    int tf = a_t[i] * p.stride + j + tap - p.pad;
+                    int tf = a_t[i] * p.stride + j + tap * p.tstep - p.pad;
                     tf = tf < 0 ? -tf : tf;
                     tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
                     const int row = a_rb[i] + (tf >> p.tshift) * p.V;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_skinny(GemmParams p) {
                     const int k = kb + 4 * hh;
                     const int tap = k / p.Cc;
                     const int cc = k - tap * p.Cc;
-                    int tf = a_t * p.stride + tap - p.pad;
+                    int tf = a_t * p.stride + tap * p.tstep - p.pad;
                     tf = tf < 0 ? -tf : tf;
                     tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
                     a4[g] = bload(rsA, ((unsigned)(a_rb + (tf >> p.tshift) * p.V) * (unsigned)p.lda + (unsigned)cc) * 4u, 0u);
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void mocha_gemm_skinny16(GemmParams p) {
                     const int k = kb + 4 * kq;
                     const int tap = k / p.Cc;
                     const int cc = k - tap * p.Cc;
-                    int tf = a_t * p.stride + tap - p.pad;
+                    int tf = a_t * p.stride + tap * p.tstep - p.pad;
                     tf = tf < 0 ? -tf : tf;
                     tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
                     a4[g] = bload(rsA, ((unsigned)(a_rb + (tf >> p.tshift) * p.V) * (unsigned)p.lda + (unsigned)cc) * 4u, 0u);

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const int cin = k0 - tap * p.Cc;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                int tf = a_t[i] * p.stride + tap - p.pad;
+                int tf = a_t[i] * p.stride + tap * p.tstep - p.pad;
                 tf = tf < 0 ? -tf : tf;
                 tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
                 const unsigned off = ((unsigned)(a_rb[i] + (tf >> p.tshift) * p.V) * (unsigned)p.lda + lc * 4) * 4u;
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             const int cin = k0 - tap * p.Cc;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                int tf = T.a_t[i] * p.stride + tap - p.pad;
+                int tf = T.a_t[i] * p.stride + tap * p.tstep - p.pad;
                 tf = tf < 0 ? -tf : tf;
                 tf = tf >= p.T_full ? 2 * (p.T_full - 1) - tf : tf;
                 const unsigned off = ((unsigned)(T.a_rb[i] + (tf >> p.tshift) * p.V) * (unsigned)p.lda + lc * 4) * 4u;

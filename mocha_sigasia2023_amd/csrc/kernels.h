@@ -13,9 +13,10 @@ namespace mocha {
 // (batch, time, node, channel) activation tensor that realises a temporal convolution with
 // reflect padding as a GEMM (net/blocks.py:112-118): for output row (b, t, v) and
 // k = tap*Cc + c the operand is
-//      ascale * sum_{j<R} src[(b, refl(t*stride + j + tap - pad, T_full) >> tshift, v), c]
+//      ascale * sum_{j<R} src[(b, refl(t*stride + j + tap*tstep - pad, T_full) >> tshift, v), c]
 // R = 4, stride = 4 additionally folds AvgPool2d((4,1)) (model.py:47) into the operand;
-// tshift = 2 reads a nearest-x4-upsampled tensor (model.py:74) without materialising it.
+// tshift = 2 reads a nearest-x4-upsampled tensor (model.py:74) without materialising it; tstep = 4 with stride = 4 walks that tensor's
+// SOURCE frames (taps a source frame apart; the reflection at the upsampled ends is then a clamp on source frames: mocha_api.cpp, fold_upsample).
 // ---------------------------------------------------------------------------------------
 struct GemmParams {
     const float* A = nullptr;     // source activations
@@ -33,6 +34,7 @@ struct GemmParams {
     int a_lrelu = 0;      // LeakyReLU(0.2) applied to the A operand as it is loaded
     int gather = 0;       // 0 plain rows, 1 temporal gather
     int T_out = 1, V = 1, ntaps = 1, pad = 0, stride = 1, R = 1, T_full = 1, tshift = 0, Cc = 0, T_src = 1;
+    int tstep = 1;        // distance between taps on the T_full time line
     float ascale = 1.f;
     int ksplit = 1;               // >1: split K over gridDim.z, raw partial sums to C + z*slab_stride
     long long slab_stride = 0;
@@ -102,7 +104,7 @@ hipError_t launch_joint_expand(const float* g, const float* AU /*3*6*V*/, float*
 // z rows x 64 -> LeakyReLU -> 1x1 conv 64->Cout + bias -> Y rows x Cout   [model.py:77-79]
 // ymean/ystd ((V+1)*Cout, root row first) non-null: Y is de-normalised in the epilogue
 hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, float* Y, int rows, int Cout, int V,
-                             const float* ymean, const float* ystd, hipStream_t s);
+                             const float* ymean, const float* ystd, hipStream_t s, int phased = 0);
 // per (b, channel) instance norm over n tokens (net/transformer.py:13-20).
 //   out = (x-mean)/(std+eps); mean_out (B,256) optional; zn = (out - gm)/gs optional
 // optional extras of the instance norm: zc = zn - centre (the matcher's centred queries, bit-identical to mocha_sub_rows on zn);

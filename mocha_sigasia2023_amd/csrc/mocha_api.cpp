@@ -166,6 +166,8 @@ struct mocha_ctx {
     bool attn_x3 = true;               // the Generator's attention as plane products on the bf16 pipe (attention_x3.hip)
     std::map<std::tuple<const float*, int, int>, unsigned short*> x3w;
     bool fold_decoder = true;          // decoder key / value projections folded into the query / output weights
+    int upsample_split_min = 256;      // windows from which that conv runs as two 2-tap launches (no zero weight blocks)
+    bool fold_upsample = true;         // to_mot: the k=5 temporal conv over the x4-upsampled frames as a 3-tap conv over the SOURCE frames with per-phase summed weights
     bool fold_joint = true;            // embedding joint block: gcn 1x1 conv folded into the k=5 temporal conv (one K = 960 GEMM)
     int* bone_parents = nullptr;       // device: parents of the (V+1)-bone skeleton with the root bone in front
     float* pose_norm = nullptr;        // [x_mean | x_std | y_mean | y_std], (V+1)*C_in each (norm.npz of the reference)
@@ -697,12 +699,27 @@ int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s
     GEMM(c, s, "mot.gcn_joint", g3);
     LAUNCH(c, s, "mocha_joint_expand", "mot.joint_expand", b * 15.0 * V * 64 * 36, b * 15.0 * (6 * 192 + V * 64) * 4, launch_joint_expand(WS(c, "g"), DW(c, "AU"), WS(c, "y2c"), b * 15, V, s));
     // temporal conv k=5 over the x4-upsampled frames, read through the gather (t >> 2)
+    if (c->fold_upsample) {
+        // rows (window, source frame s, joint), columns (phase, channel): z[(b, s, v)][phase*64 + c] is the conv's output at frame 4 s + phase
+        GemmParams g4 = plain(WS(c, "y2c"), 64, DW(c, "mot.Wt2p"), WS(c, "z"), 256, b * 15 * V, 256, 192);
+        g4.gather = 1; g4.T_out = 15; g4.V = V; g4.ntaps = 3; g4.pad = 2; g4.stride = 4; g4.tstep = 4; g4.R = 1; g4.T_full = 60;
+        g4.tshift = 2; g4.Cc = 64; g4.T_src = 15; g4.bias = DW(c, "mot.bt2p");
+        if (b >= c->upsample_split_min) {
+            // large batches: two launches of two taps each instead of one with a third of its weight blocks zero
+            GemmParams ga = g4; ga.W = DW(c, "mot.Wt2a"); ga.N = 128; ga.K = 128; ga.ntaps = 2;
+            GEMM(c, s, "mot.tcn_joint", ga);
+            GemmParams gb = ga; gb.W = DW(c, "mot.Wt2b"); gb.C = WS(c, "z") + 128; gb.pad = -2; gb.bias = DW(c, "mot.bt2p") + 128;
+            GEMM(c, s, "mot.tcn_joint", gb);
+        } else
+        GEMM(c, s, "mot.tcn_joint", g4);
+    } else {
     GemmParams g4 = plain(WS(c, "y2c"), 64, DW(c, "mot.Wt2"), WS(c, "z"), 64, b * 60 * V, 64, 320);
     g4.gather = 1; g4.T_out = 60; g4.V = V; g4.ntaps = 5; g4.pad = 2; g4.stride = 1; g4.R = 1; g4.T_full = 60;
     g4.tshift = 2; g4.Cc = 64; g4.T_src = 15; g4.bias = DW(c, "mot.bt2");
     GEMM(c, s, "mot.tcn_joint", g4);
+    }
     LAUNCH(c, s, "mocha_final_proj", "mot.final_proj", b * 60.0 * V * 64 * 15 * 2, b * 60.0 * V * (64 + 15) * 4, launch_final_proj(WS(c, "z"), DW(c, "mot.W6"), DW(c, "mot.b6"), Y, b * 60 * V, c->cfg.C_in, V,
-                             denorm ? c->pose_norm + 2 * nn : nullptr, denorm ? c->pose_norm + 3 * nn : nullptr, s));
+                             denorm ? c->pose_norm + 2 * nn : nullptr, denorm ? c->pose_norm + 3 * nn : nullptr, s, c->fold_upsample ? 1 : 0));
     return 0;
 }
 
@@ -1192,6 +1209,32 @@ int mocha_finalize_weights(mocha_ctx* c) {
     // ---- to_mot joint block + head
     up("mot.Wg2", W(c, "to_mot.4.blk.gcn.conv.weight")); up("mot.bg2", W(c, "to_mot.4.blk.gcn.conv.bias"));
     up("mot.Wt2", repack_tcn(W(c, "to_mot.4.blk.tcn.weight"), 64, 64, 5)); up("mot.bt2", W(c, "to_mot.4.blk.tcn.bias"));
+    {
+        // Output frame t = 4 s + phase of the k = 5 conv over the nearest-x4-upsampled frames (model.py:74, net/blocks.py:112-118) reads
+        // upsampled frames t-2 .. t+2 = source frames s-1, s, s+1 only, each several times: the taps that land on one source frame are
+        // summed into one weight.  [phase*64 + co][j*64 + ci], j = source frame s-1, s, s+1; a third of the blocks are zero.
+        // The reflection at the upsampled ends (frames -2, -1 -> 2, 1; 60, 61 -> 58, 57) stays inside the first / last source frame.
+        const std::vector<float>& w = W(c, "to_mot.4.blk.tcn.weight");          // (64, 64, 5, 1)
+        static const int JOF[4][5] = {{0, 0, 1, 1, 1}, {0, 1, 1, 1, 1}, {1, 1, 1, 1, 2}, {1, 1, 1, 2, 2}};
+        std::vector<double> acc((size_t)256 * 192, 0.0);
+        for (int ph = 0; ph < 4; ++ph)
+            for (int co = 0; co < 64; ++co)
+                for (int ci = 0; ci < 64; ++ci)
+                    for (int t = 0; t < 5; ++t) acc[((size_t)ph * 64 + co) * 192 + JOF[ph][t] * 64 + ci] += (double)w[((size_t)co * 64 + ci) * 5 + t];
+        std::vector<float> wp(acc.size()), bp(256);
+        for (size_t i = 0; i < acc.size(); ++i) wp[i] = (float)acc[i];
+        const std::vector<float>& bt = W(c, "to_mot.4.blk.tcn.bias");
+        for (int i = 0; i < 256; ++i) bp[i] = bt[i & 63];
+        up("mot.Wt2p", wp); up("mot.bt2p", bp);
+        // the same without the zero blocks, for large batches: phases 0, 1 read source frames (s-1, s), phases 2, 3 read (s, s+1)
+        std::vector<float> wa((size_t)128 * 128), wb((size_t)128 * 128);
+        for (int r = 0; r < 128; ++r)
+            for (int k = 0; k < 128; ++k) {
+                wa[(size_t)r * 128 + k] = wp[(size_t)r * 192 + k];
+                wb[(size_t)r * 128 + k] = wp[(size_t)(128 + r) * 192 + 64 + k];
+            }
+        up("mot.Wt2a", wa); up("mot.Wt2b", wb);
+    }
     up("mot.W6", W(c, "to_mot.6.weight")); up("mot.b6", W(c, "to_mot.6.bias"));
     if (rc) return rc;
     c->finalized = true;
@@ -2176,6 +2219,8 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     // Path-selecting options change which kernels a step launches: a captured step graph (mocha_step_graph_lane, OursSession)
     // replays the old path until it is re-captured, so every one of them moves the generation.
     if (n == "fold_decoder") { c->fold_decoder = value != 0; c->generation++; return 0; }
+    if (n == "upsample_split_min") { c->upsample_split_min = value; c->generation++; return 0; }
+    if (n == "fold_upsample") { c->fold_upsample = value != 0; c->generation++; return 0; }
     if (n == "fold_joint") { c->fold_joint = value != 0; c->generation++; return 0; }
     if (n == "scan16") { c->scan16 = value != 0; c->generation++; return 0; }             // bank side takes effect at the next mocha_bank_set
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only

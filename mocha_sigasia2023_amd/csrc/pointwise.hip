@@ -501,17 +501,24 @@ hipError_t launch_joint_expand(const float* g, const float* AU, float* out, int 
 __global__ __launch_bounds__(256) void mocha_final_proj(const float* __restrict__ z, const float* __restrict__ W6,
                                                         const float* __restrict__ b6, float* __restrict__ Y, int rows,
                                                         int Cout, int V, const float* __restrict__ ymean,
-                                                        const float* __restrict__ ystd) {
+                                                        const float* __restrict__ ystd, int phased) {
     __shared__ float ys[128 * 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int r0 = blockIdx.x * 128;
     const int row = r0 + wave * 32 + l31;
+    // phased (mocha_api.cpp, fold_upsample): z holds rows (window, source frame s, joint) x (phase, channel); output row (window, t, joint)
+    // reads the 64 channels of phase t & 3 in row (window, t >> 2, joint)
+    const float* zr = z + (size_t)row * 64;
+    if (phased && row < rows) {
+        const int v = row % V, bt = row / V, t = bt % 60, b = bt / 60;
+        zr = z + ((size_t)(b * 15 + (t >> 2)) * V + v) * 256 + (t & 3) * 64;
+    }
     f32x4 a[8], w[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        a[q] = row < rows ? *reinterpret_cast<const f32x4*>(z + (size_t)row * 64 + 8 * q + 4 * hh) : zero;
+        a[q] = row < rows ? *reinterpret_cast<const f32x4*>(zr + 8 * q + 4 * hh) : zero;
         w[q] = l31 < Cout ? *reinterpret_cast<const f32x4*>(W6 + l31 * 64 + 8 * q + 4 * hh) : zero;
     }
     f32x16 d;
@@ -541,10 +548,10 @@ __global__ __launch_bounds__(256) void mocha_final_proj(const float* __restrict_
 }
 
 hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, float* Y, int rows, int Cout, int V,
-                             const float* ymean, const float* ystd, hipStream_t s) {
+                             const float* ymean, const float* ystd, hipStream_t s, int phased) {
     if (rows <= 0) return hipSuccess;
     if (Cout > 16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_final_proj, dim3((rows + 127) / 128), dim3(256), 0, s, z, W6, b6, Y, rows, Cout, V, ymean, ystd);
+    hipLaunchKernelGGL(mocha_final_proj, dim3((rows + 127) / 128), dim3(256), 0, s, z, W6, b6, Y, rows, Cout, V, ymean, ystd, phased);
     return hipGetLastError();
 }
 

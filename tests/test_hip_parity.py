@@ -456,6 +456,37 @@ def test_joint_block_folding_is_only_rounding(golden_dir, name):
     assert float((f2 - l2).abs().max()) < 1e-5 * float(l2.abs().max())
 
 
+@pytest.mark.parametrize("name", VARIANTS)
+def test_upsample_folding_is_only_rounding(golden_dir, name):
+    """Default path (round 4): to_mot's k = 5 temporal conv over the nearest-x4-upsampled frames (model.py:74, net/blocks.py:112-118) runs
+    as a 3-tap conv over the 15 SOURCE frames with per-phase summed weights (output frame 4 s + phase only ever reads source frames
+    s-1, s, s+1; the reflection at the upsampled ends stays inside the first / last source frame); mocha_set_option "fold_upsample".
+    Folded and literal forms both meet the fixture tolerance and agree to fp32 rounding - at fixture size (fp32 kernels), on a batch
+    large enough for the plane engine, with both engines, and on every frame (the first and last source frames are where the
+    reflection matters)."""
+    z, meta, model, _ = load(golden_dir, name)
+    dec = T(z["decoded"])
+    folded = model.to_mot(dec)
+    model.set_option("fold_upsample", 0)
+    literal = model.to_mot(dec)
+    model.set_option("fold_upsample", 1)
+    assert absmax(folded, z["Y"]) < TOL and absmax(literal, z["Y"]) < TOL
+    assert not torch.equal(folded, literal)
+    assert float((folded - literal).abs().max()) < 1e-5 * float(literal.abs().max())
+    g = torch.Generator(device="cpu"); g.manual_seed(3)
+    for engine in (1, 0):
+        model.set_option("gemm_bf16x3", engine)
+        for B in (96, 7):
+            big = (2.0 * torch.randn((B, 90, 256), generator=g)).to(dev())
+            f2 = model.to_mot(big)
+            model.set_option("fold_upsample", 0)
+            l2 = model.to_mot(big)
+            model.set_option("fold_upsample", 1)
+            d = (f2 - l2).abs().amax(dim=(0, 2, 3))                 # per frame
+            assert float(d.max()) < 1e-5 * float(l2.abs().max()), d
+    model.set_option("gemm_bf16x3", 1)
+
+
 def test_characterize_pair_matches_the_three_call_path():
     """mocha_characterize_pair = encode(cha) + bank_set + characterize(src) with shared launches: same indices, outputs equal
     up to the kernel choice of a larger batch (<= 2e-6 relative), the context's own bank untouched, oracle parity."""

@@ -317,11 +317,11 @@ def test_dual_stream_with_lane_sets_never_halves_into_a_small_set():
 
 def test_path_selecting_options_move_the_generation(model):
     """an option that changes which kernels a step launches must invalidate captured step graphs."""
-    for name, other in (("scan16", 0), ("fold_joint", 0), ("fold_decoder", 0), ("attention_split_max", 0), ("gemm_bf16x3", 0),
-                        ("attention_bf16x3", 0)):
+    for name, other in (("scan16", 0), ("fold_joint", 0), ("fold_decoder", 0), ("fold_upsample", 0), ("embed_sums", 0), ("attention_split_max", 0),
+                        ("gemm_bf16x3", 0), ("attention_bf16x3", 0)):
         g = model._ctx.generation()
         model.set_option(name, other)
         assert model._ctx.generation() > g, name
-    for name, dflt in (("scan16", 1), ("fold_joint", 1), ("fold_decoder", 1), ("attention_split_max", 192), ("gemm_bf16x3", 1),
-                       ("attention_bf16x3", 1)):
+    for name, dflt in (("scan16", 1), ("fold_joint", 1), ("fold_decoder", 1), ("fold_upsample", 1), ("embed_sums", 1), ("attention_split_max", 192),
+                       ("gemm_bf16x3", 1), ("attention_bf16x3", 1)):
         model.set_option(name, dflt)
