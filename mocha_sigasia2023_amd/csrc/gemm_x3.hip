@@ -348,6 +348,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         constexpr int C4 = TILE_N / 4;
         static_assert(64 * LDP * 4 <= 2 * STAGE * 2, "epilogue staging fits the operand stages");
         float* stage = reinterpret_cast<float*>(x3_sm);
+        // epilogue operands are fetched ahead of their use and ahead of the stores before them (mocha_gemm_x3p's epilogue has the reasoning):
+        // the bias quad once per tile, the residual (else the row-bias) rows two store iterations ahead
+        static_assert(256 % C4 == 0, "a thread keeps its column quad over the iterations");
+        constexpr int NIT = 64 * C4 / 256, RSTEP = 256 / C4;
+        const int c4 = tid % C4, r0 = tid / C4;
+        const unsigned cb = (unsigned)c4 * 16u;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 bias4 = p.bias ? bload(rsBias, cb, 0u) : zero4;
+        const bool pre_res = p.residual != nullptr, pre_rb = !pre_res && p.rowbias != nullptr;
+        f32x4 pre[2];
+        auto fetch_pre = [&](int k) __attribute__((always_inline)) {
+            const int rloc = 64 * (k / NIT) + r0 + RSTEP * (k % NIT);
+            int row = m0 + rloc;
+            row = row < p.M ? row : p.M - 1;                                          // rows past M: any valid address, the value is not used
+            if (pre_res) pre[k & 1] = bload(rsRes, (unsigned)(row - m0) * (unsigned)p.ldr * 4u + cb, 0u);
+            else if (pre_rb) pre[k & 1] = bload(rsRb, (unsigned)(row % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);
+        };
+        if (pre_res || pre_rb) { fetch_pre(0); fetch_pre(1); }
+        const bool plain_out = !p.bias && !p.rowbias && !p.residual;          // nothing to fetch: read the stage and store (A/B: the pipelined form below costs such launches 5 %)
 #pragma unroll
         for (int h = 0; h < TM; ++h) {                // 64 rows of the tile per pass
 #pragma unroll
@@ -364,23 +383,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     }
             }
             __syncthreads();
+            if (plain_out) {
 #pragma unroll
-            for (int it = 0; it < 64 * C4 / 256; ++it) {
-                const int e = tid + 256 * it;
-                const int r = e / C4, c4 = e - r * C4;
-                const int rloc = 64 * h + r;
-                const int row = m0 + rloc;
-                if (row < p.M) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4);
-                    const unsigned cb = (unsigned)c4 * 16u;
-                    if (p.bias) v += bload(rsBias, cb, 0u);
-                    if (p.rowbias) v += bload(rsRb, (unsigned)(row % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);
-                    if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
-                    else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
-                    else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                    if (p.residual) v += bload(rsRes, (unsigned)rloc * (unsigned)p.ldr * 4u + cb, 0u);
-                    bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
+                for (int it = 0; it < NIT; ++it) {
+                    const int r = r0 + RSTEP * it;
+                    const int rloc = 64 * h + r;
+                    if (m0 + rloc < p.M) {
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4);
+                        if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
+                        else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
+                        else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                        bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
+                    }
                 }
+            } else
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int r = r0 + RSTEP * it;
+                const int rloc = 64 * h + r;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4) + bias4;
+                if (pre_rb) v += pre[(NIT * h + it) & 1];
+                else if (p.rowbias) v += bload(rsRb, (unsigned)((m0 + rloc) % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);   // a residual too: inline (2 GiB window)
+                if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
+                else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
+                else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (pre_res) v += pre[(NIT * h + it) & 1];
+                if ((pre_res || pre_rb) && NIT * h + it + 2 < NIT * TM) fetch_pre(NIT * h + it + 2);      // ahead of this store
+                if (m0 + rloc < p.M) bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
             }
             if (h + 1 < TM) __syncthreads();
         }
@@ -425,7 +454,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // accumulators through the ONE stage the last step read from (32 rows per pass instead of 64), the other stage holds the next tile's step 0.
 // Same arithmetic, same order per output element: results are bit-identical to mocha_gemm_x3.  128 x 128 tiles, ksplit = 1 only.
 // -----------------------------------------------------------------------------------------------------------------------------------
-template <bool LRELU, bool GATHER>
+// EPI: which epilogue operand is fetched ahead of the stores - 0 none (bias only), 1 the residual rows, 2 the row-bias rows (no residual)
+template <bool LRELU, bool GATHER, int EPI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void mocha_gemm_x3p(GemmParams p) {
     constexpr int TM = 2, TN = 2;
     constexpr int TILE_M = 128, TILE_N = 128, B_HALF = XT<2>::B_HALF, B_PLANE = XT<2>::B_PLANE, STAGE = XT<2>::STAGE;
@@ -442,7 +472,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     const int lrow = tid >> 2, lc = tid & 3;
 
     // a tile's loader state: base pointers stay uniform (SGPRs), per-lane offsets in a few VGPRs
-    struct Tile { int m0, n0; bool valid; int a_rb[TM], a_t[TM]; unsigned a_off[TM]; };
+    struct Tile { int m0, n0; int valid; int a_rb[TM], a_t[TM]; unsigned a_off[TM]; };       // no padding bytes: a bool here made every tile hand-over copy three of them through scratch
     auto make_tile = [&](int t) __attribute__((always_inline)) -> Tile {
         Tile T;
         int mt, nt;
@@ -633,6 +663,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
             // thread id so that they are recomputed here.
             int te = tid, l31e = l31, hhe = hh;
             asm volatile("" : "+v"(te), "+v"(l31e), "+v"(hhe));
+            // Epilogue operands from global memory are fetched AHEAD of their use and ahead of the previous pass's stores: the vector-memory
+            // counter retires in order, so a load issued after a store cannot be waited for without waiting for that store's acknowledgement
+            // (the first build loaded bias and residual inside each of the 16 store iterations of a tile: 16 serial round trips, each behind
+            // the previous store).  A thread's column quad is the same in every iteration (C4 = 32 divides 256): the bias is loaded once per
+            // tile; `pre` holds the residual rows (or the row-bias rows where there is no residual) of the NEXT 32-row pass.
+            static_assert(256 % C4 == 0, "a thread keeps its column quad over the iterations");
+            constexpr int NIT = 32 * C4 / 256;
+            const int c4 = te % C4, r0 = te / C4;
+            const unsigned cb = (unsigned)c4 * 16u;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 bias4 = p.bias ? bload(rsBias, cb, 0u) : zero4;
+            f32x4 pre[EPI ? 2 : 1];                              // the operand of store iterations k and k + 1 (k = 4 h + it), refilled two ahead
+            auto fetch_pre = [&](int k) __attribute__((always_inline)) {
+                const int rloc = 32 * (k / NIT) + r0 + (256 / C4) * (k % NIT);
+                int row = m0 + rloc;
+                row = row < p.M ? row : p.M - 1;                                      // rows past M: any valid address, the value is not used
+                if constexpr (EPI == 1) pre[k & 1] = bload(rsRes, (unsigned)(row - m0) * (unsigned)p.ldr * 4u + cb, 0u);
+                else if constexpr (EPI == 2) pre[k & 1] = bload(rsRb, (unsigned)(row % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);
+            };
+            if constexpr (EPI != 0) { fetch_pre(0); fetch_pre(1); }
 #pragma unroll
             for (int h = 0; h < 2 * TM; ++h) {            // 32 rows of the tile per pass: MFMA row block h
 #pragma unroll
@@ -648,23 +698,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         }
                 }
                 __syncthreads();
+                if (EPI == 0 && !p.bias) {                  // nothing to fetch: read the stage and store (A/B: the pipelined form costs such launches 5 %)
 #pragma unroll
-                for (int it = 0; it < 32 * C4 / 256; ++it) {
-                    const int e = te + 256 * it;
-                    const int r = e / C4, c4 = e - r * C4;
-                    const int rloc = 32 * h + r;
-                    const int row = m0 + rloc;
-                    if (row < p.M) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4);
-                        const unsigned cb = (unsigned)c4 * 16u;
-                        if (p.bias) v += bload(rsBias, cb, 0u);
-                        if (p.rowbias) v += bload(rsRb, (unsigned)(row % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);
-                        if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
-                        else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
-                        else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                        if (p.residual) v += bload(rsRes, (unsigned)rloc * (unsigned)p.ldr * 4u + cb, 0u);
-                        bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
+                    for (int it = 0; it < NIT; ++it) {
+                        const int rloc = 32 * h + r0 + (256 / C4) * it;
+                        if (m0 + rloc < p.M) {
+                            f32x4 v = *reinterpret_cast<const f32x4*>(stage + (r0 + (256 / C4) * it) * LDP + c4 * 4);
+                            if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
+                            else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
+                            else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                            bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
+                        }
                     }
+                } else
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {         // one store iteration at a time: few live registers
+                    const int rloc = 32 * h + r0 + (256 / C4) * it;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stage + (r0 + (256 / C4) * it) * LDP + c4 * 4) + bias4;
+                    if constexpr (EPI == 2) v += pre[(NIT * h + it) & 1];
+                    else if (EPI == 1 && p.rowbias) v += bload(rsRb, (unsigned)((m0 + rloc) % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);   // a residual too: inline (2 GiB window)
+                    if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
+                    else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
+                    else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                    if constexpr (EPI == 1) v += pre[(NIT * h + it) & 1];
+                    if constexpr (EPI != 0) { if (NIT * h + it + 2 < NIT * 2 * TM) fetch_pre(NIT * h + it + 2); }      // ahead of this store
+                    if (m0 + rloc < p.M) bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
                 }
                 __syncthreads();                          // the stage is rewritten by the next pass - or by the next tile's step 0
             }
@@ -720,10 +778,18 @@ hipError_t gemm_x3_init() {
     if (e == hipSuccess) e = x3_attr<true, false, 2, 1>();
     if (e == hipSuccess) e = x3_attr<false, true, 2, 1>();
     if (e == hipSuccess) e = x3_attr<true, true, 2, 1>();
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
     return e;
 }
 
@@ -779,13 +845,16 @@ hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
         const int m_tiles = (p.M + 127) / 128, m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
         const long long total = (long long)m_pad * (p.N / XN);
         const unsigned grid = (unsigned)std::min<long long>(total, gemm_x3_persistent);
-        if (p.a_lrelu) {
-            if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3p<true, true>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);
-            else hipLaunchKernelGGL((mocha_gemm_x3p<true, false>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);
-        } else {
-            if (p.gather) hipLaunchKernelGGL((mocha_gemm_x3p<false, true>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);
-            else hipLaunchKernelGGL((mocha_gemm_x3p<false, false>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);
-        }
+        const int epi = p.residual ? 1 : p.rowbias ? 2 : 0;
+#define X3P_LAUNCH(L, G)                                                                                                                  \
+        do {                                                                                                                              \
+            if (epi == 1) hipLaunchKernelGGL((mocha_gemm_x3p<L, G, 1>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);                 \
+            else if (epi == 2) hipLaunchKernelGGL((mocha_gemm_x3p<L, G, 2>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);            \
+            else hipLaunchKernelGGL((mocha_gemm_x3p<L, G, 0>), dim3(grid), dim3(256), x3_lds_bytes<2>(), s, p);                          \
+        } while (0)
+        if (p.a_lrelu) { if (p.gather) X3P_LAUNCH(true, true); else X3P_LAUNCH(true, false); }
+        else { if (p.gather) X3P_LAUNCH(false, true); else X3P_LAUNCH(false, false); }
+#undef X3P_LAUNCH
         return hipGetLastError();
     }
     if (p.ksplit <= 1 && p.N % XN != 0) x3_launch<2, 1>(p, s);
