@@ -52,6 +52,58 @@ __device__ __forceinline__ float mocha_erf(float a) {
     return t > 0.927734375f ? big : small;
 }
 
+// The exact-erf GELU of net/transformer.py:27 (nn.GELU()) for the GEMM epilogues: GELU(x) = x Phi(x), Phi(x) = 0.5 erfc(-x / sqrt 2).
+// With t = |x| / sqrt 2:  h = 0.5 erfc(t) = exp2(q(t)), q a degree-9 polynomial fitted to log2(0.5 erfc) on [0, 4.3] with weight erfc
+// (the error of h is what counts: 2e-9 from the fit, the rest is float32 evaluation), h = 0 beyond (0.5 erfc < 6e-10);
+// Phi = h for x < 0 (no cancellation on the negative tail), 1 - h otherwise.  One polynomial and one v_exp_f32 per element - 17 + 4 issue
+// slots against the 26 + 4 of 0.5 x (1 + mocha_erf(x / sqrt 2)) with its two polynomials - and |error| <= 1.1e-7 max(1, |x|), relative error
+// below 2.2e-6 for x > -3 (the erf form: 1.1e-7 and 1.8e-5).  Checked against float64 in tests/test_erf_polynomial.py.
+__device__ __forceinline__ float mocha_gelu(float x) {
+    const float t = fabsf(x) * 0.70710678118654752440f;
+    float q = 1.146809295e-05f;
+    q = fmaf(q, t, -1.515590512e-04f);
+    q = fmaf(q, t, 8.423155240e-04f);
+    q = fmaf(q, t, -2.261537520e-03f);
+    q = fmaf(q, t, 6.770915453e-05f);
+    q = fmaf(q, t, 2.773738608e-02f);
+    q = fmaf(q, t, -1.483134404e-01f);
+    q = fmaf(q, t, -9.184416673e-01f);
+    q = fmaf(q, t, -1.627907386e+00f);
+    q = fmaf(q, t, -9.999999969e-01f);
+    float h = __builtin_amdgcn_exp2f(q);
+    h = t > 4.3f ? 0.f : h;
+    return x * (x < 0.f ? h : 1.0f - h);
+}
+
+// four at a time, the polynomial on float pairs (v_pk_fma_f32 / v_pk_mul_f32: half the instructions); the same operations per element
+// as mocha_gelu, so the results are the same bits
+__device__ __forceinline__ f32x4_t mocha_gelu4(f32x4_t x) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f32x4_t out;
+#pragma unroll
+    for (int hpair = 0; hpair < 2; ++hpair) {
+        const f2 xv = {x[2 * hpair], x[2 * hpair + 1]};
+        const f2 t = __builtin_elementwise_abs(xv) * 0.70710678118654752440f;
+        f2 q = {1.146809295e-05f, 1.146809295e-05f};
+        q = __builtin_elementwise_fma(q, t, (f2){-1.515590512e-04f, -1.515590512e-04f});
+        q = __builtin_elementwise_fma(q, t, (f2){8.423155240e-04f, 8.423155240e-04f});
+        q = __builtin_elementwise_fma(q, t, (f2){-2.261537520e-03f, -2.261537520e-03f});
+        q = __builtin_elementwise_fma(q, t, (f2){6.770915453e-05f, 6.770915453e-05f});
+        q = __builtin_elementwise_fma(q, t, (f2){2.773738608e-02f, 2.773738608e-02f});
+        q = __builtin_elementwise_fma(q, t, (f2){-1.483134404e-01f, -1.483134404e-01f});
+        q = __builtin_elementwise_fma(q, t, (f2){-9.184416673e-01f, -9.184416673e-01f});
+        q = __builtin_elementwise_fma(q, t, (f2){-1.627907386e+00f, -1.627907386e+00f});
+        q = __builtin_elementwise_fma(q, t, (f2){-9.999999969e-01f, -9.999999969e-01f});
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float h = __builtin_amdgcn_exp2f(q[e]);
+            h = t[e] > 4.3f ? 0.f : h;
+            out[2 * hpair + e] = xv[e] * (xv[e] < 0.f ? h : 1.0f - h);
+        }
+    }
+    return out;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Plane split (gemm_x3.hip, attention_x3.hip, pointwise.hip): x = x0 + x1 + x2 with x0 = bf16(x), x1 = bf16(x - x0),
 // x2 = bf16(x - x0 - x1), round to nearest even (v_cvt_pk_bf16_f32).  Exact for practically every fp32 value, residual <= 2^-24 |x|

@@ -34,7 +34,7 @@ static constexpr int BK = 32;
 static constexpr int LDSK = BK + 4;
 
 __device__ __forceinline__ float lrelu02(float x) { return x > 0.f ? x : 0.2f * x; }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + mocha_erf(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf(float x) { return mocha_gelu(x); }
 
 template <int BN, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BN == 64 ? 5 : 3))) void mocha_gemm_f32(GemmParams p) {

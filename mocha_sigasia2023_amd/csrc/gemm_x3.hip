@@ -60,7 +60,7 @@ template <int TN> struct XT {
 static_assert(XT<2>::STAGE == X_STAGE && XT<2>::B_HALF == XA_HALF, "TN = 2 is the 128-wide layout");
 
 __device__ __forceinline__ float x3_lrelu(float x) { return x > 0.f ? x : 0.2f * x; }
-__device__ __forceinline__ float x3_gelu(float x) { return 0.5f * x * (1.0f + mocha_erf(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float x3_gelu(float x) { return mocha_gelu(x); }
 
 // W [N][K] fp32 -> packed planes.  One workgroup per (n tile, k step) block: thread = (row, k half) reads 32 bytes and writes one
 // 16-byte piece per plane, so every wave writes 512-byte runs of the 12 KB block (the image is written once per weight, but once per
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     const int rloc = 64 * h + r;
                     if (m0 + rloc < p.M) {
                         f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4);
-                        if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
+                        if (p.act == 1) { v = mocha_gelu4(v); }
                         else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
                         else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                         bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4) + bias4;
                 if (pre_rb) v += pre[(NIT * h + it) & 1];
                 else if (p.rowbias) v += bload(rsRb, (unsigned)((m0 + rloc) % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);   // a residual too: inline (2 GiB window)
-                if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
+                if (p.act == 1) { v = mocha_gelu4(v); }
                 else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
                 else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                 if (pre_res) v += pre[(NIT * h + it) & 1];
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                         const int rloc = 32 * h + r0 + (256 / C4) * it;
                         if (m0 + rloc < p.M) {
                             f32x4 v = *reinterpret_cast<const f32x4*>(stage + (r0 + (256 / C4) * it) * LDP + c4 * 4);
-                            if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
+                            if (p.act == 1) { v = mocha_gelu4(v); }
                             else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
                             else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                             bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                     f32x4 v = *reinterpret_cast<const f32x4*>(stage + (r0 + (256 / C4) * it) * LDP + c4 * 4) + bias4;
                     if constexpr (EPI == 2) v += pre[(NIT * h + it) & 1];
                     else if (EPI == 1 && p.rowbias) v += bload(rsRb, (unsigned)((m0 + rloc) % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);   // a residual too: inline (2 GiB window)
-                    if (p.act == 1) { v[0] = x3_gelu(v[0]); v[1] = x3_gelu(v[1]); v[2] = x3_gelu(v[2]); v[3] = x3_gelu(v[3]); }
+                    if (p.act == 1) { v = mocha_gelu4(v); }
                     else if (p.act == 2) { v[0] = x3_lrelu(v[0]); v[1] = x3_lrelu(v[1]); v[2] = x3_lrelu(v[2]); v[3] = x3_lrelu(v[3]); }
                     else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                     if constexpr (EPI == 1) v += pre[(NIT * h + it) & 1];
