@@ -109,11 +109,12 @@ hipError_t launch_final_proj(const float* z, const float* W6, const float* b6, f
 //   out = (x-mean)/(std+eps); mean_out (B,256) optional; zn = (out - gm)/gs optional
 // optional extras of the instance norm: zc = zn - centre (the matcher's centred queries, bit-identical to mocha_sub_rows on zn);
 // rows gathered from a table (x row of window b = table[clamp(row_idx[b])], the decoder's cha_encoded[frame_index]) and copied out
+static constexpr int QSTAT_PARTS = 4;      // row statistics come in parts (one per workgroup of a window's channel quarter), added in order by mocha_match_select2
 struct InormExtra {
     const float* centre = nullptr; float* zc = nullptr;      // zc: (z-score - centre), fp32
     unsigned short* zc16 = nullptr;                          // the same as bf16 (round to nearest even): the many-query bf16 pass's query plane
     // zc16 with plane_stride > 0: a SECOND plane bf16(zc - plane 0) at zc16 + plane_stride (elements) - the coarse pass then carries 16
-    // significant bits of every query value; qstat (2 floats per window): ||zc||^2 and the squared norm of what the planes (zc16) leave out
+    // significant bits of every query value; qstat (2 x QSTAT_PARTS floats per window, summed by the consumer in part order): ||zc||^2 and the squared norm of what the planes (zc16) leave out
     // - or, with zc alone, {||zc||^2, 0} - the selection's error bound (match_select2.hip) without a pass over the row
     long long plane_stride = 0; float* qstat = nullptr;
     const float* table = nullptr; const int32_t* row_idx = nullptr; long long table_rows = 0; float* copy_out = nullptr;
@@ -182,7 +183,7 @@ hipError_t match_mfma_init();
 int match_bf16_ksplit(int Q, int64_t N);
 hipError_t launch_center_bf16(const float* x, const float* centre, void* out, int64_t rows, int cols, hipStream_t s);
 // row by row: planes[0] = bf16(x - centre) and, with nplanes = 2, planes[1] = bf16(x - centre - planes[0]) (stacked: plane 1 starts rows * cols
-// elements after plane 0), or out32 = x - centre in fp32; qstat[row] = {||x - centre||^2, ||x - centre - planes||^2 (0 for fp32)}.  One
+// elements after plane 0), or out32 = x - centre in fp32; qstat[row] = QSTAT_PARTS pairs whose sums are {||x - centre||^2, ||x - centre - planes||^2 (0 for fp32)} (all of it in part 0).  One
 // workgroup per row, fixed summation order.  Exactly one of planes / out32 is non-null.
 hipError_t launch_center_rows(const float* x, const float* centre, void* planes, int nplanes, float* out32, float* qstat, int64_t rows, int cols, hipStream_t s);
 // planes = 2: qc16 holds two stacked bf16 planes of the queries (plane 1 starts Q * D elements after plane 0), S = (a0 + a1) b^T
@@ -195,7 +196,7 @@ hipError_t launch_match_select(const float* S, int ksplit, long long slab_stride
                                const float* centre, const float* bank, const void* bank16, float margin_rel, int Q, int64_t N, int D,
                                int32_t* idx, float* dist, hipStream_t s);
 // the same selection without the usually unnecessary work (match_select2.hip): the row statistics of the error bound come from the
-// producer of the centred queries (qstat: 2 floats per query - launch_center_rows, InormExtra::qstat), nothing is staged in LDS, and a
+// producer of the centred queries (qstat: 2 x QSTAT_PARTS floats per query - launch_center_rows, InormExtra::qstat), nothing is staged in LDS, and a
 // query whose coarse minimum stands alone is answered without touching a bank row when dist == nullptr.  Otherwise the same arguments,
 // bounds and result semantics as launch_match_select.
 hipError_t launch_match_select2(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm, const float* query,

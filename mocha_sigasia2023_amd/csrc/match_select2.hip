@@ -40,7 +40,7 @@ __device__ __forceinline__ unsigned long long s2_key(float v, unsigned n) {     
 struct Select2Params {
     const float* S; int ksplit; long long slab_stride; int lds;
     const float* bnorm; const float* query; const float* centre; const float* bank; const unsigned short* bank16;
-    const float* qstat;           // per query: ||q - c||^2, ||dq||^2
+    const float* qstat;           // per query: QSTAT_PARTS parts of ||q - c||^2, ||dq||^2
     long long N; int D; float margin_rel; int32_t* idx; float* dist;
 };
 
@@ -56,7 +56,9 @@ __global__ __launch_bounds__(S2_T) void mocha_match_select2(Select2Params p) {
     const long long N = p.N;
     const int D = p.D;
     if (tid == 0) ncand = 0;
-    const float qn = p.qstat[2 * q], dq = p.qstat[2 * q + 1];     // in flight beside the scores
+    const float* qs = p.qstat + (size_t)q * 2 * QSTAT_PARTS;      // in flight beside the scores; the parts in order
+    const float qn = ((qs[0] + qs[2]) + qs[4]) + qs[6], dq = ((qs[1] + qs[3]) + qs[5]) + qs[7];
+    static_assert(QSTAT_PARTS == 4, "four parts");
 
     // ---- 1. coarse scores; thread t owns rows c0 + 4 t .. + 3 of every chunk (one 16-byte load per K slice and chunk)
     const float* Sq = p.S + (size_t)q * p.lds;

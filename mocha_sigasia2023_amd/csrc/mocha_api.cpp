@@ -820,7 +820,7 @@ int ensure_match_scratch(mocha_ctx* c, int set, int Q, int64_t N, bool every_q_u
         size_t need = 0;
         for (int q = every_q_up_to ? 9 : Q; q <= Q; ++q) need = std::max(need, (size_t)match_ksplit(q, N) * q * (size_t)N);
         if ((rc = grow(c, c->match_S[set], need))) return rc;
-        if ((rc = grow(c, c->match_qstat[set], (size_t)2 * std::max(Q, 256)))) return rc;
+        if ((rc = grow(c, c->match_qstat[set], (size_t)2 * QSTAT_PARTS * std::max(Q, 256)))) return rc;
     }
     if (c->scan16 && !c->bank_is_bf16 && N >= SCAN16_MIN && c->scan_keys_n[set] < (size_t)8 * N) {      // every row's coarse key, 8 queries
         HIPCHK(c, hipDeviceSynchronize());

@@ -568,7 +568,7 @@ static constexpr int IN_NG = 8;             // token groups per window
 static constexpr int IN_MAXT = 12;          // tokens per thread (n <= 96)
 
 // QW = channel quads per workgroup: 16 (a window's 256 channels over four workgroups; the default for every batch since round 4) or 64 (one
-// workgroup per window: needed when the row statistics of the whole window are wanted, InormExtra::qstat).  A channel's tokens are
+// workgroup per window).  A channel's tokens are
 // partitioned and summed in the same order either way: results are bit-identical.
 template <int QW>
 __device__ __forceinline__ f32x4 group_sum4(f32x4 v, f32x4* red, int q, int g) {
@@ -684,8 +684,8 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
                 }
             }
         }
-    if (ex.qstat) {                                          // one workgroup per window (QW == 64, see launch_instnorm): wave sums, then the waves in order
-        __shared__ float qsr[2][QW * IN_NG / 64 > 0 ? QW * IN_NG / 64 : 1];
+    if (ex.qstat) {                                          // this workgroup's share of the row statistics: wave sums, then the waves in order;
+        __shared__ float qsr[2][QW * IN_NG / 64 > 0 ? QW * IN_NG / 64 : 1];      // part blockIdx.y of QSTAT_PARTS (the consumer adds the parts in order)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { qs_n += __shfl_xor(qs_n, o); qs_d += __shfl_xor(qs_d, o); }
         if ((threadIdx.x & 63) == 0) { qsr[0][threadIdx.x >> 6] = qs_n; qsr[1][threadIdx.x >> 6] = qs_d; }
@@ -693,7 +693,10 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
         if (threadIdx.x == 0) {
             float a = 0.f, d = 0.f;
             for (int w = 0; w < QW * IN_NG / 64; ++w) { a += qsr[0][w]; d += qsr[1][w]; }
-            ex.qstat[2 * b] = a; ex.qstat[2 * b + 1] = d;
+            float* qo = ex.qstat + (size_t)b * 2 * QSTAT_PARTS;
+            qo[2 * blockIdx.y] = a; qo[2 * blockIdx.y + 1] = d;
+            if (gridDim.y == 1)
+                for (int k = 1; k < QSTAT_PARTS; ++k) { qo[2 * k] = 0.f; qo[2 * k + 1] = 0.f; }
         }
     }
     if (ex.kvimg && g < 96 - n) {                            // rows n .. 95 of both images: zero (a padded key's score is masked, its value row multiplies P = 0)
@@ -723,8 +726,8 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
     if (ex.kvimg && n < 96 - IN_NG) return hipErrorInvalidValue;      // the image's zero rows n .. 95 are written by the first 96 - n token groups
     if (ex.qstat && !(ex.zc || ex.zc16)) return hipErrorInvalidValue;
     if ((long long)ex.plane_stride < 0 || (ex.plane_stride > 0 && !ex.zc16)) return hipErrorInvalidValue;
-    // the row statistics are a whole-window reduction: one workgroup per window then, whatever the batch
-    if (inorm_split(B) && !ex.qstat) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
+    static_assert(QSTAT_PARTS == 4, "the four workgroups of a window write one part of the row statistics each");
+    if (inorm_split(B)) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     else hipLaunchKernelGGL(mocha_instnorm<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     return hipGetLastError();
 }
@@ -893,7 +896,9 @@ __global__ __launch_bounds__(512) void mocha_center_rows(const float* __restrict
     if (threadIdx.x == 0) {
         float a = red[0][0], d = red[1][0];
         for (int w = 1; w < 8; ++w) { a += red[0][w]; d += red[1][w]; }
-        qstat[2 * row] = a; qstat[2 * row + 1] = d;
+        float* qo = qstat + (size_t)row * 2 * QSTAT_PARTS;      // the whole row in part 0
+        qo[0] = a; qo[1] = d;
+        for (int k = 1; k < QSTAT_PARTS; ++k) { qo[2 * k] = 0.f; qo[2 * k + 1] = 0.f; }
     }
 }
 
