@@ -1,6 +1,6 @@
 """The GEMM epilogues evaluate the exact-erf GELU of net/transformer.py:27 (nn.GELU()) as x * Phi(x) with Phi from ONE polynomial and one
-exp2 (mocha_gelu, csrc/device_utils.h); the CVAE's and other code paths keep the branch-free single-precision erf (mocha_erf).  Both are
-checked here from the coefficients in the source (float32 fma emulated in float64) against float64 references: the erf to < 1 ulp, the
+exp2 (mocha_gelu, csrc/device_utils.h); the branch-free single-precision erf it replaced (mocha_erf) stays in the header as a utility.  Both
+are checked here from the coefficients in the source (float32 fma emulated in float64) against float64 references: the erf to < 1 ulp, the
 GELU to 1.2e-7 max(1, |x|) absolute and 3e-6 relative for x > -3 - below the error of 0.5 x (1 + erff(x / sqrt 2)) in float32."""
 import re
 import os
