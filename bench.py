@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--dual-stream", action="store_true",
                     help="add a second timing of the same step with the opt-in two-stream overlap (reported beside the headline, "
                          "never as it; off by default so that a rocprofv3 run of the default command sees only the headline kernels)")
-    ap.add_argument("--cpu-sample", type=int, default=585, help="windows per clip for the CPU baseline leg (default: the full 585 + 585 of the GPU workload)")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="windows per clip of the CPU baseline leg's bounded sample (thread sweep, BASELINE.md section 3)")
+    ap.add_argument("--cpu-full", type=int, default=0, help="additionally time this many + this many windows once at the sweep's best configuration (585 = the GPU workload)")
     ap.add_argument("--sustained-s", type=float, default=2.5, help="seconds of the extra back-to-back timing of the same step (0 = skip)")
     ap.add_argument("--launch-timeout", type=float, default=3600.0,
                     help="seconds after which `--gpus N`'s own launcher stops ranks that have not finished (0 = never)")
@@ -213,28 +214,82 @@ def dist_device_and_backend(local):
     return (0 if os.environ.get("MOCHA_BENCH_ONE_GPU") == "1" else local), os.environ.get("MOCHA_BENCH_BACKEND", "nccl")
 
 
-def cpu_baseline(sd, V, n, mean, std):
-    """The oracle (CPU restatement of the reference path, same op sequence on torch CPU) timed on a
-    bounded sample of the same workload: n source + n character windows through the same step."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sd, V, n, mean, std, full=0):
+    """The oracle (CPU restatement of the reference path, same op sequence on torch CPU) timed on the GPU box's host cores, per
+    BASELINE.md section 3 (the reference's only timing code is model.py:311-318): a thread sweep with warm-up and medians on a BOUNDED
+    sample of the same step (n source + n character windows: encode both, 1-NN match, decode, to_mot), at the encode / decode batch the
+    reference's own scripts use (32, collect_CVAE_feature_action.py:167) and with the whole clip as one batch at the best thread count.
+    `value` is the BEST median over the sweep (the fairest figure for the CPU); every configuration is in `sweep`.  One thread runs a
+    quarter of the sample (it is ~10x slower).  full > 0: additionally one run of `full` + `full` windows at the best configuration."""
     from oracle import mocha_oracle as O      # checker / baseline only
     from mocha_sigasia2023_amd import synthetic
     tsd = O.to_torch_state(sd)
-    src = torch.from_numpy(synthetic.pose_windows(901, n, V))
-    cha = torch.from_numpy(synthetic.pose_windows(902, n, V))
-    threads = torch.get_num_threads()
+    src = torch.from_numpy(synthetic.pose_windows(901, max(n, full), V))
+    cha = torch.from_numpy(synthetic.pose_windows(902, max(n, full), V))
+    ncpu = os.cpu_count() or 1
+    threads0 = torch.get_num_threads()
+    counts = sorted({t for t in (1, 8, 16, 32, 64, threads0) if 1 <= t <= max(threads0, 1)})
+
+    def timed(nw, batch, reps):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            O.characterize(tsd, src[:nw], cha[:nw], mean, std, batch=batch)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    sweep = []
+    t_all = time.perf_counter()
     with torch.no_grad():
-        O.characterize(tsd, src[:8], cha[:8], mean, std)          # warm-up (oneDNN primitive caches)
-        t0 = time.perf_counter()
-        O.characterize(tsd, src, cha, mean, std)
-        dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"{n} src + {n} cha windows through the same step (encode both, 1-NN match, decode, to_mot), "
-                      f"torch-CPU oracle batch 32, {dt:.1f} s, os.cpu_count()={os.cpu_count()}"}
+        for t in counts:
+            torch.set_num_threads(t)
+            nw = max(8, n // 4) if t == 1 else n
+            for _ in range(3):                                    # warm-up: oneDNN primitive caches, thread pool at this size
+                O.characterize(tsd, src[:8], cha[:8], mean, std, batch=8)
+            dt = timed(nw, 32, 3)
+            sweep.append({"threads": t, "batch": 32, "windows": nw, "median_s": dt, "frames_per_s": nw / dt})
+        best = max(sweep, key=lambda r: r["frames_per_s"])
+        torch.set_num_threads(best["threads"])
+        dt = timed(n, n, 3)                                       # the whole clip as one batch (test_fullframework.py:190-192 encodes a clip at once)
+        sweep.append({"threads": best["threads"], "batch": n, "windows": n, "median_s": dt, "frames_per_s": n / dt})
+        best = max(sweep, key=lambda r: r["frames_per_s"])
+        rec_full = None
+        if full > 0:
+            torch.set_num_threads(best["threads"])
+            t0 = time.perf_counter()
+            O.characterize(tsd, src[:full], cha[:full], mean, std, batch=min(best["batch"], full))
+            dtf = time.perf_counter() - t0
+            rec_full = {"windows": full, "seconds": dtf, "frames_per_s": full / dtf, "threads": best["threads"], "batch": best["batch"]}
+    torch.set_num_threads(threads0)
+    out = {"value": best["frames_per_s"], "unit": "frames/s", "cores": best["threads"], "kind": "port",
+           "sample": f"{n} src + {n} cha windows through the same step (encode both, 1-NN match, decode, to_mot), torch-CPU oracle; best of a "
+                     f"thread sweep {counts} at batch 32 plus the whole clip as one batch, 3 warm-up + median of 3 each ({time.perf_counter() - t_all:.0f} s "
+                     f"in all); one thread on {max(8, n // 4)} + {max(8, n // 4)} windows",
+           "best": {"threads": best["threads"], "batch": best["batch"]}, "sweep": sweep,
+           "single_thread_frames_per_s": next(r["frames_per_s"] for r in sweep if r["threads"] == counts[0]),
+           "cpu_model": cpu_model_name(), "os_cpu_count": ncpu, "torch_default_threads": threads0}
+    if rec_full:
+        out["full_workload"] = rec_full
+    return out
 
 
-# CRC-32 of the 1024 matched bank rows of the bank4k workload on ONE GPU (`python bench.py --workload bank4k`, synthetic seeds 1 / 2 / 7):
-# the search is exact over the rounded bank, so an N-way split must reproduce it - `idx_matches_n1` in the N > 1 record.  Keyed by V.
-BANK4K_IDX_CRC32_N1 = {22: 4269089464, 24: 2772088534}      # profiles/r04/a_bank4k_v22.json, a_bank4k_v24.json
+# CRC-32 of the 1024 matched bank rows of the bank4k workload on ONE GPU (`python bench.py --workload bank4k`, synthetic seeds 1 / 2 / 7).
+# The search is exact over the rounded bank, so an N-way split must reproduce the N = 1 answer OF THE SAME BUILD - but the value depends on
+# the encoder's last bits (a near-tie flips with any legitimate numeric change), so it is INFORMATIONAL and keyed by the kernel sources' hash:
+# `idx_matches_n1` is None unless the running library was built from exactly those sources.  The binding checks are
+# tests/test_multirank_standin.py (N-rank CRC == a 1-rank run of the same build) and test_fullsize_parity.py (indices vs float64 search).
+BANK4K_IDX_CRC32_N1 = {"545d209a9ac5cbed": {22: 4269089464, 24: 2772088534}}      # profiles/r04/h_bank4k_v2{2,4}.json
 XGMI_LINK_GBS = 153.0            # one xGMI link, one direction (MI355X: 7 links per GPU, point-to-point)
 
 
@@ -258,6 +313,51 @@ def comm_record(model, backend, world):
             "distinct_devices": len({i["pci_bus_id"] for i in infos}),
             "per_rank": [{"rank": i["rank"], "device": i["device"], "pci_bus_id": i["pci_bus_id"]} for i in infos],
             "torch_side_channel_backend": backend, "test_hooks_in_env": hooks}
+
+
+def projected_scaling_record(a, model, dev, V):
+    """N = 1 line only: what one GPU of the FINAL tree does with every per-rank share of BASELINE configs[3] (the 1024 windows of seed 1
+    against the 4096-entry bf16 bank: 1024 / 512 / 256 / 128 windows = the shares at N = 1 / 2 / 4 / 8), measured back to back on this GPU,
+    and the strong-scaling figures that follow from them if nothing else changes (no collective inside a step; the bank broadcast is a
+    one-time set-up cost and is MODELLED here: scatter + all-gather, 153 GB/s per xGMI link and direction).  A projection, not a measurement
+    of N GPUs: the driver's SCALE run is the measurement.  Also the weak-scaled headline's counterpart: the demo step's per-rank work does
+    not change with N, so its projection is N x this line's value."""
+    from mocha_sigasia2023_amd import ContextBank, synthetic
+    NB, W = 4096, 1024
+    full = torch.from_numpy(synthetic.pose_windows(1, W, V)).to(dev)
+    m0, s0 = synthetic.cnt_norm(7)
+    with torch.no_grad():
+        _, cnt_all, _ = model.encode(full, torch.from_numpy(m0).to(dev), torch.from_numpy(s0).to(dev))
+        mean = cnt_all.mean(dim=0).contiguous()
+        std = (cnt_all.std(dim=0).clamp_min(1e-6) / torch.from_numpy(synthetic.temporal_weight(15, 6, 256)).to(dev)).contiguous()
+        del cnt_all
+        g = torch.Generator(device=dev); g.manual_seed(2)
+        bank_nm = torch.randn((NB, 90 * 256), device=dev, generator=g)
+        bank_enc = torch.randn((NB, 90, 256), device=dev, generator=g)
+        bank = ContextBank(model, bank_nm, bank_enc, bf16=True)
+        shares = {}
+        for n_gpus in (1, 2, 4, 8):
+            share = W // n_gpus
+            src = full[:share].contiguous()
+            for _ in range(2):
+                bank.characterize(src, mean, std)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            reps = max(5, a.steps // 2)
+            for _ in range(reps):
+                bank.characterize(src, mean, std)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+            bank_bytes = 2 * NB * 90 * 256 * 4
+            shares[str(n_gpus)] = {"windows_per_gpu": share, "ms_per_step": dt * 1e3, "frames_per_s_per_gpu": share / dt,
+                                   "projected_whole_job_frames_per_s": n_gpus * share / dt,
+                                   "modelled_bank_broadcast_ms": (2.0 * bank_bytes / n_gpus / (XGMI_LINK_GBS * 1e9) * 1e3) if n_gpus > 1 else 0.0}
+        del bank, bank_nm, bank_enc, full
+    base = shares["1"]["projected_whole_job_frames_per_s"]
+    for k, v in shares.items():
+        v["projected_strong_scaling_efficiency"] = v["projected_whole_job_frames_per_s"] / (int(k) * base)
+    return {"workload": "BASELINE configs[3]: 1024 windows x 4096-entry bank (bf16 cnt) split over N GPUs, per-rank share run on THIS GPU",
+            "is_projection_from_one_gpu": True, "by_n_gpus": shares,
+            "note": "per-rank step time of each share measured on one GPU of this tree; whole-job = N x share / time (no in-step collective); the "
+                    "bank broadcast (755 MB fp32 rows + entries, scatter + all-gather) is modelled at 153 GB/s per link and paid once"}
 
 
 def bank4k_record(a, model, dev, V, rank, world, backend):
@@ -337,7 +437,7 @@ def bank4k_record(a, model, dev, V, rank, world, backend):
     if rank != 0:
         return None
     crc = zlib.crc32(idx_all.tobytes())
-    known = BANK4K_IDX_CRC32_N1.get(V)
+    known = BANK4K_IDX_CRC32_N1.get(kernel_source_sha16(), {}).get(V)
     return {"value": W * a.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "scaling": "strong", "dtype": "f32 (bf16 bank for matching)",
             "config": {"workload": f"BASELINE configs[2]/[3]: 1024 windows x 4096-entry bank (bf16 cnt), V={V}, "
@@ -829,6 +929,7 @@ def main():
                 out["ours"] = ours_record(model, dev)
                 out["post"] = post_record(model, dev, W)
                 out["bank_build"] = bank_build_record(model, dev, V)
+                out["projected_scaling"] = projected_scaling_record(a, model, dev, V)
                 if V != 24:
                     sd24 = synthetic_state_dict(seed=1777, gain=1.0, layout="mocha")
                     m24 = Generator(layout="mocha", device=dev).load_state_dict(sd24).eval()
@@ -845,7 +946,7 @@ def main():
                     del m24, s24, c24
         if not a.no_cpu_baseline and world == 1:         # the CPU leg runs at N=1 only (the other ranks would idle through it)
             m_, s_ = synthetic.cnt_norm(7)
-            out["cpu_baseline"] = cpu_baseline(sd, V, a.cpu_sample, m_, s_)
+            out["cpu_baseline"] = cpu_baseline(sd, V, a.cpu_sample, m_, s_, full=a.cpu_full)
             out["speedup_vs_cpu"] = value / out["cpu_baseline"]["value"]
             out["config"]["cpu_baseline_sample"] = f"{a.cpu_sample} + {a.cpu_sample} windows (the GPU workload is {W} + {W})"
         print(json.dumps(out), flush=True)

@@ -302,7 +302,7 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * QK^T and PV the same way - K, Q, V and the softmax probabilities as three bf16 planes each, six MFMA passes per product,
  * fp32 accumulation and an fp32 softmax (attention_x3.hip); 0 = v_mfma_f32_32x32x2_f32 (attention.hip).  The CVAE sampler's
  * attention (head dim 64) always uses attention.hip.
- * "attention_split_max" (default 192; PROCESS-wide, a diagnostic): up to this many (window, head) pairs the head-dim-256 attention
+ * "attention_split_max" (default 192): up to this many (window, head) pairs the head-dim-256 attention
  * (the decoder's) gives each pair twelve waves - four groups contract a quarter of the head dim each, the partial score tiles are
  * summed through LDS in a fixed order, each group then writes a quarter of the output columns - because a one-window launch is
  * otherwise a serial chain of twelve staging steps per wave.  Same operands and products; the scores are summed in a different
@@ -313,9 +313,10 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * "lanes" (default 1, 1..3): workspace sets / captured graphs for mocha_step_graph_lane; changing it re-plans the workspaces.
  * "scan16" (default 1): see MOCHA_BANK_BF16 above - fp32 banks of >= 4096 rows are scanned through a centred bf16 copy with an
  * exact fp32 re-rank when at most 8 queries are matched; takes effect at the next mocha_bank_set; 0 scans the fp32 rows.
- * Round 4 (INTEGRATION.md section 6 has the table): "embed_sums" (default 1; process-wide): mot_embedding's first stage and the joint
+ * Round 4 (INTEGRATION.md section 6 has the table; PER CONTEXT since ABI 5 - round 4 kept five of them in process-wide variables):
+ * "embed_sums" (default 1): mot_embedding's first stage and the joint
  * block's five-tap 4-frame sums in one kernel whose frame rows stay in LDS (0: two kernels, bit-identical); "embed_front_max_wgs"
- * (default 512; process-wide): that kernel's persistent grid; "inorm_split_max" (default: every batch; process-wide): windows up to
+ * (default 512): that kernel's persistent grid; "inorm_split_max" (default: every batch): windows up to
  * which the instance norms spread a window's channels over four workgroups (bit-identical either way); "gemm_persistent" (default 768
  * workgroups; 0 = off) and "gemm_persistent_max_n" (default 512): the plane GEMM's persistent instance, bit-identical; "select2"
  * (default 1) / "match_planes" (default 1; 2 = two bf16 query planes in the bf16 coarse pass): the many-query selection with
@@ -325,6 +326,23 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * "fold_upsample" (default 1): to_mot's k = 5 temporal conv over the nearest-x4-upsampled frames (model.py:74, net/blocks.py:112-118) as a
  * 3-tap conv over the 15 source frames with per-phase summed weights (exact algebra; differences are fp32 rounding of the weight sums);
  * "upsample_split_min" (default 256): windows from which it runs as two 2-tap launches.
+ * Round 5 (ABI 5):
+ * "adain_closed_form" (default 1): the decoder's AdaIN -> instance norm pair (net/transformer.py:108-113 then :49-56) from ONE set of
+ * token statistics: with m, s the mean / unbiased std of x, AdaIN(x) = (1+g)(x-m)/(s+eps) + b has token mean exactly b and std
+ * |1+g| s/(s+eps), so IN(AdaIN(x)) = (1+g)(x-m) / (|1+g| s + eps (s+eps)) - the same function in real arithmetic, without the
+ * cancellation against b that costs the literal fp32 order (and the reference) the digits of every channel whose 1+g is small.
+ * 0 = the literal two-pass order (A/B: tools/structured_matrix.py).
+ * "style_f64" (default 1): the AdaIN style MLP (net/transformer.py:100-107; mean over tokens -> Linear -> LeakyReLU -> Linear) in
+ * float64 from a float64 token mean, gamma / beta rounded to fp32 once; 0 = the fp32 GEMM engines.
+ * "bank_dec_cache" (default 1): mocha_bank_set also computes what the decoder derives from a bank ENTRY alone - IN(entry) (the folded
+ * decoder's keys) and every layer's gamma / beta - (+ 92 KB + 2 KB x decoder depth per entry), and mocha_characterize /
+ * mocha_step_graph read them in place through frame_index instead of recomputing them per call from a gathered copy
+ * (needs "style_f64", "fold_decoder", decoder_dim_head == dim, "attention_bf16x3", no "attention_kv"; otherwise, and with 0, the
+ * per-call flow).  Takes effect at the next mocha_bank_set.
+ * "match_pass" (default 1): the bf16 bank's one-plane coarse pass for up to "match_pass_max_q" (default 256) queries as
+ * mocha_match_pass256 (match_pass.hip: 128 x 256 tiles, bank operands straight into registers, K split 16); 0 = round 4's
+ * mocha_match_gemm_bf16_dma.  Same products summed over other K slices: the selection's exact re-evaluation makes the answer the same.
+ * "match_pass_variant": that kernel's prefetch depth / non-temporal bit (diagnostic).
  * Every option that changes which kernels a step launches bumps mocha_generation(ctx). */
 int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
 

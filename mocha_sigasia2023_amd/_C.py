@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmocha_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class mocha_cfg(C.Structure):

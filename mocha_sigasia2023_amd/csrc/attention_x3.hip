@@ -57,8 +57,10 @@ __global__ __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(PF2 ? 2 : 3
     const int nq = p.nq, nk = p.nk;
 
     const float* qg = p.q + (size_t)b * nq * p.ldq + head * DH;
-    const float* kg = p.k + (size_t)b * nk * p.ldk + head * (p.hsk < 0 ? DH : p.hsk);
-    const float* vg = p.v + (size_t)b * nk * p.ldv + head * (p.hsv < 0 ? DH : p.hsv);
+    long long bk = b;                                         // keys / values of window b: its own rows, or the bank entry kv_idx[b] (clamped)
+    if (p.kv_idx) { bk = p.kv_idx[b]; bk = bk < 0 ? 0 : (bk >= p.kv_rows ? p.kv_rows - 1 : bk); }
+    const float* kg = p.k + (size_t)bk * nk * p.ldk + head * (p.hsk < 0 ? DH : p.hsk);
+    const float* vg = p.v + (size_t)bk * nk * p.ldv + head * (p.hsv < 0 ? DH : p.hsv);
     const __amdgpu_buffer_rsrc_t rsq = make_rsrc(qg), rsk = make_rsrc(kg), rsv = make_rsrc(vg);
 
     // ---------------- phase 1: S^T[key][query], head dim in chunks of 32
@@ -298,8 +300,10 @@ __global__ __launch_bounds__(768) void mocha_attention_x3_split(AttnParams p) {
     if (b >= p.B) return;
     const int nq = p.nq, nk = p.nk;
     const float* qg = p.q + (size_t)b * nq * p.ldq + head * DH;
-    const float* kg = p.k + (size_t)b * nk * p.ldk + head * (p.hsk < 0 ? DH : p.hsk);
-    const float* vg = p.v + (size_t)b * nk * p.ldv + head * (p.hsv < 0 ? DH : p.hsv);
+    long long bk = b;                                         // keys / values of window b: its own rows, or the bank entry kv_idx[b] (clamped)
+    if (p.kv_idx) { bk = p.kv_idx[b]; bk = bk < 0 ? 0 : (bk >= p.kv_rows ? p.kv_rows - 1 : bk); }
+    const float* kg = p.k + (size_t)bk * nk * p.ldk + head * (p.hsk < 0 ? DH : p.hsk);
+    const float* vg = p.v + (size_t)bk * nk * p.ldv + head * (p.hsv < 0 ? DH : p.hsv);
     const __amdgpu_buffer_rsrc_t rsq = make_rsrc(qg), rsk = make_rsrc(kg), rsv = make_rsrc(vg);
 
     // ---------------- phase 1: this group's quarter of S^T[key][query]

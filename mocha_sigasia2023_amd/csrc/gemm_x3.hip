@@ -830,8 +830,7 @@ static void x3_launch(const GemmParams& p, hipStream_t s) {
 // Default: 768 workgroups (three per CU) walk the tiles of launches up to 512 columns wide - out_proj / ff1 / ff2 / the embedding and to_mot
 // GEMMs 2-3 % faster, demo step 5.59 against 5.62 ms; the 1536-wide qkv projection is 5 % SLOWER that way and stays on mocha_gemm_x3
 // (profiles/r04/d_persist_ab.txt, d_persist_selective_ab.txt)
-int gemm_x3_persistent_max_n = 512;          // ... for launches of at most this many columns
-int gemm_x3_persistent = 768;         // > 0: workgroups of the persistent instance (diagnostic / option "gemm_persistent"; a multiple of 8)
+// GemmParams::persistent (workgroups, a multiple of 8; 0 = never) / persistent_max_n: per context, options "gemm_persistent[_max_n]"
 
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;
@@ -840,11 +839,11 @@ hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
     if (128ll * p.lda * 4 >= (1ll << 31)) return hipErrorInvalidValue;
     // mid-size launches (fewer than 768 tiles of 128 x 64: a few dozen to a few hundred windows) take 64-row tiles, twice the workgroups;
     // N = 64 / 192 the 64-wide tile
-    if (gemm_x3_persistent > 0 && p.ksplit <= 1 && p.N % XN == 0 && p.N <= gemm_x3_persistent_max_n && !gemm_is_small(p)) {
-        // the persistent instance: `gemm_x3_persistent` workgroups (a multiple of 8) walk the 128 x 128 tiles
+    if (p.persistent > 0 && p.ksplit <= 1 && p.N % XN == 0 && p.N <= p.persistent_max_n && !gemm_is_small(p)) {
+        // the persistent instance: p.persistent workgroups (a multiple of 8) walk the 128 x 128 tiles
         const int m_tiles = (p.M + 127) / 128, m_pad = m_tiles >= 8 ? (m_tiles + 7) / 8 * 8 : m_tiles;
         const long long total = (long long)m_pad * (p.N / XN);
-        const unsigned grid = (unsigned)std::min<long long>(total, gemm_x3_persistent);
+        const unsigned grid = (unsigned)std::min<long long>(total, p.persistent);
         const int epi = p.residual ? 1 : p.rowbias ? 2 : 0;
 #define X3P_LAUNCH(L, G)                                                                                                                  \
         do {                                                                                                                              \

@@ -38,6 +38,9 @@ struct GemmParams {
     float ascale = 1.f;
     int ksplit = 1;               // >1: split K over gridDim.z, raw partial sums to C + z*slab_stride
     long long slab_stride = 0;
+    // gemm_x3.hip, per context (options "gemm_persistent", "gemm_persistent_max_n"): workgroups of the persistent instance (0 = never; a
+    // multiple of 8) and the widest launch, in columns, that takes it
+    int persistent = 768, persistent_max_n = 512;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 bool gemm_is_narrow(const GemmParams& p);
@@ -52,8 +55,6 @@ bool gemm_x3_supports(const GemmParams& p);
 size_t gemm_x3_packed_elems(int N, int K);
 hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s, const float* wsub = nullptr);   // wsub: K values subtracted from every row
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s);
-extern int gemm_x3_persistent_max_n;
-extern int gemm_x3_persistent;       // > 0: the persistent instance (K loop across tiles) with that many workgroups for the 128 x 128-tile launches
 
 
 // ---------------------------------------------------------------------------------------
@@ -68,6 +69,9 @@ struct AttnParams {
     float scale;
     int hsk = -1, hsv = -1;       // column offset per head of k / v (default dh; 0 = all heads share the same rows)
     int split_max = 192;          // (window, head) pairs up to which the twelve-wave head-dim-256 variant is launched (0 = never)
+    // launch_attention_x3 only: window b's keys / values are rows [kv_idx[b] * nk, +nk) of k / v (index clamped to [0, kv_rows)) - the decoder
+    // reading IN(cha) and cha of the matched bank entries in place (test_fullframework.py:465), no gathered copy
+    const int32_t* kv_idx = nullptr; long long kv_rows = 0;
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t s);
 // the same on the bf16 matrix pipe with exact three-plane operands (attention_x3.hip): nq, nk <= 96, dh = 128 / 256
@@ -94,9 +98,9 @@ hipError_t launch_attention_x3_kv(const AttnKvParams& p, hipStream_t s);
 // raw_root = 1: X frames are (V+1, Cin) with the root bone first and are z-scored with xmean/xstd ((V+1)*Cin) on load
 hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP /*3*V*6*/,
                               float* out, int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root,
-                              hipStream_t s, bool planes = false);
+                              hipStream_t s, bool planes = false, int max_wgs = 512);
 hipError_t launch_embed_sums(const float* X, const float* W1, const float* b1, const float* AP, float* u, int nwin, int V, int Cin,
-                             const float* xmean, const float* xstd, int raw_root, hipStream_t s);      // planes: both contractions as plane products on the bf16 pipe
+                             const float* xmean, const float* xstd, int raw_root, hipStream_t s, int max_wgs = 512);      // max_wgs: option "embed_front_max_wgs" (per context)
 // rows (b,t,p) x 256 -> LeakyReLU -> body-part adjacency (2 hops) -> rows (b,t,w) x (k*256+c)
 hipError_t launch_body_front(const float* x, const float* A_b /*2*6*6*/, float* out, int rows6 /*B*15*/, hipStream_t s);
 // g rows (b,t',p) x (k*64+c) -> y2c rows (b,t',w) x 64 : sum_k sum_p AU[k][p][w] g[...]
@@ -121,14 +125,20 @@ struct InormExtra {
     // kvimg: per window the pre-split key / value images of launch_attention_x3_kv (ATTN_KV_IMG_BYTES each): K = the normalised rows,
     // V = the input rows, three bf16 planes each, rows n .. 95 zero
     unsigned short* kvimg = nullptr;
+    int split_max = 1 << 30;             // windows up to which a window's channels go over four workgroups (per context: option "inorm_split_max")
+    double* mean64 = nullptr;            // (B, 256) token mean summed in float64: the input of the float64 style MLP (launch_linear_f64)
 };
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
                            int B, int n, hipStream_t s, const InormExtra* ex = nullptr);
 // AdaIN + the attention's mapping norm (net/transformer.py:108-113, 49-56):
 //   xad = (1+gamma)*IN(x)+beta ; qin = IN(xad) ; gb (B,512) = [gamma | beta]
-extern int inorm_split_max;
-extern int embed_front_max_wgs, embed_sums;
-hipError_t launch_adain(const float* x, const float* gb, int gb_stride /*floats between windows*/, float* xad, float* qin, int B, int n, hipStream_t s);
+// closed != 0: qin from the first statistics in closed form (no cancellation against beta; pointwise.hip)
+// gb_idx non-null: window b reads its gamma / beta at gb + clamp(gb_idx[b], gb_rows) * gb_stride (the bank's cached style constants)
+hipError_t launch_adain(const float* x, const float* gb, int gb_stride /*floats between windows*/, float* xad, float* qin, int B, int n, hipStream_t s,
+                        int closed = 1, const int32_t* gb_idx = nullptr, long long gb_rows = 0, int split_max = 1 << 30);
+// Y = act(X W^T + bias) in float64, L independent column blocks (pointwise.hip: the decoder's style MLP)
+hipError_t launch_linear_f64(const double* X, int ldx, int xcol, const double* W, const double* bias, double* y64, float* y32, int ldy,
+                             int M, int N, int K, int L, int act, hipStream_t s);
 // u rows (b,t',p) x (dt*256+c) = 1/4 sum of the 4 reflect-indexed frames of tap dt (conv k=5 fused with AvgPool(4))
 hipError_t launch_window_sums(const float* y, float* u, int rows, int channels /*256 or 192*/, hipStream_t s);
 // ---- CVAE sampler pieces (cvae.hip; model_CVAE.py)
@@ -190,6 +200,11 @@ hipError_t launch_center_rows(const float* x, const float* centre, void* planes,
 // tiled: the bank as launch_tile_bf16 wrote it (match_tiled_elems(N, D) bf16), or null to read the row-major bank16
 hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes = 1,
                                   const void* tiled = nullptr);
+// round 5 (match_pass.hip): 128 queries x 256 rows per workgroup, the bank straight into registers, only the queries through LDS;
+// variant: bits 0-3 register prefetch depth in 64-k stages (0 = default), bit 4 non-temporal bank loads, bit 8 fill only (measurement)
+int match_pass256_ksplit(int Q, int64_t N);
+hipError_t launch_match_pass256(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int variant = 0,
+                                int planes = 1);
 size_t match_tiled_elems(int64_t N, int D);
 hipError_t launch_tile_bf16(const void* bank16, void* out, int64_t N, int D, hipStream_t s);
 hipError_t launch_match_select(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm, const float* query,

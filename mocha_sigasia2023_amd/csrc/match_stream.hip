@@ -463,8 +463,10 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
         }
     }
     // ---- 3. the slices' winners: each workgroup publishes its own, the one that arrives last picks the smallest (distance, row) key.
-    // The ticket counts this launch's arrivals; the last arriver puts it back to zero, so a launch that was cut short (an error between the
-    // scan and this kernel) cannot leave later calls electing the wrong workgroup.  Calls that share a scratch buffer are ordered by their stream.
+    // The ticket counts this launch's arrivals; every launch runs all RF_SPLIT workgroups of every query, so the last arriver sees
+    // RF_SPLIT - 1 and puts the word back to zero for the next launch (it never wraps).  This is NOT a recovery mechanism: a launch that did
+    // not complete (a device fault) leaves the ticket at some k != 0 and the scratch head must then be zeroed again by the host
+    // (ensure_match_scratch does so whenever it allocates the buffer).  Calls that share a scratch buffer are ordered by their stream.
     __syncthreads();
     if (tid == 0) {
         __atomic_store_n(part + (size_t)q * RF_SPLIT + sl, best, __ATOMIC_RELAXED);

@@ -154,6 +154,18 @@ struct mocha_ctx {
     float* pair_center = nullptr;                           // row norms / centroid of the transient bank of mocha_characterize_pair
     unsigned short* pair_x3 = nullptr; size_t pair_x3_cap = 0;     // ... and its packed plane image (never the user's bank_x3)
     int64_t bank_N = 0;
+    // Round 5: what the decoder derives from a bank ENTRY alone - IN(cha) (the folded decoder's keys, net/transformer.py:49-56) and every
+    // layer's AdaIN gamma / beta (the style MLP of the entry's token mean, :98-107) - is computed once at mocha_bank_set, in float64 for
+    // the MLP, and read through frame_index by the decoder (adain: gb_idx, attention: kv_idx) instead of being recomputed per step from
+    // a gathered copy: + 92 KB + 4 KB per entry.  Option "bank_dec_cache" (0: recompute per call, the round-4 flow).
+    bool bank_dec_cache = true;
+    float* bank_kin = nullptr; float* bank_gb = nullptr; size_t bank_dec_cap = 0; bool bank_dec_valid = false;
+    double* style_scratch = nullptr; size_t style_scratch_rows = 0;     // float64 token means + hidden activations of the style MLP, bank build
+    // launch tuning, per context (round 4 kept these as process-wide globals: a second context, or another host thread, changed them underfoot)
+    int inorm_split_max = 1 << 30, embed_max_wgs = 512, gemm_persistent = 768, gemm_persistent_max_n = 512; bool embed_sums = true;
+    bool adain_closed = true;          // mocha_adain: qin from the first statistics in closed form (pointwise.hip); 0 = the literal two-pass order
+    bool style_f64 = true;             // the style MLP in float64 (mocha_linear_f64); 0 = the fp32 GEMM engines
+    std::map<std::string, double*> w64;                     // float64 copies of the style MLP's weights
     // CVAE sampler (row N1): weights under "cvae.<reference key>", workspace for cvae_B conditions
     std::map<std::string, std::vector<int64_t>> cvae_expect;
     std::map<std::string, HostTensor> cvae_host;
@@ -193,6 +205,9 @@ struct mocha_ctx {
     // mocha_set_option("match_planes", 2) selects that variant (profiles/r04/c_select_ab.txt)
     bool select2 = true;
     int match_planes = 1;              // bf16 query planes of the many-query coarse pass against a bf16 bank
+    // round 5: the one-plane coarse pass as mocha_match_pass256 (match_pass.hip: 256-row tiles, bank operands straight into registers) for
+    // up to match_pass_max_q queries; 0 = round 4's mocha_match_gemm_bf16_dma.  match_pass_variant: launch_match_pass256's variant bits.
+    int match_pass = 1, match_pass_variant = 0, match_pass_max_q = 256;
     DevBuf match_qstat[MAX_SETS];
 
     // captured per-window step (mocha_step_graph): one executable graph, re-captured when its key changes
@@ -363,9 +378,11 @@ int ensure_ws(mocha_ctx* c, int B) {
     const std::pair<const char*, size_t> plan[] = {
         {"hbar", 360 * 192}, {"ybar", 360 * 256}, {"u", 90 * 1280}, {"x5", T}, {"xA", 90 * 512}, {"t1", T}, {"xa", T}, {"xb", T},
         {"qkv", 90 * 3072}, {"ao", 90 * 1024}, {"hff", (size_t)90 * std::max(512, std::max(c->cfg.enc_mlp, c->cfg.dec_mlp))}, {"kin", T}, {"xad", T}, {"qin", T},
-        {"smean", 256}, {"s1", 512 * 8}, {"gb", 512 * 8}, {"qc", T}, {"g", 90 * 192}, {"y2c", (size_t)15 * V * 64},
+        {"smean", 256}, {"s1", 512 * 8}, {"gb", 512 * 8}, {"smean64", 512}, {"s1d", 512 * 8 * 2}, {"qc", T}, {"g", 90 * 192}, {"y2c", (size_t)15 * V * 64},
         {"z", (size_t)60 * V * 64}, {"enc_s", T}, {"enc_c", T}, {"qnm", T}, {"sel", T}, {"dec", T},
-        {"kvimg", (size_t)ATTN_KV_IMG_BYTES / 4},          // the decoder attention's pre-split key / value images (attention_kv.hip)
+        // the decoder attention's pre-split key / value images (attention_kv.hip): 295 KB per window, planned only while option
+        // "attention_kv" is on (setting it re-plans the workspaces)
+        {"kvimg", c->attn_kv ? (size_t)ATTN_KV_IMG_BYTES / 4 : (size_t)4},
     };
     // free old workspaces
     for (int set = 0; set < mocha_ctx::MAX_SETS; ++set) {
@@ -398,6 +415,7 @@ int ensure_ws(mocha_ctx* c, int B) {
 }
 
 float* WS(mocha_ctx* c, const char* n) { return c->wss[c->cur].at(n).p; }
+InormExtra IEX(const mocha_ctx* c) { InormExtra e; e.split_max = c->inorm_split_max; return e; }     // the instance norm's extras with this context's launch tuning
 float* DW(mocha_ctx* c, const std::string& n) { return c->w.at(n); }
 
 // Every kernel launch goes through LAUNCH: error check, and when profiling is on a HIP event
@@ -464,7 +482,7 @@ int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
         int rc = x3_image(c, s, p, &img);
         if (rc) return rc;
         if (img) {
-            GemmParams q = p; q.Wsplit = img;
+            GemmParams q = p; q.Wsplit = img; q.persistent = c->gemm_persistent; q.persistent_max_n = c->gemm_persistent_max_n;
             LAUNCH(c, s, "mocha_gemm_x3", site, flops, bytes, launch_gemm_x3(q, s));
             return 0;
         }
@@ -500,17 +518,17 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     const int V = c->cfg.V;
     const int nn = (V + 1) * c->cfg.C_in;
     if (raw && !c->pose_norm) return fail(c, MOCHA_ERR_STATE, "raw input needs mocha_set_pose_norm first");
-    if (c->fold_joint && c->gemm_x3 && embed_sums) {
+    if (c->fold_joint && c->gemm_x3 && c->embed_sums) {
         // conv1 + lrelu + adjacency + joint->part pool, and the 4-frame sums of the five taps, in one kernel: the frame rows stay in LDS
         LAUNCH(c, s, "mocha_embed_sums_x3", "emb.front_sums", b * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18) + b * 90.0 * 960 * 4,
                b * 4.0 * (60.0 * V * 15 + 90.0 * 960),
                launch_embed_sums(X, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "u"), b, V, c->cfg.C_in,
-                                 raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s));
+                                 raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s, c->embed_max_wgs));
         if (X2 && b2 > 0) {
             LAUNCH(c, s, "mocha_embed_sums_x3", "emb.front_sums", b2 * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18) + b2 * 90.0 * 960 * 4,
                    b2 * 4.0 * (60.0 * V * 15 + 90.0 * 960),
                    launch_embed_sums(X2, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "u") + (size_t)b * 90 * 960, b2, V, c->cfg.C_in,
-                                     raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s));
+                                     raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s, c->embed_max_wgs));
             b += b2;
         }
         GemmParams gf = plain(WS(c, "u"), 960, DW(c, "emb.Wc"), WS(c, "x5"), 256, b * 90, 256, 960);
@@ -521,11 +539,11 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     const char* efk = c->gemm_x3 ? "mocha_embed_front_x3" : "mocha_embed_front";
     LAUNCH(c, s, efk, "emb.front", b * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b * 60.0 * (V * 15 + 6 * 192) * 4,
            launch_embed_front(X, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar"), b * 60, V, c->cfg.C_in,
-                              raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s, c->gemm_x3));
+                              raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s, c->gemm_x3, c->embed_max_wgs));
     if (X2 && b2 > 0) {
         LAUNCH(c, s, efk, "emb.front", b2 * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18), b2 * 60.0 * (V * 15 + 6 * 192) * 4,
                launch_embed_front(X2, DW(c, "emb.W1"), DW(c, "emb.b1"), DW(c, "AP"), WS(c, "hbar") + (size_t)b * 360 * 192, b2 * 60, V,
-                                  c->cfg.C_in, raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s, c->gemm_x3));
+                                  c->cfg.C_in, raw ? c->pose_norm : nullptr, raw ? c->pose_norm + nn : nullptr, raw ? 1 : 0, s, c->gemm_x3, c->embed_max_wgs));
         b += b2;
     }
     if (c->fold_joint) {
@@ -599,49 +617,95 @@ int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStr
     return 0;
 }
 
+// the style MLPs of every decoder layer in float64 (net/transformer.py:102-107): gb (rows, 512 L) = [gamma | beta] per layer, from the
+// float64 token means; hidden = rows x 512 L doubles of scratch
+int run_style_f64(mocha_ctx* c, const double* mean64, double* hidden, float* gb, int rows, hipStream_t s) {
+    const int L = c->cfg.dec_depth;
+    LAUNCH(c, s, "mocha_linear_f64", "dec.style1", 2.0 * rows * 512.0 * L * 256, rows * 8.0 * (256 + 512 * L) + 8.0 * 512 * L * 256,
+           launch_linear_f64(mean64, 256, 0, c->w64.at("dec.Ws1_all"), c->w64.at("dec.bs1_all"), hidden, nullptr, 512 * L, rows, 512 * L, 256, 1, 2, s));
+    LAUNCH(c, s, "mocha_linear_f64", "dec.style2", 2.0 * rows * 512.0 * L * 512, rows * (8.0 + 4.0) * 512 * L + 8.0 * L * 512 * 512,
+           launch_linear_f64(hidden, 512 * L, 512, c->w64.at("dec.Ws2_all"), c->w64.at("dec.bs2_all"), nullptr, gb, 512 * L, rows, 512, 512, L, 0, s));
+    return 0;
+}
+
+// can the decoder read a bank entry's constants (IN(cha), gamma / beta) in place through frame_index?  (the folded decoder on the plane
+// attention kernel; the image variant and the un-folded projections want contiguous per-window copies)
+bool dec_cache_ok(const mocha_ctx* c) {
+    return c->bank_dec_cache && c->style_f64 && c->fold_decoder && c->cfg.dec_dim_head == 256 && c->attn_x3 && !c->attn_kv;
+}
+
+// What the decoder derives from bank entries alone, for rows [0, N) of `enc`: kin = IN(entry) (the folded decoder's keys) and gb = every
+// layer's AdaIN gamma / beta (float64 style MLP of the entry's float64 token mean).  mean64 / hidden: scratch for `cap` rows.
+int build_dec_consts(mocha_ctx* c, const float* enc, int64_t N, float* kin, float* gb, double* mean64, double* hidden, int64_t cap, hipStream_t s) {
+    const size_t D = 90 * 256;
+    const int L = c->cfg.dec_depth;
+    for (int64_t r0 = 0; r0 < N; r0 += cap) {
+        const int rows = (int)std::min<int64_t>(cap, N - r0);
+        InormExtra ex = IEX(c); ex.mean64 = mean64;
+        LAUNCH(c, s, "mocha_instnorm", "bank.in_cha", 0.0, rows * 90.0 * 256 * 4 * 2,
+               launch_instnorm(enc + (size_t)r0 * D, kin + (size_t)r0 * D, nullptr, nullptr, nullptr, nullptr, rows, 90, s, &ex));
+        int rc = run_style_f64(c, mean64, hidden, gb + (size_t)r0 * 512 * L, rows, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 // decoder (model.py:62-68; net/transformer.py:90-121 with adain=True)
-// gather_table / gather_idx: cha is cha_encoded[frame_index] (test_fullframework.py:298, 465) - the first kernel reads the bank rows
-// through the indices itself and leaves the gathered copy in the "sel" workspace (cha may then be null)
+// gather_table / gather_idx: cha is cha_encoded[frame_index] (test_fullframework.py:298, 465).  With the bank's cached constants
+// (kin_table = IN of every entry, gb_table = its gamma / beta: build_dec_consts) the decoder reads everything that depends on the matched
+// entry IN PLACE through the indices - no instance norm of cha, no style MLP, no gathered copy; without them the first kernel gathers
+// the rows itself, leaves the copy in the "sel" workspace (cha may then be null) and the constants are computed here.
 int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* outp, hipStream_t s,
-                const float* gather_table = nullptr, const int32_t* gather_idx = nullptr, long long gather_rows = 0) {
+                const float* gather_table = nullptr, const int32_t* gather_idx = nullptr, long long gather_rows = 0,
+                const float* kin_table = nullptr, const float* gb_table = nullptr) {
     const int M = b * 90, H = c->cfg.dec_heads, DH = c->cfg.dec_dim_head, inner = H * DH, L = c->cfg.dec_depth;
+    const bool cached = gather_table && gather_idx && kin_table && gb_table && dec_cache_ok(c);
     // IN(cha) feeds every layer's keys; mean over tokens of cha feeds every layer's style MLP
     // Folded decoder at batch size: keys IN(cha) and values cha are the same for every head and layer - the instance norm writes them once
     // as pre-split bf16 plane images (InormExtra::kvimg) and every layer's attention reads those (attention_kv.hip); no fp32 copies
     const bool use_kv = c->fold_decoder && DH == 256 && c->attn_x3 && c->attn_kv && H >= 2 && H % 2 == 0 && (long long)b * H > c->attn_split_max;
-    {
-        InormExtra ex;
+    if (!cached) {
+        InormExtra ex = IEX(c);
         if (gather_table) { ex.table = gather_table; ex.row_idx = gather_idx; ex.table_rows = gather_rows; ex.copy_out = use_kv ? nullptr : WS(c, "sel"); }
         if (use_kv) ex.kvimg = reinterpret_cast<unsigned short*>(WS(c, "kvimg"));
+        if (c->style_f64) ex.mean64 = reinterpret_cast<double*>(WS(c, "smean64"));
         const double wr = use_kv ? (double)ATTN_KV_IMG_BYTES * 90.0 / 96.0 : 90.0 * 256 * 4 * (gather_table ? 2 : 1);
         LAUNCH(c, s, "mocha_instnorm", "dec.in_cha", 0.0, b * (90.0 * 256 * 4 + wr),
                launch_instnorm(gather_table ? gather_table : cha, use_kv ? nullptr : WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s, &ex));
         if (gather_table) cha = use_kv ? nullptr : WS(c, "sel");
-    }
-    // style MLPs of every layer at once: Linear 256->512, LeakyReLU, Linear 512->512 per layer          net/transformer.py:102-107
-    GemmParams s1 = plain(WS(c, "smean"), 256, DW(c, "dec.Ws1_all"), WS(c, "s1"), 512 * L, b, 512 * L, 256);
-    s1.bias = DW(c, "dec.bs1_all"); s1.act = 2;
-    GEMM(c, s, "dec.style1", s1);
-    if (b <= 192 || L == 1) {
-        // a handful of windows: launch count matters, the block-diagonal matrix's zero half does not
-        GemmParams s2 = plain(WS(c, "s1"), 512 * L, DW(c, "dec.Ws2_blk"), WS(c, "gb"), 512 * L, b, 512 * L, 512 * L);
-        s2.bias = DW(c, "dec.bs2_all");
-        GEMM(c, s, "dec.style2", s2);
-    } else {
-        for (int l = 0; l < L; ++l) {                     // large batches: layer l's 512 x 512 on its own slice of the hidden activations
-            const std::string p = "dec" + std::to_string(l);
-            GemmParams s2 = plain(WS(c, "s1") + (size_t)l * 512, 512 * L, DW(c, p + ".Ws2"), WS(c, "gb") + (size_t)l * 512, 512 * L, b, 512, 512);
-            s2.bias = DW(c, p + ".bs2");
-            GEMM(c, s, "dec.style2", s2);
+        // style MLPs of every layer at once: Linear 256->512, LeakyReLU, Linear 512->512 per layer          net/transformer.py:102-107
+        if (c->style_f64) {
+            int rc = run_style_f64(c, reinterpret_cast<const double*>(WS(c, "smean64")), reinterpret_cast<double*>(WS(c, "s1d")), WS(c, "gb"), b, s);
+            if (rc) return rc;
+        } else {
+            GemmParams s1 = plain(WS(c, "smean"), 256, DW(c, "dec.Ws1_all"), WS(c, "s1"), 512 * L, b, 512 * L, 256);
+            s1.bias = DW(c, "dec.bs1_all"); s1.act = 2;
+            GEMM(c, s, "dec.style1", s1);
+            if (b <= 192 || L == 1) {
+                // a handful of windows: launch count matters, the block-diagonal matrix's zero half does not
+                GemmParams s2 = plain(WS(c, "s1"), 512 * L, DW(c, "dec.Ws2_blk"), WS(c, "gb"), 512 * L, b, 512 * L, 512 * L);
+                s2.bias = DW(c, "dec.bs2_all");
+                GEMM(c, s, "dec.style2", s2);
+            } else {
+                for (int l = 0; l < L; ++l) {                     // large batches: layer l's 512 x 512 on its own slice of the hidden activations
+                    const std::string p = "dec" + std::to_string(l);
+                    GemmParams s2 = plain(WS(c, "s1") + (size_t)l * 512, 512 * L, DW(c, p + ".Ws2"), WS(c, "gb") + (size_t)l * 512, 512 * L, b, 512, 512);
+                    s2.bias = DW(c, p + ".bs2");
+                    GEMM(c, s, "dec.style2", s2);
+                }
+            }
         }
     }
+    const float* gbp = cached ? gb_table : WS(c, "gb");
     const float* x = src;
     float* qb = WS(c, "qkv");
     float* kb = qb + (size_t)M * inner;
     float* vb = kb + (size_t)M * inner;
     for (int l = 0; l < c->cfg.dec_depth; ++l) {
         const std::string p = "dec" + std::to_string(l);
-        LAUNCH(c, s, "mocha_adain", "dec.adain", 0.0, b * 90.0 * 256 * 4 * 3, launch_adain(x, WS(c, "gb") + (size_t)l * 512, 512 * L, WS(c, "xad"), WS(c, "qin"), b, 90, s));
+        LAUNCH(c, s, "mocha_adain", "dec.adain", 0.0, b * 90.0 * 256 * 4 * 3,
+               launch_adain(x, gbp + (size_t)l * 512, 512 * L, WS(c, "xad"), WS(c, "qin"), b, 90, s, c->adain_closed ? 1 : 0,
+                            cached ? gather_idx : nullptr, gather_rows, c->inorm_split_max));
         if (c->fold_decoder && DH == 256) {
             // S_h = IN(x) (Wq_h^T Wk_h) IN(cha)^T and out = sum_h (P_h cha) (Wv_h^T Wo_h^T): with dim_head == dim the key and
             // value projections fold into the query and output weights (exact algebra, net/transformer.py:62-76), so the
@@ -653,7 +717,8 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
                 LAUNCH(c, s, "mocha_attention_x3_kv<256>", "dec.attn", 4.0 * b * H * 90.0 * 90 * DH, 4.0 * M * 2 * inner + (double)b * ATTN_KV_IMG_BYTES,
                        launch_attention_x3_kv(a, s));
             } else {
-            AttnParams a{qb, WS(c, "kin"), cha, WS(c, "ao"), inner, 256, 256, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5), 0, 0};
+            AttnParams a{qb, cached ? kin_table : WS(c, "kin"), cached ? gather_table : cha, WS(c, "ao"), inner, 256, 256, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5), 0, 0};
+            if (cached) { a.kv_idx = gather_idx; a.kv_rows = gather_rows; }      // keys / values of window b = the matched entry's rows, in place
             LAUNCH(c, s, attn_kernel_name(c, DH, (long long)b * H), "dec.attn", 4.0 * b * H * 90.0 * 90 * DH, 4.0 * M * (2 * inner + 2 * 256),
                    attention(c, a, s));
             }
@@ -818,7 +883,8 @@ int ensure_match_scratch(mocha_ctx* c, int set, int Q, int64_t N, bool every_q_u
     }
     if (Q > 8) {
         size_t need = 0;
-        for (int q = every_q_up_to ? 9 : Q; q <= Q; ++q) need = std::max(need, (size_t)match_ksplit(q, N) * q * (size_t)N);
+        for (int q = every_q_up_to ? 9 : Q; q <= Q; ++q)
+            need = std::max(need, (size_t)std::max(match_ksplit(q, N), match_pass256_ksplit(q, N)) * q * (size_t)N);
         if ((rc = grow(c, c->match_S[set], need))) return rc;
         if ((rc = grow(c, c->match_qstat[set], (size_t)2 * QSTAT_PARTS * std::max(Q, 256)))) return rc;
     }
@@ -891,8 +957,9 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
         // row whose coarse score is within the query rounding's error bound of the best one - 2 ||dq|| (||b|| + ||b0||) with the query's
         // measured rounding residual dq, plus 5e-5 (2||q||^2 + ||b||^2 + ||b0||^2) of slack for the pass's fp32 accumulation - exactly
         // (fp32 centred query against the bf16 rows), so the result is the exact search over the rounded bank
-        const int ksplit = match_bf16_ksplit(Q, N);
         const int npl = sel2 ? c->match_planes : 1;
+        const bool pass256 = c->match_pass && !c->use_tiled && Q <= c->match_pass_max_q;
+        const int ksplit = pass256 ? match_pass256_ksplit(Q, N) : match_bf16_ksplit(Q, N);
         const void* tiled = nullptr;
         if (c->use_tiled && (size_t)N * D * 2 <= ((size_t)4 << 30)) {          // up to 4 GB of image (N = 93 k rows)
             const size_t need = match_tiled_elems(N, D);
@@ -909,6 +976,10 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
             }
             tiled = c->bank_tiled;
         }
+        if (pass256)
+            LAUNCH(c, s, "mocha_match_pass256", "match.qk_bf16", 2.0 * npl * Q * (double)N * D, 2.0 * npl * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
+                   launch_match_pass256(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, c->match_pass_variant, npl));
+        else
         LAUNCH(c, s, "mocha_match_gemm_bf16", "match.qk_bf16", 2.0 * npl * Q * (double)N * D, 2.0 * npl * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
                launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, npl, tiled));
         if (sel2)
@@ -932,6 +1003,7 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     }
     if (c->bank_x3_valid && c->gemm_x3 && gemm_x3_supports(g)) {
         g.Wsplit = c->bank_x3;                          // the centred bank as planes (bank_set_impl); same coarse-score accuracy as below
+        g.persistent = c->gemm_persistent; g.persistent_max_n = c->gemm_persistent_max_n;
         LAUNCH(c, s, "mocha_gemm_x3", "match.qk", 2.0 * Q * (double)N * D, 4.0 * ((double)Q * D + (double)Q * N * g.ksplit) + 6.0 * N * D,
                launch_gemm_x3(g, s));
     } else {
@@ -958,7 +1030,7 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
 // =========================================================================================== C ABI
 extern "C" {
 
-int mocha_abi_version(void) { return 4; }
+int mocha_abi_version(void) { return 5; }
 
 #define MOCHA_STR2(x) #x
 #define MOCHA_STR(x) MOCHA_STR2(x)
@@ -1205,6 +1277,22 @@ int mocha_finalize_weights(mocha_ctx* c) {
                 std::copy(a2.begin() + (size_t)o * 512, a2.begin() + (size_t)(o + 1) * 512, w2.begin() + ((size_t)l * 512 + o) * L * 512 + (size_t)l * 512);
         }
         up("dec.Ws1_all", w1); up("dec.bs1_all", b1v); up("dec.Ws2_blk", w2); up("dec.bs2_all", b2v);
+        // ... and the same MLP's operands in float64 (mocha_linear_f64; the fp32 values are exact in float64): first linear stacked over the
+        // layers, second linear per layer [L][512][512]
+        std::vector<double> w2d((size_t)L * 512 * 512);
+        for (int l = 0; l < L; ++l) {
+            const auto& a2 = W(c, "decoder.layers." + std::to_string(l) + ".0.style.4.weight");
+            std::copy(a2.begin(), a2.end(), w2d.begin() + (size_t)l * 512 * 512);
+        }
+        auto up64 = [&](const std::string& n, const std::vector<double>& v) {
+            if (rc) return;
+            double*& d = c->w64[n];
+            if (!d) { float* f = nullptr; rc = dev_alloc(c, &f, 2 * v.size()); d = reinterpret_cast<double*>(f); }
+            if (!rc && hipMemcpy(d, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = fail(c, MOCHA_ERR_HIP, "upload of %s failed", n.c_str());
+        };
+        up64("dec.Ws1_all", std::vector<double>(w1.begin(), w1.end())); up64("dec.bs1_all", std::vector<double>(b1v.begin(), b1v.end()));
+        up64("dec.Ws2_all", w2d); up64("dec.bs2_all", std::vector<double>(b2v.begin(), b2v.end()));
+        c->bank_dec_valid = false;                          // cached bank constants were made with the previous weights
     }
     // ---- to_mot joint block + head
     up("mot.Wg2", W(c, "to_mot.4.blk.gcn.conv.weight")); up("mot.bg2", W(c, "to_mot.4.blk.gcn.conv.bias"));
@@ -1301,7 +1389,8 @@ int mocha_mvn(mocha_ctx* c, const float* encoded, int B, float* cnt, const float
     HIPCHK(c, hipSetDevice(c->device));
     const bool zn = cnt_nm != nullptr;
     hipStream_t s = (hipStream_t)stream;
-    LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * (1 + (cnt ? 1 : 0) + (zn ? 1 : 0)), launch_instnorm(encoded, cnt, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr, zn ? cnt_nm : nullptr, B, 90, s));
+    const InormExtra iex0 = IEX(c);
+    LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * (1 + (cnt ? 1 : 0) + (zn ? 1 : 0)), launch_instnorm(encoded, cnt, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr, zn ? cnt_nm : nullptr, B, 90, s, &iex0));
     return 0;
 }
 
@@ -1316,10 +1405,12 @@ int mocha_encode(mocha_ctx* c, const float* X, int B, float* encoded, float* cnt
         int r = run_embed(c, X + b0 * xs, b, WS(c, "x5"), true, s);      // x5 is free again once the body block has read it
         if (r) return r;
         if ((r = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s))) return r;
-        if (cnt || zn)
+        if (cnt || zn) {
+            const InormExtra iex0 = IEX(c);
             LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (1 + (cnt ? 1 : 0) + (zn ? 1 : 0)),
                    launch_instnorm(encoded + b0 * ts, cnt ? cnt + b0 * ts : nullptr, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
-                                   zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
+                                   zn ? cnt_nm + b0 * ts : nullptr, b, 90, s, &iex0));
+        }
         return 0;
     });
 }
@@ -1434,6 +1525,31 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
         LAUNCH(c, s, "mocha_rowresid", "bank.resid", 3.0 * N * D, 6.0 * N * D, launch_rowresid(c->bank_cnt, c->bank_center, c->bank16f, c->bank_rho, N, (int)D, s));
         c->bank16f_valid = true;
     }
+    // decoder constants of every entry (round 5): IN(entry) and its AdaIN gamma / beta, read in place through frame_index by the decoder
+    if (current) {
+        c->bank_dec_valid = false;
+        if (dec_cache_ok(c)) {
+            const int L = c->cfg.dec_depth;
+            if (c->bank_dec_cap < (size_t)N) {
+                for (float** p : {&c->bank_kin, &c->bank_gb})
+                    if (*p) { dev_free(c, *p); *p = nullptr; }
+                c->bank_dec_cap = 0;
+                if ((rc = dev_alloc(c, &c->bank_kin, (size_t)N * D))) return rc;
+                if ((rc = dev_alloc(c, &c->bank_gb, (size_t)N * 512 * L))) return rc;
+                c->bank_dec_cap = (size_t)N;
+            }
+            const size_t rows = (size_t)std::min<int64_t>(N, 4096);
+            if (c->style_scratch_rows < rows) {
+                if (c->style_scratch) dev_free(c, reinterpret_cast<float*>(c->style_scratch));
+                c->style_scratch = nullptr; c->style_scratch_rows = 0;
+                float* f = nullptr;
+                if ((rc = dev_alloc(c, &f, 2 * rows * (256 + (size_t)512 * L)))) return rc;
+                c->style_scratch = reinterpret_cast<double*>(f); c->style_scratch_rows = rows;
+            }
+            if ((rc = build_dec_consts(c, c->bank_enc, N, c->bank_kin, c->bank_gb, c->style_scratch, c->style_scratch + rows * 256, (int64_t)rows, s))) return rc;
+            c->bank_dec_valid = true;
+        }
+    }
     // many-query matching against a small fp32 bank runs on the plane engine: centred bank as its packed image (6 B per value)
     c->bank_x3_valid = false;
     if (!c->bank_is_bf16 && c->gemm_x3 && N <= X3_BANK_MAX) {
@@ -1531,13 +1647,14 @@ static int characterize_impl(mocha_ctx* c, const float* src_X, int B, const floa
         const bool q16 = c->bank_is_bf16 && b > 8;
         const bool sel2 = use_select2(c, b);                     // the selection's row statistics (and the second bf16 plane) come from this pass too
         if (sel2 && (r = ensure_match_scratch(c, c->cur, b, c->bank_N, false))) return r;
-        InormExtra ex; ex.centre = c->bank_center;
+        InormExtra ex = IEX(c); ex.centre = c->bank_center;
         if (q16) ex.zc16 = reinterpret_cast<unsigned short*>(WS(c, "qc")); else ex.zc = WS(c, "qc");
         if (sel2) { ex.qstat = c->match_qstat[c->cur].p; if (q16 && c->match_planes == 2) ex.plane_stride = (long long)b * 90 * 256; }
         LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (q16 ? (sel2 ? 3.0 : 2.5) : 3.0), launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), b, 90, s, &ex));
         if ((r = do_match(c, WS(c, "qnm"), b, ix, nullptr, s, WS(c, "qc"), q16, sel2))) return r;
         // decoder on cha_encoded[frame_index]: its first kernel gathers the rows itself
-        if ((r = run_decoder(c, WS(c, "enc_s"), nullptr, b, WS(c, "dec"), s, c->bank_enc, ix, c->bank_N))) return r;
+        if ((r = run_decoder(c, WS(c, "enc_s"), nullptr, b, WS(c, "dec"), s, c->bank_enc, ix, c->bank_N,
+                             c->bank_dec_valid ? c->bank_kin : nullptr, c->bank_dec_valid ? c->bank_gb : nullptr))) return r;
         return run_to_mot(c, WS(c, "dec"), b, Y + b0 * ys, s, raw);
     });
 }
@@ -1574,8 +1691,9 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     // character windows first: rows [0, B_cha) of every buffer are the bank, rows [B_cha, B) the queries
     if ((rc = run_embed(c, cha_X, B_cha, WS(c, "x5"), true, s, raw, src_X, B_src))) return rc;
     if ((rc = run_encoder(c, WS(c, "x5"), B, WS(c, "enc_s"), s))) return rc;
+    const InormExtra iex0 = IEX(c);
     LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * 2,
-           launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), B, 90, s));
+           launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), B, 90, s, &iex0));
     if (cha_encoded) HIPCHK(c, hipMemcpyAsync(cha_encoded, WS(c, "enc_s"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (cha_cnt_nm) HIPCHK(c, hipMemcpyAsync(cha_cnt_nm, WS(c, "qnm"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (B_src == 0) return 0;
@@ -1600,7 +1718,15 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     if (rc) return rc;
     // decoder on the matched character rows: the transient bank's encoded rows are rows [0, B_cha) of the workspace; the first kernel
     // of the decoder gathers them through the indices
-    if ((rc = run_decoder(c, WS(c, "enc_s") + (size_t)B_cha * T, nullptr, B_src, WS(c, "dec"), s, WS(c, "enc_s"), ix, B_cha))) return rc;
+    const float *kin_t = nullptr, *gb_t = nullptr;
+    if (dec_cache_ok(c)) {
+        // the transient bank's decoder constants (part of the bank build, as mocha_bank_set does for a user's bank): in the workspace rows the
+        // un-cached flow would have filled per source window
+        if ((rc = build_dec_consts(c, WS(c, "enc_s"), B_cha, WS(c, "kin"), WS(c, "gb"), reinterpret_cast<double*>(WS(c, "smean64")),
+                                   reinterpret_cast<double*>(WS(c, "s1d")), B_cha, s))) return rc;
+        kin_t = WS(c, "kin"); gb_t = WS(c, "gb");
+    }
+    if ((rc = run_decoder(c, WS(c, "enc_s") + (size_t)B_cha * T, nullptr, B_src, WS(c, "dec"), s, WS(c, "enc_s"), ix, B_cha, kin_t, gb_t))) return rc;
     return run_to_mot(c, WS(c, "dec"), B_src, Y, s, raw);
 }
 
@@ -1904,10 +2030,12 @@ int mocha_encode_raw(mocha_ctx* c, const float* X_raw, int B, float* encoded, fl
         int r;
         if ((r = run_embed(c, X_raw + b0 * xs, b, WS(c, "x5"), true, s, true))) return r;
         if ((r = run_encoder(c, WS(c, "x5"), b, encoded + b0 * ts, s))) return r;
-        if (cnt || zn)
+        if (cnt || zn) {
+            const InormExtra iex0 = IEX(c);
             LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, b * 90.0 * 256 * 4 * (1 + (cnt ? 1 : 0) + (zn ? 1 : 0)),
                    launch_instnorm(encoded + b0 * ts, cnt ? cnt + b0 * ts : nullptr, nullptr, zn ? cnt_mean : nullptr, zn ? cnt_std : nullptr,
-                                   zn ? cnt_nm + b0 * ts : nullptr, b, 90, s));
+                                   zn ? cnt_nm + b0 * ts : nullptr, b, 90, s, &iex0));
+        }
         return 0;
     });
 }
@@ -2224,15 +2352,27 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "fold_joint") { c->fold_joint = value != 0; c->generation++; return 0; }
     if (n == "scan16") { c->scan16 = value != 0; c->generation++; return 0; }             // bank side takes effect at the next mocha_bank_set
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only
-    if (n == "gemm_persistent_max_n") { gemm_x3_persistent_max_n = value < 128 ? 128 : value; c->generation++; return 0; }      // process-wide (diagnostic)
-    if (n == "gemm_persistent") { gemm_x3_persistent = value < 0 ? 0 : (value + 7) / 8 * 8; c->generation++; return 0; }      // process-wide (diagnostic)
-    if (n == "embed_sums") { embed_sums = value != 0; c->generation++; return 0; }                          // process-wide (diagnostic)
-    if (n == "embed_front_max_wgs") { embed_front_max_wgs = value; c->generation++; return 0; }              // process-wide (diagnostic)
-    if (n == "inorm_split_max") { inorm_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // process-wide (diagnostic)
+    if (n == "gemm_persistent_max_n") { c->gemm_persistent_max_n = value < 128 ? 128 : value; c->generation++; return 0; }
+    if (n == "gemm_persistent") { c->gemm_persistent = value < 0 ? 0 : (value + 7) / 8 * 8; c->generation++; return 0; }
+    if (n == "embed_sums") { c->embed_sums = value != 0; c->generation++; return 0; }
+    if (n == "embed_front_max_wgs") { c->embed_max_wgs = value; c->generation++; return 0; }
+    if (n == "inorm_split_max") { c->inorm_split_max = value < 0 ? 0 : value; c->generation++; return 0; }
+    if (n == "adain_closed_form") { c->adain_closed = value != 0; c->generation++; return 0; }
+    if (n == "style_f64") { c->style_f64 = value != 0; c->bank_dec_valid = false; c->generation++; return 0; }     // cached bank constants: rebuilt at the next mocha_bank_set
+    if (n == "bank_dec_cache") { c->bank_dec_cache = value != 0; if (!value) c->bank_dec_valid = false; c->generation++; return 0; }     // takes effect at the next mocha_bank_set
     if (n == "bank_tiled") { c->use_tiled = value != 0; c->generation++; return 0; }
     if (n == "match_planes") { if (value != 1 && value != 2) return fail(c, MOCHA_ERR_ARG, "match_planes must be 1 or 2"); c->match_planes = value; c->generation++; return 0; }
     if (n == "select2") { c->select2 = value != 0; c->generation++; return 0; }
-    if (n == "attention_kv") { c->attn_kv = value != 0; c->generation++; return 0; }
+    if (n == "match_pass") { c->match_pass = value != 0; c->generation++; return 0; }
+    if (n == "match_pass_variant") { c->match_pass_variant = value; c->generation++; return 0; }
+    if (n == "match_pass_max_q") { c->match_pass_max_q = value; c->generation++; return 0; }
+    if (n == "attention_kv") {
+        HIPCHK(c, hipSetDevice(c->device));
+        HIPCHK(c, hipDeviceSynchronize());
+        c->attn_kv = value != 0;
+        c->chunk = 0;                              // the key / value image workspace exists only while the option is on: re-planned on the next call
+        return 0;
+    }
     if (n == "attention_kv_pairs") { c->attn_kv_pairs = value != 0; c->generation++; return 0; }
     if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; c->generation++; return 0; }
     if (n == "attention_bf16x3") { c->attn_x3 = value != 0; c->generation++; return 0; }
@@ -2259,7 +2399,7 @@ int mocha_linear(mocha_ctx* c, const float* x, const float* w, const float* bias
     void* img = nullptr;
     HIPCHK(c, hipMalloc(&img, gemm_x3_packed_elems(N, K) * sizeof(unsigned short)));
     hipError_t e = launch_pack_x3(w, N, K, (unsigned short*)img, s);
-    p.Wsplit = (const unsigned short*)img;
+    p.Wsplit = (const unsigned short*)img; p.persistent = c->gemm_persistent; p.persistent_max_n = c->gemm_persistent_max_n;
     if (e == hipSuccess) e = launch_gemm_x3(p, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(img);

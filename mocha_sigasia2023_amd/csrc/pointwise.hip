@@ -363,19 +363,18 @@ __global__ __launch_bounds__(256) void mocha_embed_sums_x3(const float* __restri
         w = w2; a = a2; n = n2; s = s2;
     }
 }
-int embed_sums = 1;                   // option "embed_sums": the fused kernel where the folded joint block and the plane engine are on
-
 // Workgroups of the plane build: every workgroup pays the per-lane plane constants (W1, AP', the staging map) before its first frame, so the
 // grid is what the chip holds at once (2 workgroups of 4 waves per CU at 158 + 32 registers) and each wave takes ~17 frames of the demo
-// step: 78 -> 65 us per launch (profiles/r04/h_embed_front_ab.txt; 256: 79, 1024: 69, uncapped: 122).  Option "embed_front_max_wgs".
-int embed_front_max_wgs = 512;
+// step: 78 -> 65 us per launch (profiles/r04/h_embed_front_ab.txt; 256: 79, 1024: 69, uncapped: 122).  Option "embed_front_max_wgs" (per
+// context, passed in as max_wgs; default 512).
 
 hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, const float* AP, float* out,
-                              int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root, hipStream_t s, bool planes) {
+                              int nframes, int V, int Cin, const float* xmean, const float* xstd, int raw_root, hipStream_t s, bool planes,
+                              int max_wgs) {
     if (nframes <= 0) return hipSuccess;
     if (V > 32 || Cin > 16 || V * Cin > 512) return hipErrorInvalidValue;
     const int wgs = (nframes + 3) / 4;
-    const int cap = !planes ? 2048 : embed_front_max_wgs > 0 ? embed_front_max_wgs : 512;
+    const int cap = !planes ? 2048 : max_wgs > 0 ? max_wgs : 512;
     if (planes)
         hipLaunchKernelGGL(mocha_embed_front_x3, dim3(wgs < cap ? wgs : cap), dim3(256), 0, s, X, W1, b1, AP, out,
                            nframes, V, Cin, xmean, xstd, raw_root);
@@ -386,11 +385,11 @@ hipError_t launch_embed_front(const float* X, const float* W1, const float* b1, 
 }
 
 hipError_t launch_embed_sums(const float* X, const float* W1, const float* b1, const float* AP, float* u, int nwin, int V, int Cin,
-                             const float* xmean, const float* xstd, int raw_root, hipStream_t s) {
+                             const float* xmean, const float* xstd, int raw_root, hipStream_t s, int max_wgs) {
     if (nwin <= 0) return hipSuccess;
     if (V > 32 || Cin > 16 || V * Cin > 512) return hipErrorInvalidValue;
     const long long T = (long long)nwin * 15;
-    const int cap = embed_front_max_wgs > 0 ? embed_front_max_wgs : 512;
+    const int cap = max_wgs > 0 ? max_wgs : 512;
     hipLaunchKernelGGL(mocha_embed_sums_x3, dim3((unsigned)(T < cap ? T : cap)), dim3(256), 0, s, X, W1, b1, AP, u, nwin, V, Cin, xmean, xstd, raw_root);
     return hipGetLastError();
 }
@@ -636,6 +635,23 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
     f32x4 mean, den;
     inorm_stats<QW>(xv, cnt, n, red, ql, g, mean, den);
     if (mean_out && g == 0) reinterpret_cast<f32x4*>(mean_out + (size_t)b * 256)[q] = mean;
+    if (ex.mean64) {
+        // the style MLP's input (AdaptiveAvgPool1d over the tokens, net/transformer.py:100-101) summed in float64: the MLP that follows runs
+        // in float64 too (mocha_linear_f64), so that gamma / beta carry no rounding of their own into AdaIN (tools/precision_study.py)
+        __shared__ double red64[QW * IN_NG][4];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < IN_MAXT; ++i)
+            if (i < cnt) { a0 += (double)xv[i][0]; a1 += (double)xv[i][1]; a2 += (double)xv[i][2]; a3 += (double)xv[i][3]; }
+        red64[g * QW + ql][0] = a0; red64[g * QW + ql][1] = a1; red64[g * QW + ql][2] = a2; red64[g * QW + ql][3] = a3;
+        __syncthreads();
+        if (g < 4) {                                         // token group g sums channel g of the quad over the groups, fixed order
+            double a = red64[ql][g];
+#pragma unroll
+            for (int k = 1; k < IN_NG; ++k) a += red64[k * QW + ql][g];
+            ex.mean64[(size_t)b * 256 + 4 * q + g] = a / (double)n;
+        }
+    }
     f32x4* ob = reinterpret_cast<f32x4*>(out + (size_t)b * n * 256) + q;
     float qs_n = 0.f, qs_d = 0.f;                            // this thread's share of ||zc||^2 and of the planes' residual (InormExtra::qstat)
 #pragma unroll
@@ -714,8 +730,7 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
 // Windows up to which a window's 256 channels go over four workgroups (option "inorm_split_max").  Round 4: EVERY batch - the variant built
 // for a handful of windows is also the faster one at 585 / 1 170 (mvn 77 -> 59 us, adain 43 -> 40, in_cha 43 -> 40; eight workgroups
 // per window: no further gain; tools/inorm_ab.py): four times the workgroups overlap each other's load -> reduce -> store phases.
-int inorm_split_max = 1 << 30;
-static inline bool inorm_split(int B) { return B <= inorm_split_max; }
+// (per context since round 5: InormExtra::split_max / launch_adain's split_max; default: every batch)
 
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
                            int B, int n, hipStream_t s, const InormExtra* exp) {
@@ -727,16 +742,24 @@ hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const fl
     if (ex.qstat && !(ex.zc || ex.zc16)) return hipErrorInvalidValue;
     if ((long long)ex.plane_stride < 0 || (ex.plane_stride > 0 && !ex.zc16)) return hipErrorInvalidValue;
     static_assert(QSTAT_PARTS == 4, "the four workgroups of a window write one part of the row statistics each");
-    if (inorm_split(B)) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
+    if (B <= ex.split_max) hipLaunchKernelGGL(mocha_instnorm<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     else hipLaunchKernelGGL(mocha_instnorm<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, out, mean_out, gm, gs, zn, n, ex);
     return hipGetLastError();
 }
 
 // AdaIN followed by the attention's own mapping norm (net/transformer.py:108-113 then :49-56):
 //   xad = (1+gamma) * IN(x) + beta ;  qin = IN(xad)
+// closed != 0 (default, option "adain_closed_form"): qin from the FIRST statistics.  With m, s the mean / unbiased std of x over the
+// tokens, xad's own token mean is exactly beta and its std |1+gamma| s / (s+eps), hence
+//   qin = IN(xad) = (1+gamma) (x-m) / (|1+gamma| s + eps (s+eps))
+// The literal order subtracts mean(xad) ~ beta from values whose spread is |1+gamma|: wherever a channel's 1+gamma is small the
+// reference's own fp32 evaluation loses that channel's digits to the cancellation (tools/precision_study.py: two fp32 runs of the
+// reference differ by up to 2e-3 on such inputs); the closed form has no cancellation and one reduction fewer.  closed == 0 keeps
+// the literal two-pass order for A/B (tools/structured_matrix.py).
 template <int QW>
 __global__ __launch_bounds__(QW * IN_NG) void mocha_adain(const float* __restrict__ x, const float* __restrict__ gb, int gb_stride,
-                                                          float* __restrict__ xad, float* __restrict__ qin, int n) {
+                                                          float* __restrict__ xad, float* __restrict__ qin, int n, int closed,
+                                                          const int32_t* __restrict__ gb_idx, long long gb_rows) {
     __shared__ f32x4 red[QW * IN_NG];
     const int b = blockIdx.x, ql = threadIdx.x % QW, g = threadIdx.x / QW;
     const int q = blockIdx.y * QW + ql;
@@ -746,12 +769,32 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_adain(const float* __restric
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) xv[i] = xb[(size_t)(g + IN_NG * i) * 64];
-    f32x4 gamma1 = reinterpret_cast<const f32x4*>(gb + (size_t)b * gb_stride)[q];
-    const f32x4 beta = reinterpret_cast<const f32x4*>(gb + (size_t)b * gb_stride + 256)[q];
+    long long gr = b;
+    if (gb_idx) { gr = gb_idx[b]; gr = gr < 0 ? 0 : (gr >= gb_rows ? gb_rows - 1 : gr); }      // the matched bank entry's constants, index clamped
+    f32x4 gamma1 = reinterpret_cast<const f32x4*>(gb + (size_t)gr * gb_stride)[q];
+    const f32x4 beta = reinterpret_cast<const f32x4*>(gb + (size_t)gr * gb_stride + 256)[q];
     gamma1 += 1.f;
     f32x4 mean, den;
     inorm_stats<QW>(xv, cnt, n, red, ql, g, mean, den);
     f32x4* ab = reinterpret_cast<f32x4*>(xad + (size_t)b * n * 256) + q;
+    f32x4* qb = reinterpret_cast<f32x4*>(qin + (size_t)b * n * 256) + q;
+    if (closed) {
+        f32x4 a1, a2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float s = den[k] - 1e-5f;                  // exact: den = s + eps was rounded once, s is recovered to an ulp of den
+            a1[k] = gamma1[k] / den[k];
+            a2[k] = gamma1[k] / fmaf(fabsf(gamma1[k]), s, 1e-5f * den[k]);
+        }
+#pragma unroll
+        for (int i = 0; i < IN_MAXT; ++i)
+            if (i < cnt) {
+                const f32x4 d = xv[i] - mean;
+                ab[(size_t)(g + IN_NG * i) * 64] = a1 * d + beta;
+                qb[(size_t)(g + IN_NG * i) * 64] = a2 * d;
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) {
@@ -759,17 +802,89 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_adain(const float* __restric
             ab[(size_t)(g + IN_NG * i) * 64] = xv[i];
         }
     inorm_stats<QW>(xv, cnt, n, red, ql, g, mean, den);
-    f32x4* qb = reinterpret_cast<f32x4*>(qin + (size_t)b * n * 256) + q;
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) qb[(size_t)(g + IN_NG * i) * 64] = (xv[i] - mean) / den;
 }
 
-hipError_t launch_adain(const float* x, const float* gb, int gb_stride, float* xad, float* qin, int B, int n, hipStream_t s) {
+hipError_t launch_adain(const float* x, const float* gb, int gb_stride, float* xad, float* qin, int B, int n, hipStream_t s, int closed,
+                        const int32_t* gb_idx, long long gb_rows, int split_max) {
     if (B <= 0) return hipSuccess;
-    if (n > IN_NG * IN_MAXT || n < 2 || gb_stride < 512 || (gb_stride & 3)) return hipErrorInvalidValue;
-    if (inorm_split(B)) hipLaunchKernelGGL(mocha_adain<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, gb, gb_stride, xad, qin, n);
-    else hipLaunchKernelGGL(mocha_adain<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, gb, gb_stride, xad, qin, n);
+    if (n > IN_NG * IN_MAXT || n < 2 || gb_stride < 512 || (gb_stride & 3) || (gb_idx && gb_rows < 1)) return hipErrorInvalidValue;
+    if (B <= split_max) hipLaunchKernelGGL(mocha_adain<16>, dim3(B, 4), dim3(16 * IN_NG), 0, s, x, gb, gb_stride, xad, qin, n, closed, gb_idx, gb_rows);
+    else hipLaunchKernelGGL(mocha_adain<64>, dim3(B, 1), dim3(64 * IN_NG), 0, s, x, gb, gb_stride, xad, qin, n, closed, gb_idx, gb_rows);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// Y = act(X W^T + bias) in float64 (the decoder's style MLP, net/transformer.py:102-107): X (M, ldx) float64, W (N, K) float64
+// (the fp32 weights converted once), float64 accumulation; the result is stored as float64 (y64) and / or rounded once to fp32 (y32).
+// gridDim.z = L independent blocks: block l reads X columns [l*xcol, l*xcol + K), W + l*N*K, bias + l*N and writes columns [l*N, (l+1)*N).
+// Why float64: AdaIN's (1 + gamma) multiplies the normalised activations and the attention's mapping norm divides by |1 + gamma| s + eps:
+// where 1 + gamma is within ~1e-4 of zero the fp32 rounding of gamma (1e-6 absolute) moves that channel of the queries by per cent
+// - the largest single contribution to the reference's own fp32 error on structured inputs (tools/precision_study.py, part 2).
+// 64 x 64 tile per 256-thread workgroup, 4 x 4 outputs per thread, K staged through LDS 32 deep.  ~20 us for 585 windows.
+// ---------------------------------------------------------------------------------------
+template <int ACT /* 0 none, 2 LeakyReLU(0.2) */>
+__global__ __launch_bounds__(256) void mocha_linear_f64(const double* __restrict__ X, int ldx, int xcol, const double* __restrict__ W,
+                                                        const double* __restrict__ bias, double* __restrict__ y64, float* __restrict__ y32,
+                                                        int ldy, int M, int N, int K) {
+    constexpr int KT = 32, LDT = 64 + 2;
+    __shared__ double Xs[KT][LDT];
+    __shared__ double Ws[KT][LDT];
+    const int l = blockIdx.z;
+    const int r0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const double* Xl = X + (size_t)l * xcol;
+    const double* Wl = W + (size_t)l * N * K;
+    double acc[4][4] = {};
+    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 8;          // loader: row / column lr of the tile, 8 consecutive k
+    for (int k0 = 0; k0 < K; k0 += KT) {
+        double xr[8], wr[8];
+        const int xrow = r0 + lr;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            xr[i] = (xrow < M) ? Xl[(size_t)xrow * ldx + k0 + lk + i] : 0.0;
+            wr[i] = (n0 + lr < N) ? Wl[(size_t)(n0 + lr) * K + k0 + lk + i] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { Xs[lk + i][lr] = xr[i]; Ws[lk + i][lr] = wr[i]; }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < KT; ++kk) {
+            double xa[4], wb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xa[i] = Xs[kk][ty * 4 + i]; wb[i] = Ws[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fma(xa[i], wb[j], acc[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty * 4 + i;
+        if (r >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n0 + tx * 4 + j;
+            if (nn >= N) continue;
+            double v = acc[i][j] + (bias ? bias[(size_t)l * N + nn] : 0.0);
+            if (ACT == 2) v = v > 0.0 ? v : 0.2 * v;
+            if (y64) y64[(size_t)r * ldy + (size_t)l * N + nn] = v;
+            if (y32) y32[(size_t)r * ldy + (size_t)l * N + nn] = (float)v;
+        }
+    }
+}
+
+hipError_t launch_linear_f64(const double* X, int ldx, int xcol, const double* W, const double* bias, double* y64, float* y32, int ldy,
+                             int M, int N, int K, int L, int act, hipStream_t s) {
+    if (M <= 0) return hipSuccess;
+    if (N < 1 || K < 32 || (K & 31) || L < 1 || (act != 0 && act != 2) || (!y64 && !y32)) return hipErrorInvalidValue;
+    const dim3 grid((N + 63) / 64, (M + 63) / 64, L);
+    if (act == 2) hipLaunchKernelGGL(mocha_linear_f64<2>, grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);
+    else hipLaunchKernelGGL(mocha_linear_f64<0>, grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);
     return hipGetLastError();
 }
 

@@ -239,6 +239,58 @@ def test_lazy_selection_is_the_staged_selection(model, Q, N):
         assert res[1][1][Q - 1].item() == N - 1 and res[1][0][Q - 1].item() == 0.0 if not bf16 else True
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("dup", ["identical", "perturbed"])
+def test_selection_with_more_candidates_than_its_list_holds(model, dup):
+    """mocha_match_select2 keeps at most 64 candidates per pass; a query with MORE rows inside the coarse pass's error bound
+    takes the 'windowed' branch (the list is rebuilt per 64-row window).  Nothing else reaches it: here 150 / 200 bank rows are identical
+    to (or within 1e-6 of) the rows two queries sit on - duplicated database clips - among ordinary rows, for an fp32 bank and for a bf16
+    bank with two query planes.  The answer must be the LOWEST row among the nearest (float64 search; ties to the lowest index, the
+    BallTree / argmin convention of test_fullframework.py:296) and equal to the staged selection's (select2 = 0)."""
+    from mocha_sigasia2023_amd import ContextBank
+    N, Q = 1500, 12
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    bank = torch.randn((N, 90 * 256), device="cuda", generator=g)
+    q = torch.randn((Q, 90 * 256), device="cuda", generator=g)
+    crowd_a = torch.arange(40, 40 + 150, device="cuda")                       # 150 consecutive rows: more than two 64-row windows
+    crowd_b = torch.randperm(N - 400, device="cuda", generator=g)[:200] + 400    # 200 scattered rows
+    base_a, base_b = bank[40].clone(), bank[777].clone()
+    if dup == "identical":
+        bank[crowd_a] = base_a; bank[crowd_b] = base_b
+    else:
+        bank[crowd_a] = base_a + 1e-6 * torch.randn((150, 90 * 256), device="cuda", generator=g)
+        bank[crowd_b] = base_b + 1e-6 * torch.randn((200, 90 * 256), device="cuda", generator=g)
+    q[0] = base_a + 1e-4 * q[0]
+    q[1] = base_b + 1e-4 * q[1]
+    q[2] = base_a                                                              # exactly on the crowd
+    for bf16 in (False, True):
+        # what the search runs over: the fp32 rows, or the bf16-rounded centred rows (the bank the bf16 matcher is exact over)
+        res = {}
+        for sel in (1, 0):
+            model.set_option("select2", sel)
+            model.set_option("match_planes", 2 if (sel and bf16) else 1)
+            cb = ContextBank(model, bank, bank.view(N, 90, 256), bf16=bf16)
+            d, i = cb.query(q)
+            res[sel] = (d[:, 0].clone(), i[:, 0].clone())
+            assert torch.equal(cb.query(q, return_distance=False)[:, 0], i[:, 0])
+        model.set_option("select2", 1); model.set_option("match_planes", 1)
+        assert torch.equal(res[1][1], res[0][1]), f"bf16={bf16}: select2 and the staged selection disagree at {torch.nonzero(res[1][1] != res[0][1]).flatten().tolist()}"
+        assert torch.allclose(res[1][0], res[0][0], rtol=2e-6, atol=1e-6)
+        if not bf16:
+            # float64 search with ties to the lowest row
+            d64 = torch.cdist(q.double(), bank.double())
+            best = d64.min(dim=1).values
+            lowest = torch.stack([torch.nonzero(d64[k] <= best[k] * (1 + 1e-12)).flatten()[0] for k in range(Q)])
+            got = res[1][1].long()
+            for k in range(Q):
+                # fp32 direct-form distances cannot separate rows 1e-6 apart beyond their own rounding: the winner must be AS NEAR as the
+                # float64 winner to fp32 accuracy, and where rows are identical it must be the lowest of them
+                assert d64[k, got[k]] <= best[k] * (1 + 1e-5) + 1e-6, (k, int(got[k]), float(d64[k, got[k]]), float(best[k]))
+            if dup == "identical":
+                assert torch.equal(got, lowest), (got.tolist(), lowest.tolist())
+                assert got[0].item() == 40 and got[2].item() == 40 and got[1].item() == int(crowd_b.min())
+
+
 @pytest.mark.parametrize("bf16", [False, True])
 def test_top_k_query_and_soft_blend(model, bf16):
     """BallTree.query(k > 1) semantics (optional): the k nearest rows, exact, distances ascending, ties to the
