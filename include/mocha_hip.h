@@ -105,6 +105,12 @@ int mocha_encode(mocha_ctx* ctx, const float* X, int B, float* encoded, float* c
                  const float* cnt_mean, const float* cnt_std, float* cnt_nm, void* stream);
 /* model.decoder(src_enc, cha_enc), model.py:62-68, net/transformer.py:90-121 (test_fullframework.py:301,455,465). */
 int mocha_decoder(mocha_ctx* ctx, const float* src_enc, const float* cha_enc, int B, float* out, void* stream);
+/* AdaIN's style constants of character features (net/transformer.py:98-107: AdaptiveAvgPool1d over the tokens, Linear 256->512,
+ * LeakyReLU(0.2), Linear 512->512, of EVERY decoder layer): gb (B, 512 * decoder_depth) = [gamma_0 | beta_0 | gamma_1 | beta_1 | ...] for
+ * cha_enc (B, 90, 256) - what model.decoder computes from its second argument before anything else, and what mocha_bank_set caches per
+ * bank entry ("bank_dec_cache").  In float64 from a float64 token mean, rounded to fp32 once, unless "style_f64" = 0. */
+int mocha_style_constants(mocha_ctx* ctx, const float* cha_enc, int B, float* gb, void* stream);
+
 /* model.to_mot(tokens), model.py:71-80 (test_fullframework.py:302,456,466). */
 int mocha_to_mot(mocha_ctx* ctx, const float* tokens, int B, float* Y, void* stream);
 /* Generator.forward(src_X, cha_X), model.py:82-106. */

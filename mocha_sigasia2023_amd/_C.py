@@ -44,6 +44,7 @@ SIGNATURES = {
     "mocha_encode": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mocha_decoder": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "mocha_to_mot": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "mocha_style_constants": (_i, [_vp, _vp, _i, _vp, _vp]),
     "mocha_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "mocha_forward_features": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mocha_bank_set": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),

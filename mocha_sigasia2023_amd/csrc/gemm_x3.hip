@@ -311,8 +311,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
                 if (FETCH_W && m < 11 * TM) { split_op(2 * m); split_op(2 * m + 1); }
                 if (FETCH_W && m == 10) write_row(0);
                 if (FETCH_W && TM == 2 && m == 21) write_row(1);
+            } else if (TM == 1) {                       // TN = 1, TM = 1 (round 5: the 64 x 64 tile of mid-size launches): 22 split instructions over 6 MFMAs
+                if (FETCH_W) {
+#pragma unroll
+                    for (int k = 4 * m; k < 4 * m + 4; ++k)
+                        if (k < 22) split_op(k);
+                }
+                if (FETCH_W && m == 5) write_row(0);
             } else {                                    // TN = 1, TM = 2: 44 split instructions over 11 of the 12 MFMAs
-                static_assert(TN == 2 || TM == 2, "the 64-wide tile is built for 128 rows");
                 if (FETCH_W && m < 11) { split_op(4 * m); split_op(4 * m + 1); split_op(4 * m + 2); split_op(4 * m + 3); }
                 if (FETCH_W && m == 5) write_row(0);
                 if (FETCH_W && m == 10) write_row(1);
@@ -778,6 +784,10 @@ hipError_t gemm_x3_init() {
     if (e == hipSuccess) e = x3_attr<true, false, 2, 1>();
     if (e == hipSuccess) e = x3_attr<false, true, 2, 1>();
     if (e == hipSuccess) e = x3_attr<true, true, 2, 1>();
+    if (e == hipSuccess) e = x3_attr<false, false, 1, 1>();
+    if (e == hipSuccess) e = x3_attr<true, false, 1, 1>();
+    if (e == hipSuccess) e = x3_attr<false, true, 1, 1>();
+    if (e == hipSuccess) e = x3_attr<true, true, 1, 1>();
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<false, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
@@ -791,6 +801,15 @@ hipError_t gemm_x3_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_gemm_x3p<true, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)x3_lds_bytes<2>());
     return e;
+}
+
+// Mid-size launches whose 64 x 128 tiles would still leave CU slots empty (fewer than p.tile64_below of them: 128 windows give 360 for
+// N = 256) take 64 x 64 tiles: twice the workgroups, each K step a quarter of the 128 x 128 tile's MFMAs - such a launch's time is one tile's
+// serial K loop, not the chip's throughput.  Option "gemm_tile64_below" (0 = never).
+static bool x3_tile64(const GemmParams& p) {
+    if (p.ksplit > 1 || p.N % 64 != 0 || !gemm_is_small(p)) return false;
+    const long long t64x128 = (long long)((p.M + 63) / 64) * ((p.N + 127) / 128);
+    return t64x128 < p.tile64_below;
 }
 
 // shapes this engine takes; everything else stays on the exact-f32 kernels
@@ -808,7 +827,8 @@ bool gemm_x3_supports(const GemmParams& p) {
         return (long long)total * XW_BLOCK * 2 < (1ll << 31);
     }
     if (p.N % 64 != 0) return false;
-    if (p.N % XN != 0 && gemm_is_small(p)) return false;    // N = 64 / 192 (to_mot's joint block): the 64-wide tile exists for large launches only
+    // N = 64 / 192 (to_mot's joint block): the 128 x 64 tile serves large launches, the 64 x 64 tile (round 5) the mid-size ones it is enabled for
+    if (p.N % XN != 0 && gemm_is_small(p) && !(p.N % 64 == 0 && x3_tile64(p))) return false;
     if (gemm_is_skinny(p)) return false;            // a handful of windows: latency-bound, mocha_gemm_skinny
     return true;
 }
@@ -856,7 +876,8 @@ hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s) {
 #undef X3P_LAUNCH
         return hipGetLastError();
     }
-    if (p.ksplit <= 1 && p.N % XN != 0) x3_launch<2, 1>(p, s);
+    if (x3_tile64(p)) x3_launch<1, 1>(p, s);
+    else if (p.ksplit <= 1 && p.N % XN != 0) x3_launch<2, 1>(p, s);
     else if (p.ksplit <= 1 && gemm_is_small(p)) x3_launch<1, 2>(p, s);
     else x3_launch<2, 2>(p, s);
     return hipGetLastError();

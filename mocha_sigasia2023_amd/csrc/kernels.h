@@ -41,6 +41,7 @@ struct GemmParams {
     // gemm_x3.hip, per context (options "gemm_persistent", "gemm_persistent_max_n"): workgroups of the persistent instance (0 = never; a
     // multiple of 8) and the widest launch, in columns, that takes it
     int persistent = 768, persistent_max_n = 512;
+    int tile64_below = 0;         // gemm_x3.hip: mid-size launches with fewer 64 x 128 tiles than this take 64 x 64 tiles (option "gemm_tile64_below")
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 bool gemm_is_narrow(const GemmParams& p);
@@ -204,7 +205,10 @@ hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S
 // variant: bits 0-3 register prefetch depth in 64-k stages (0 = default), bit 4 non-temporal bank loads, bit 8 fill only (measurement)
 int match_pass256_ksplit(int Q, int64_t N);
 hipError_t launch_match_pass256(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int variant = 0,
-                                int planes = 1);
+                                int planes = 1, const void* tiled32 = nullptr);
+// the bank in the pass's operand order (every wave-level load 1 KB contiguous): match_tile32_elems(N, D) bf16
+size_t match_tile32_elems(int64_t N, int D);
+hipError_t launch_tile32_bf16(const void* bank16, void* out, int64_t N, int D, hipStream_t s);
 size_t match_tiled_elems(int64_t N, int D);
 hipError_t launch_tile_bf16(const void* bank16, void* out, int64_t N, int D, hipStream_t s);
 hipError_t launch_match_select(const float* S, int ksplit, long long slab_stride, int lds, const float* bnorm, const float* query,

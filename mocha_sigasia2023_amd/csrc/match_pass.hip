@@ -31,6 +31,7 @@ struct MatchPassParams {
     const unsigned short* A; const unsigned short* B; float* S;
     int Q; long long N; int D; int ksplit; long long slab_stride; int m_tiles, n_tiles;
     long long a_plane;            // elements between the two stacked query planes (NPL == 2)
+    const unsigned short* Bt;     // TILED: the bank in operand order (mocha_tile32_bf16): [32-row tile][64-k stage][k16 step][lane] x 16 B
 };
 
 static constexpr int MP_Q = 128, MP_ROWS = 256, MP_BK = 64;
@@ -56,7 +57,9 @@ __device__ __forceinline__ void mp_wait_dyn(int k) {
 // NPL = 2: the queries come as TWO stacked bf16 planes (a = a0 + a1 to 16 significant bits; the selection's error bound shrinks by 2^8 and
 // with it the rows it must re-evaluate exactly: match_select2.hip).  The second plane doubles the ring's stages and the MFMAs, not the
 // bank bytes - and here, unlike in round 4's kernel, the ring does not hold the bank.
-template <int PFS, bool NT, bool FILL_ONLY, int NPL>
+// TILED: the bank operands come from an image in which every wave-level load is 1 KB of contiguous memory (row-major rows give 32 pieces
+// of 32 B, 46 KB apart, per load)
+template <int PFS, bool NT, bool FILL_ONLY, int NPL, bool TILED>
 __global__ __launch_bounds__(512) void mocha_match_pass256(MatchPassParams p) {
     constexpr int R = PFS + 1;
     constexpr int OPS = 2 * NPL + 4;                                                  // vector-memory operations per wave and stage
@@ -96,7 +99,9 @@ __global__ __launch_bounds__(512) void mocha_match_pass256(MatchPassParams p) {
             a_off[i] = ((unsigned)(ra - m0) * (unsigned)p.D + c * 8u) * 2u;
         }
         long long rb = n0 + 32 * wave + l31; rb = rb < p.N ? rb : p.N - 1;
-        const u32x4* bp = reinterpret_cast<const u32x4*>(p.B + (size_t)rb * p.D + (size_t)s_begin * MP_BK + 8 * hh);      // stage s, k16 step ks: bp[8 s + 2 ks]
+        const u32x4* bp = TILED ? reinterpret_cast<const u32x4*>(p.Bt) + ((size_t)(nt * 8 + wave) * steps_total + s_begin) * 256 + lane      // stage s, step ks: bp[(4 s + ks) 64]
+                                : reinterpret_cast<const u32x4*>(p.B + (size_t)rb * p.D + (size_t)s_begin * MP_BK + 8 * hh);      // stage s, k16 step ks: bp[8 s + 2 ks]
+        constexpr int BS = TILED ? 256 : 8, BK = TILED ? 64 : 2;
         unsigned ra_off[4], key_a[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const int r_a = i * 32 + l31; ra_off[i] = (unsigned)r_a * 64u; key_a[i] = (unsigned)((r_a >> 1) & 7); }
@@ -111,7 +116,7 @@ __global__ __launch_bounds__(512) void mocha_match_pass256(MatchPassParams p) {
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (__attribute__((address_space(3))) void*)(st + MP_Q * MP_BK + (wave + 8 * i) * 512), 16, a_off[i], so, 0, 0);
             }
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) breg[ks] = NT ? __builtin_nontemporal_load(bp + 8 * s + 2 * ks) : bp[8 * s + 2 * ks];
+            for (int ks = 0; ks < 4; ++ks) breg[ks] = NT ? __builtin_nontemporal_load(bp + BS * s + BK * ks) : bp[BS * s + BK * ks];
         };
         auto compute = [&](int s, const u32x4 (&breg)[4]) __attribute__((always_inline)) {
             const unsigned short* st = mp_sm + (s % R) * STAGE;
@@ -208,22 +213,47 @@ int match_pass256_ksplit(int Q, int64_t N) {
     return k;
 }
 
-template <int PFS, bool NT, bool FILL, int NPL>
-static hipError_t mp_launch(const MatchPassParams& p, unsigned grid, hipStream_t s) {
+template <int PFS, bool NT, bool FILL, int NPL, bool TILED>
+static hipError_t mp_launch2(const MatchPassParams& p, unsigned grid, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_pass256<PFS, NT, FILL, NPL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_pass256<PFS, NT, FILL, NPL, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)mp_lds_bytes<PFS, NPL>());
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL((mocha_match_pass256<PFS, NT, FILL, NPL>), dim3(grid), dim3(512), (mp_lds_bytes<PFS, NPL>()), s, p);
+    hipLaunchKernelGGL((mocha_match_pass256<PFS, NT, FILL, NPL, TILED>), dim3(grid), dim3(512), (mp_lds_bytes<PFS, NPL>()), s, p);
+    return hipGetLastError();
+}
+template <int PFS, bool NT, bool FILL, int NPL>
+static hipError_t mp_launch(const MatchPassParams& p, unsigned grid, hipStream_t s) {
+    return p.Bt ? mp_launch2<PFS, NT, FILL, NPL, true>(p, grid, s) : mp_launch2<PFS, NT, FILL, NPL, false>(p, grid, s);
+}
+
+// bank16 (N, D) bf16 row-major -> the pass's operand-order image: block (32-row tile, 64-k stage) = 4 k16 steps x 64 lanes x 16 B; rows past N
+// repeat the last row.  One 256-thread workgroup per block.
+__global__ __launch_bounds__(256) void mocha_tile32_bf16(const unsigned short* __restrict__ bank16, unsigned short* __restrict__ out, long long N, int D) {
+    const int stages = D / MP_BK;
+    const long long rt = blockIdx.x / stages; const int st = (int)(blockIdx.x - rt * stages);
+    const int ks = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    long long row = rt * 32 + (lane & 31); row = row < N ? row : N - 1;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(bank16 + (size_t)row * D + st * MP_BK + ks * 16 + 8 * (lane >> 5));
+    reinterpret_cast<u32x4*>(out)[(size_t)blockIdx.x * 256 + threadIdx.x] = v;
+}
+size_t match_tile32_elems(int64_t N, int D) { return (size_t)((N + 255) / 256) * 256 * (size_t)D; }       // whole 256-row workgroup tiles
+hipError_t launch_tile32_bf16(const void* bank16, void* out, int64_t N, int D, hipStream_t s) {
+    if (N <= 0) return hipSuccess;
+    if (D % MP_BK) return hipErrorInvalidValue;
+    const long long blocks = (long long)((N + 255) / 256) * 8 * (D / MP_BK);
+    if (blocks > 0x7fffffffll) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_tile32_bf16, dim3((unsigned)blocks), dim3(256), 0, s, (const unsigned short*)bank16, (unsigned short*)out, (long long)N, D);
     return hipGetLastError();
 }
 
 // variant: bits 0-3 = PFS (one plane 3 .. 6, default 5; two planes 2 .. 4, default 3), bit 4 = non-temporal bank loads, bit 8 = fill only
 // (measurement: S is garbage).  planes = 2: qc16 holds two stacked planes, plane 1 starts Q * D elements after plane 0.
-hipError_t launch_match_pass256(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int variant, int planes) {
+hipError_t launch_match_pass256(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int variant, int planes,
+                                const void* tiled32) {
     if (Q <= 0 || N <= 0) return hipSuccess;
     if (D % MP_BK || ksplit < 1 || ksplit > 16 || (ksplit & (ksplit - 1)) || (planes != 1 && planes != 2)) return hipErrorInvalidValue;
     if ((long long)MP_Q * D * 2 >= (1ll << 31)) return hipErrorInvalidValue;              // 32-bit buffer offsets inside a query tile
@@ -232,6 +262,7 @@ hipError_t launch_match_pass256(const void* qc16, const void* bank16, float* S, 
     p.Q = Q; p.N = N; p.D = D; p.ksplit = ksplit; p.slab_stride = (long long)Q * N;
     p.m_tiles = (Q + MP_Q - 1) / MP_Q; p.n_tiles = (int)((N + MP_ROWS - 1) / MP_ROWS);
     p.a_plane = (long long)Q * D;
+    p.Bt = (const unsigned short*)tiled32;
     const long long pairs = (long long)p.n_tiles * ksplit;
     const unsigned grid = (unsigned)(((pairs + 7) / 8) * p.m_tiles * 8);
     const int pfs = (variant & 15) ? (variant & 15) : (planes == 2 ? 3 : 5);

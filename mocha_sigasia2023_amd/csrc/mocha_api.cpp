@@ -163,6 +163,7 @@ struct mocha_ctx {
     double* style_scratch = nullptr; size_t style_scratch_rows = 0;     // float64 token means + hidden activations of the style MLP, bank build
     // launch tuning, per context (round 4 kept these as process-wide globals: a second context, or another host thread, changed them underfoot)
     int inorm_split_max = 1 << 30, embed_max_wgs = 512, gemm_persistent = 768, gemm_persistent_max_n = 512; bool embed_sums = true;
+    int gemm_tile64_below = 640;       // plane GEMM: 64 x 64 tiles for mid-size launches with fewer 64 x 128 tiles than this (gemm_x3.hip)
     bool adain_closed = true;          // mocha_adain: qin from the first statistics in closed form (pointwise.hip); 0 = the literal two-pass order
     bool style_f64 = true;             // the style MLP in float64 (mocha_linear_f64); 0 = the fp32 GEMM engines
     std::map<std::string, double*> w64;                     // float64 copies of the style MLP's weights
@@ -472,7 +473,8 @@ void x3_drop_images(mocha_ctx* c) {
     c->x3w.clear();
 }
 
-int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
+int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p0) {
+    GemmParams p = p0; p.tile64_below = c->gemm_tile64_below; p.persistent = c->gemm_persistent; p.persistent_max_n = c->gemm_persistent_max_n;
     const double flops = 2.0 * p.M * (double)p.N * p.K;
     // algorithmic bytes: every operand once - activations, weights, the output, and the residual matrix where the epilogue adds one
     const double bytes = 4.0 * ((double)p.M * p.K / (p.gather ? p.ntaps : 1) * (p.R) + (double)p.N * p.K + (double)p.M * p.N * p.ksplit +
@@ -482,7 +484,7 @@ int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p) {
         int rc = x3_image(c, s, p, &img);
         if (rc) return rc;
         if (img) {
-            GemmParams q = p; q.Wsplit = img; q.persistent = c->gemm_persistent; q.persistent_max_n = c->gemm_persistent_max_n;
+            GemmParams q = p; q.Wsplit = img;
             LAUNCH(c, s, "mocha_gemm_x3", site, flops, bytes, launch_gemm_x3(q, s));
             return 0;
         }
@@ -628,6 +630,31 @@ int run_style_f64(mocha_ctx* c, const double* mean64, double* hidden, float* gb,
     return 0;
 }
 
+// style MLPs of every layer at once for the b windows whose token means the instance norm left in the workspace ("smean" fp32,
+// "smean64" float64): Linear 256->512, LeakyReLU, Linear 512->512 per layer -> "gb" (b, 512 L)          net/transformer.py:102-107
+int run_style(mocha_ctx* c, int b, hipStream_t s) {
+    const int L = c->cfg.dec_depth;
+    if (c->style_f64)
+        return run_style_f64(c, reinterpret_cast<const double*>(WS(c, "smean64")), reinterpret_cast<double*>(WS(c, "s1d")), WS(c, "gb"), b, s);
+    GemmParams s1 = plain(WS(c, "smean"), 256, DW(c, "dec.Ws1_all"), WS(c, "s1"), 512 * L, b, 512 * L, 256);
+    s1.bias = DW(c, "dec.bs1_all"); s1.act = 2;
+    GEMM(c, s, "dec.style1", s1);
+    if (b <= 192 || L == 1) {
+        // a handful of windows: launch count matters, the block-diagonal matrix's zero half does not
+        GemmParams s2 = plain(WS(c, "s1"), 512 * L, DW(c, "dec.Ws2_blk"), WS(c, "gb"), 512 * L, b, 512 * L, 512 * L);
+        s2.bias = DW(c, "dec.bs2_all");
+        GEMM(c, s, "dec.style2", s2);
+    } else {
+        for (int l = 0; l < L; ++l) {                     // large batches: layer l's 512 x 512 on its own slice of the hidden activations
+            const std::string p = "dec" + std::to_string(l);
+            GemmParams s2 = plain(WS(c, "s1") + (size_t)l * 512, 512 * L, DW(c, p + ".Ws2"), WS(c, "gb") + (size_t)l * 512, 512 * L, b, 512, 512);
+            s2.bias = DW(c, p + ".bs2");
+            GEMM(c, s, "dec.style2", s2);
+        }
+    }
+    return 0;
+}
+
 // can the decoder read a bank entry's constants (IN(cha), gamma / beta) in place through frame_index?  (the folded decoder on the plane
 // attention kernel; the image variant and the un-folded projections want contiguous per-window copies)
 bool dec_cache_ok(const mocha_ctx* c) {
@@ -673,28 +700,8 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
         LAUNCH(c, s, "mocha_instnorm", "dec.in_cha", 0.0, b * (90.0 * 256 * 4 + wr),
                launch_instnorm(gather_table ? gather_table : cha, use_kv ? nullptr : WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s, &ex));
         if (gather_table) cha = use_kv ? nullptr : WS(c, "sel");
-        // style MLPs of every layer at once: Linear 256->512, LeakyReLU, Linear 512->512 per layer          net/transformer.py:102-107
-        if (c->style_f64) {
-            int rc = run_style_f64(c, reinterpret_cast<const double*>(WS(c, "smean64")), reinterpret_cast<double*>(WS(c, "s1d")), WS(c, "gb"), b, s);
-            if (rc) return rc;
-        } else {
-            GemmParams s1 = plain(WS(c, "smean"), 256, DW(c, "dec.Ws1_all"), WS(c, "s1"), 512 * L, b, 512 * L, 256);
-            s1.bias = DW(c, "dec.bs1_all"); s1.act = 2;
-            GEMM(c, s, "dec.style1", s1);
-            if (b <= 192 || L == 1) {
-                // a handful of windows: launch count matters, the block-diagonal matrix's zero half does not
-                GemmParams s2 = plain(WS(c, "s1"), 512 * L, DW(c, "dec.Ws2_blk"), WS(c, "gb"), 512 * L, b, 512 * L, 512 * L);
-                s2.bias = DW(c, "dec.bs2_all");
-                GEMM(c, s, "dec.style2", s2);
-            } else {
-                for (int l = 0; l < L; ++l) {                     // large batches: layer l's 512 x 512 on its own slice of the hidden activations
-                    const std::string p = "dec" + std::to_string(l);
-                    GemmParams s2 = plain(WS(c, "s1") + (size_t)l * 512, 512 * L, DW(c, p + ".Ws2"), WS(c, "gb") + (size_t)l * 512, 512 * L, b, 512, 512);
-                    s2.bias = DW(c, p + ".bs2");
-                    GEMM(c, s, "dec.style2", s2);
-                }
-            }
-        }
+        int rc = run_style(c, b, s);
+        if (rc) return rc;
     }
     const float* gbp = cached ? gb_table : WS(c, "gb");
     const float* x = src;
@@ -1421,6 +1428,22 @@ int mocha_decoder(mocha_ctx* c, const float* src_enc, const float* cha_enc, int 
     const size_t ts = 90 * 256;
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         return run_decoder(c, src_enc + b0 * ts, cha_enc + b0 * ts, b, out + b0 * ts, s);
+    });
+}
+
+int mocha_style_constants(mocha_ctx* c, const float* cha_enc, int B, float* gb, void* stream) {
+    int rc = ready(c, B); if (rc) return rc;
+    NEED_PTRS(c, B, "mocha_style_constants", cha_enc, gb);
+    const size_t T = 90 * 256, G = (size_t)512 * c->cfg.dec_depth;
+    return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
+        InormExtra ex = IEX(c);
+        if (c->style_f64) ex.mean64 = reinterpret_cast<double*>(WS(c, "smean64"));
+        LAUNCH(c, s, "mocha_instnorm", "dec.in_cha", 0.0, b * 90.0 * 256 * 4 * 2,
+               launch_instnorm(cha_enc + b0 * T, WS(c, "kin"), WS(c, "smean"), nullptr, nullptr, nullptr, b, 90, s, &ex));
+        int r = run_style(c, b, s);
+        if (r) return r;
+        HIPCHK(c, hipMemcpyAsync(gb + b0 * G, WS(c, "gb"), (size_t)b * G * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
     });
 }
 
@@ -2353,6 +2376,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "scan16") { c->scan16 = value != 0; c->generation++; return 0; }             // bank side takes effect at the next mocha_bank_set
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only
     if (n == "gemm_persistent_max_n") { c->gemm_persistent_max_n = value < 128 ? 128 : value; c->generation++; return 0; }
+    if (n == "gemm_tile64_below") { c->gemm_tile64_below = value < 0 ? 0 : value; c->generation++; return 0; }
     if (n == "gemm_persistent") { c->gemm_persistent = value < 0 ? 0 : (value + 7) / 8 * 8; c->generation++; return 0; }
     if (n == "embed_sums") { c->embed_sums = value != 0; c->generation++; return 0; }
     if (n == "embed_front_max_wgs") { c->embed_max_wgs = value; c->generation++; return 0; }

@@ -839,18 +839,26 @@ __global__ __launch_bounds__(256) void mocha_linear_f64(const double* __restrict
     const double* Wl = W + (size_t)l * N * K;
     double acc[4][4] = {};
     const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 8;          // loader: row / column lr of the tile, 8 consecutive k
-    for (int k0 = 0; k0 < K; k0 += KT) {
-        double xr[8], wr[8];
-        const int xrow = r0 + lr;
+    // rows / columns past the edge read the last valid one (their products are never stored): no predicated loads in the loop
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const int xrow = (r0 + lr) < M ? (r0 + lr) : M - 1, wrow = (n0 + lr) < N ? (n0 + lr) : N - 1;
+    const f64x2* xp = reinterpret_cast<const f64x2*>(Xl + (size_t)xrow * ldx + lk);
+    const f64x2* wp = reinterpret_cast<const f64x2*>(Wl + (size_t)wrow * K + lk);
+    f64x2 xr[4], wr[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            xr[i] = (xrow < M) ? Xl[(size_t)xrow * ldx + k0 + lk + i] : 0.0;
-            wr[i] = (n0 + lr < N) ? Wl[(size_t)(n0 + lr) * K + k0 + lk + i] : 0.0;
+    for (int i = 0; i < 4; ++i) { xr[i] = xp[i]; wr[i] = wp[i]; }
+    for (int k0 = 0; k0 < K; k0 += KT) {
+        __syncthreads();                                                  // the previous tile has been read
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Xs[lk + 2 * i][lr] = xr[i][0]; Xs[lk + 2 * i + 1][lr] = xr[i][1];
+            Ws[lk + 2 * i][lr] = wr[i][0]; Ws[lk + 2 * i + 1][lr] = wr[i][1];
         }
         __syncthreads();
+        if (k0 + KT < K) {                                                // the next tile's operands travel while this one is multiplied
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { Xs[lk + i][lr] = xr[i]; Ws[lk + i][lr] = wr[i]; }
-        __syncthreads();
+            for (int i = 0; i < 4; ++i) { xr[i] = xp[(k0 + KT) / 2 + i]; wr[i] = wp[(k0 + KT) / 2 + i]; }
+        }
 #pragma unroll 8
         for (int kk = 0; kk < KT; ++kk) {
             double xa[4], wb[4];
@@ -881,7 +889,7 @@ __global__ __launch_bounds__(256) void mocha_linear_f64(const double* __restrict
 hipError_t launch_linear_f64(const double* X, int ldx, int xcol, const double* W, const double* bias, double* y64, float* y32, int ldy,
                              int M, int N, int K, int L, int act, hipStream_t s) {
     if (M <= 0) return hipSuccess;
-    if (N < 1 || K < 32 || (K & 31) || L < 1 || (act != 0 && act != 2) || (!y64 && !y32)) return hipErrorInvalidValue;
+    if (N < 1 || K < 32 || (K & 31) || L < 1 || (act != 0 && act != 2) || (!y64 && !y32) || (ldx & 1) || (xcol & 1)) return hipErrorInvalidValue;      // 16-byte row loads
     const dim3 grid((N + 63) / 64, (M + 63) / 64, L);
     if (act == 2) hipLaunchKernelGGL(mocha_linear_f64<2>, grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);
     else hipLaunchKernelGGL(mocha_linear_f64<0>, grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);

@@ -264,6 +264,16 @@ class Generator:
         self._ctx.call("mocha_decoder", _ptr(s), _ptr(c), s.shape[0], _ptr(out), _stream())
         return out
 
+    def style_constants(self, cha_encoded):
+        """AdaIN's gamma / beta of every decoder layer for character features (net/transformer.py:98-107: token mean -> Linear ->
+        LeakyReLU -> Linear), (B, 512 * decoder_depth) = [gamma_0 | beta_0 | gamma_1 | beta_1 ...] - what ``decoder`` derives from its
+        second argument first, and what a bank caches per entry."""
+        self._need()
+        c = self._tok(cha_encoded, "cha_encoded")
+        out = torch.empty((c.shape[0], 512 * int(self.cfg["decoder_depth"])), dtype=torch.float32, device=self.device)
+        self._ctx.call("mocha_style_constants", _ptr(c), c.shape[0], _ptr(out), _stream())
+        return out
+
     def to_mot(self, tokens):                        # model.py:71-80
         self._need()
         tokens = self._tok(tokens, "tokens")

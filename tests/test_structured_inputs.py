@@ -8,11 +8,14 @@ in a capture is a 30-50 sigma spike; and a character can be matched against itse
 
 Tolerance (north star): |Y - Y_oracle| < 1e-4 absolute, nearest-neighbour indices equal with ties judged in float64 on the
 oracle's own features.  Where the fp32 arithmetic itself cannot deliver 1e-4 - the oracle run in float64 on the same inputs says
-how far the fp32 ORACLE is from the exact result - the HIP path is held to four times the fp32 oracle's own error instead,
-and the test prints both (pytest -s) so the numbers land in profiles/.  Why a factor and not equality: on such inputs the decoder is
-ill-conditioned and either fp32 evaluation is a sample of rounding noise - fed the float64 oracle's own encoder features, the fp32
-ORACLE's decoder is 1.8e-2 from float64 on the 'outliers in both' case and the HIP decoder 1.1e-2; end to end the two land between
-7e-4 and 2.4e-3 depending on which engine rounds where (tools/outlier_diag.py, profiles/r04/a_outlier_diag.txt).
+how far the fp32 ORACLE is from the exact result, and two fp32 runs of the reference (another batch size, another thread count) differ
+from EACH OTHER by up to 2e-3 on such inputs (profiles/r05/a_reference_self_consistency.txt) - the HIP path is held to float64 instead:
+|hip - f64| <= max(1e-4 max(1, max|Y|), 2 |oracle32 - f64|), the per-row bound the round-5 matrix supports (tests/test_structured_matrix.py,
+profiles/r05/a_structured_matrix.txt: worst ratio 1.49 over 240 rows; round 4's factor was 4 and its arithmetic reached 5.0).  The test prints
+all three distances (pytest -s) so the numbers land in profiles/.  Why the decoder is ill-conditioned here: AdaIN's gain 1 + gamma is near
+zero in some channel, and the instance norm that follows divides every earlier rounding by it (tools/precision_study.py); round 5 evaluates
+that pair in closed form and the style MLP in float64, which is why the HIP path is now CLOSER to float64 than the fp32 reference arithmetic
+in most rows.
 """
 import numpy as np
 import pytest
@@ -75,15 +78,16 @@ def _ties_ok(ours, best, q64, k64, rtol=1e-6):
 
 def _check_Y(name, Y_hip, Y32, Y64):
     """|Y - oracle| < 1e-4 absolute; if the fp32 oracle itself is further than that from the float64 result, the HIP path may be up
-    to four times as far from float64 as the fp32 oracle is (and must still be finite)."""
+    to twice as far from float64 as the fp32 oracle is (and must still be finite)."""
     Yh = Y_hip.detach().cpu().numpy().astype(np.float64)
     e_ho = float(np.abs(Yh - Y32.numpy()).max())
     e_h64 = float(np.abs(Yh - Y64.numpy()).max())
     e_o64 = float(np.abs(Y32.numpy().astype(np.float64) - Y64.numpy()).max())
-    print(f"[structured] {name}: max|Y| = {float(np.abs(Y64.numpy()).max()):.3g}   |hip - oracle32| = {e_ho:.2e}   "
+    scale = max(1.0, float(np.abs(Y64.numpy()).max()))
+    print(f"[structured] {name}: max|Y| = {scale:.3g}   |hip - oracle32| = {e_ho:.2e}   "
           f"|hip - f64| = {e_h64:.2e}   |oracle32 - f64| = {e_o64:.2e}")
     assert np.isfinite(Yh).all(), name
-    assert e_ho < TOL or e_h64 <= max(TOL, 4.0 * e_o64), f"{name}: |hip - oracle| = {e_ho:.3e}, |hip - f64| = {e_h64:.3e}, |oracle - f64| = {e_o64:.3e}"
+    assert e_ho < TOL or e_h64 <= max(TOL * scale, 2.0 * e_o64), f"{name}: |hip - oracle| = {e_ho:.3e}, |hip - f64| = {e_h64:.3e}, |oracle - f64| = {e_o64:.3e}"
     return e_ho, e_h64, e_o64
 
 
