@@ -39,6 +39,10 @@
  *     tools/isa_lint.py additionally keeps the one pattern that failed (low result from the HIGH register of a VGPR pair) out
  *     of the library's device code.  If foreign kernels must overlap with the library's calls and may contain that pattern,
  *     order them after the library's stream, or run with mocha_set_option "gemm_bf16x3" = 0 and "attention_bf16x3" = 0.
+ *     Scope of this statement: ONE builder-written reproduction, observed on the boxes of this build's GPU pool - MI355X (gfx950:sramecc+:xnack-),
+ *     kernel driver 6.18.51, ROCm runtime 7.0.2 (HIP 7.0.51831), code objects built with hipcc 7.2.26015, VBIOS 113-M355-01-1K1-020F,
+ *     firmware MEC 44 / RLC 43 / SDMA 14 / SMC 04.86.15.106 (profiles/r05/c_versions.txt) - not a vendor erratum and not re-checked
+ *     on any other driver / firmware; the canary test re-measures it on whatever box runs the GPU suite.
  */
 #ifndef MOCHA_HIP_H
 #define MOCHA_HIP_H

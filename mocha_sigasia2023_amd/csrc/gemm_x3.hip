@@ -803,11 +803,16 @@ hipError_t gemm_x3_init() {
     return e;
 }
 
-// Mid-size launches whose 64 x 128 tiles would still leave CU slots empty (fewer than p.tile64_below of them: 128 windows give 360 for
-// N = 256) take 64 x 64 tiles: twice the workgroups, each K step a quarter of the 128 x 128 tile's MFMAs - such a launch's time is one tile's
-// serial K loop, not the chip's throughput.  Option "gemm_tile64_below" (0 = never).
+// The 64 x 64 tile (round 5): four waves of 32 x 32, six MFMAs per wave and K step.
+//  * mid-size launches whose width is a multiple of 64 but not of 128 (to_mot's joint block, N = 192, at a few dozen to a few hundred
+//    windows) take it ALWAYS: their alternative was the exact-f32 engine (128 windows: 18.7 -> 13.4 us);
+//  * mid-size launches of 128-multiples take it when they have fewer 64 x 128 tiles than p.tile64_below (option "gemm_tile64_below",
+//    default 0 = never): measured NO gain - 128 windows, N = 256: K = 512 26.8 -> 27.5 us, K = 1024 47.2 -> 49.6 us; the whole 128-window
+//    step 1.116 -> 1.150 ms (profiles/r05/c_tile64.txt) - a mid-size launch's time is its tiles' serial K loop, and a K step's floor
+//    (barrier, LDS round trip, the activation split) does not shrink with the tile.
 static bool x3_tile64(const GemmParams& p) {
     if (p.ksplit > 1 || p.N % 64 != 0 || !gemm_is_small(p)) return false;
+    if (p.N % XN != 0) return true;
     const long long t64x128 = (long long)((p.M + 63) / 64) * ((p.N + 127) / 128);
     return t64x128 < p.tile64_below;
 }
@@ -828,7 +833,7 @@ bool gemm_x3_supports(const GemmParams& p) {
     }
     if (p.N % 64 != 0) return false;
     // N = 64 / 192 (to_mot's joint block): the 128 x 64 tile serves large launches, the 64 x 64 tile (round 5) the mid-size ones it is enabled for
-    if (p.N % XN != 0 && gemm_is_small(p) && !(p.N % 64 == 0 && x3_tile64(p))) return false;
+    if (p.N % XN != 0 && gemm_is_small(p) && !x3_tile64(p)) return false;
     if (gemm_is_skinny(p)) return false;            // a handful of windows: latency-bound, mocha_gemm_skinny
     return true;
 }

@@ -74,7 +74,9 @@ static constexpr int MG_BM = 128, MG_BN = 128, MG_BK = 64;
 // pass is HBM-bound on the bank (a step's 36 - 48 KB arrive in ~0.8 us, its 16 / 32 MFMAs per wave take 0.25 / 0.5 us), so the second plane
 // costs LDS (a stage grows from 32 to 48 KB: ring of 3) and 6 MB of query traffic, not time - and shrinks the selection's error bound, and
 // with it the rows that must be re-evaluated exactly, by 2^8.
-template <int R, int NPL>
+// NTB (round 5): the bank's LDS-DMA loads carry the non-temporal hint (aux = 2): read once - with caches full of other kernels' dirty lines
+// (the state inside mocha_characterize) they do not wait for write-backs they do not need (tools/match_pass_probe.hip)
+template <int R, int NPL, bool NTB>
 __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short mg_sm[];          // [R][NPL * BM + BN][64]
     constexpr int STAGE = (NPL * MG_BM + MG_BN) * MG_BK;                             // bf16 per stage
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(st + (wave + 4 * i) * 512), 16, a_off[i], so, 0, 0);
             if (NPL == 2)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA1, (__attribute__((address_space(3))) void*)(st + MG_BM * MG_BK + (wave + 4 * i) * 512), 16, a_off[i], so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + NPL * MG_BM * MG_BK + (wave + 4 * i) * 512), 16, b_off[i], sob, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (__attribute__((address_space(3))) void*)(st + NPL * MG_BM * MG_BK + (wave + 4 * i) * 512), 16, b_off[i], sob, 0, NTB ? 2 : 0);
         }
     };
 
@@ -209,8 +211,10 @@ hipError_t match_select_init();
 
 hipError_t match_mfma_init() {
     constexpr size_t lds2 = mg_dma_lds_bytes<3, 2>(), lds1 = mg_dma_lds_bytes<4, 1>();
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_gemm_bf16_dma<4, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_gemm_bf16_dma<3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_gemm_bf16_dma<4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_gemm_bf16_dma<4, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_gemm_bf16_dma<3, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    if (r == hipSuccess) r = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_gemm_bf16_dma<3, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     if (r == hipSuccess) r = match_select_init();
     return r;
 }
@@ -253,7 +257,8 @@ hipError_t launch_tile_bf16(const void* bank16, void* out, int64_t N, int D, hip
     return hipGetLastError();
 }
 
-hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes, const void* tiled) {
+hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes, const void* tiled,
+                                  int nt_bank) {
     if (Q <= 0 || N <= 0) return hipSuccess;
     if (D % MG_BK || (ksplit != 1 && ksplit != 2 && ksplit != 4 && ksplit != 8)) return hipErrorInvalidValue;
     if ((long long)MG_BM * D * 2 >= (1ll << 31)) return hipErrorInvalidValue;            // 32-bit buffer offsets inside a tile
@@ -271,8 +276,14 @@ hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S
     // through registers with ds_write (tools/experiments/README.md)
     // two query planes: stages of 48 KB, ring of 3 (two steps = 96 KB in flight, as before)
     constexpr size_t lds2 = mg_dma_lds_bytes<3, 2>(), lds1 = mg_dma_lds_bytes<4, 1>();
-    if (planes == 2) hipLaunchKernelGGL((mocha_match_gemm_bf16_dma<3, 2>), dim3((unsigned)(groups * p.m_tiles * 8)), dim3(256), lds2, s, p);
-    else hipLaunchKernelGGL((mocha_match_gemm_bf16_dma<4, 1>), dim3((unsigned)(groups * p.m_tiles * 8)), dim3(256), lds1, s, p);
+    const dim3 grid((unsigned)(groups * p.m_tiles * 8));
+    if (planes == 2) {
+        if (nt_bank) hipLaunchKernelGGL((mocha_match_gemm_bf16_dma<3, 2, true>), grid, dim3(256), lds2, s, p);
+        else hipLaunchKernelGGL((mocha_match_gemm_bf16_dma<3, 2, false>), grid, dim3(256), lds2, s, p);
+    } else {
+        if (nt_bank) hipLaunchKernelGGL((mocha_match_gemm_bf16_dma<4, 1, true>), grid, dim3(256), lds1, s, p);
+        else hipLaunchKernelGGL((mocha_match_gemm_bf16_dma<4, 1, false>), grid, dim3(256), lds1, s, p);
+    }
     return hipGetLastError();
 }
 

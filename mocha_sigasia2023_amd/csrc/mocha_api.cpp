@@ -163,7 +163,7 @@ struct mocha_ctx {
     double* style_scratch = nullptr; size_t style_scratch_rows = 0;     // float64 token means + hidden activations of the style MLP, bank build
     // launch tuning, per context (round 4 kept these as process-wide globals: a second context, or another host thread, changed them underfoot)
     int inorm_split_max = 1 << 30, embed_max_wgs = 512, gemm_persistent = 768, gemm_persistent_max_n = 512; bool embed_sums = true;
-    int gemm_tile64_below = 640;       // plane GEMM: 64 x 64 tiles for mid-size launches with fewer 64 x 128 tiles than this (gemm_x3.hip)
+    int gemm_tile64_below = 0;         // plane GEMM: 64 x 64 tiles for mid-size 128-multiple launches with fewer 64 x 128 tiles than this (measured: no gain; gemm_x3.hip)
     bool adain_closed = true;          // mocha_adain: qin from the first statistics in closed form (pointwise.hip); 0 = the literal two-pass order
     bool style_f64 = true;             // the style MLP in float64 (mocha_linear_f64); 0 = the fp32 GEMM engines
     std::map<std::string, double*> w64;                     // float64 copies of the style MLP's weights
@@ -208,7 +208,11 @@ struct mocha_ctx {
     int match_planes = 1;              // bf16 query planes of the many-query coarse pass against a bf16 bank
     // round 5: the one-plane coarse pass as mocha_match_pass256 (match_pass.hip: 256-row tiles, bank operands straight into registers) for
     // up to match_pass_max_q queries; 0 = round 4's mocha_match_gemm_bf16_dma.  match_pass_variant: launch_match_pass256's variant bits.
-    int match_pass = 1, match_pass_variant = 0, match_pass_max_q = 256;
+    int match_pass = 0, match_pass_variant = 0, match_pass_max_q = 256;
+    // match_pass = 2: mocha_match_pass256 reading the bank from its operand-order image (every wave-level load 1 KB contiguous), built at
+    // the first such match (+ 2 B per bank value); match_nt: round 4's kernel with non-temporal bank loads
+    void* bank_tile32 = nullptr; size_t bank_tile32_cap = 0; bool bank_tile32_valid = false;
+    int match_nt = 1;                  // applied to launches with ONE query tile (Q <= 128): the bank is then read exactly once per launch
     DevBuf match_qstat[MAX_SETS];
 
     // captured per-window step (mocha_step_graph): one executable graph, re-captured when its key changes
@@ -983,12 +987,28 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
             }
             tiled = c->bank_tiled;
         }
-        if (pass256)
+        if (pass256) {
+            const void* t32 = nullptr;
+            if (c->match_pass == 2 && (size_t)N * D * 2 <= ((size_t)4 << 30)) {
+                const size_t need = match_tile32_elems(N, D);
+                if (!c->bank_tile32_valid) {
+                    if (c->bank_tile32_cap < need) {
+                        HIPCHK(c, hipDeviceSynchronize());
+                        if (c->bank_tile32) (void)hipFree(c->bank_tile32);
+                        c->bank_tile32 = nullptr; c->bank_tile32_cap = 0;
+                        HIPCHK(c, hipMalloc(&c->bank_tile32, need * 2));
+                        c->bank_tile32_cap = need;
+                    }
+                    LAUNCH(c, s, "mocha_tile32_bf16", "bank.tile32", 0.0, 4.0 * N * D, launch_tile32_bf16(c->bank_bf16, c->bank_tile32, N, D, s));
+                    c->bank_tile32_valid = true;
+                }
+                t32 = c->bank_tile32;
+            }
             LAUNCH(c, s, "mocha_match_pass256", "match.qk_bf16", 2.0 * npl * Q * (double)N * D, 2.0 * npl * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
-                   launch_match_pass256(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, c->match_pass_variant, npl));
-        else
+                   launch_match_pass256(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, c->match_pass_variant, npl, t32));
+        } else
         LAUNCH(c, s, "mocha_match_gemm_bf16", "match.qk_bf16", 2.0 * npl * Q * (double)N * D, 2.0 * npl * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
-               launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, npl, tiled));
+               launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, npl, tiled, (c->match_nt && Q <= 128) ? 1 : 0));
         if (sel2)
             LAUNCH(c, s, "mocha_match_select2", "match.select", 0.0, 4.0 * ksplit * Q * N + 4.0 * N + 8.0 * Q,
                    launch_match_select2(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, nullptr, c->bank_bf16,
@@ -1096,6 +1116,7 @@ void mocha_destroy(mocha_ctx* c) {
     for (int set = 0; set < mocha_ctx::MAX_SETS; ++set) { if (c->idx_ws[set]) (void)hipFree(c->idx_ws[set]); if (c->best_ws[set]) (void)hipFree(c->best_ws[set]); }
     if (c->bank_bf16) (void)hipFree(c->bank_bf16);
     if (c->bank_tiled) (void)hipFree(c->bank_tiled);
+    if (c->bank_tile32) (void)hipFree(c->bank_tile32);
     if (c->bank_x3) (void)hipFree(c->bank_x3);
     if (c->pair_x3) (void)hipFree(c->pair_x3);
     if (c->bank16f) (void)hipFree(c->bank16f);
@@ -1508,7 +1529,7 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
     }
     c->bank_N = N;
     c->bank_is_bf16 = (flags & MOCHA_BANK_BF16) != 0;
-    c->bank_tiled_valid = false;
+    c->bank_tiled_valid = false; c->bank_tile32_valid = false;
     if (current) c->generation++;                         // a captured step has the previous bank's pointers and row count baked in
     // match scratch for every query count the workspace admits: a later match never allocates (capture-safe)
     for (int set = 0; set < mocha_ctx::MAX_SETS; ++set)
@@ -2387,7 +2408,8 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "bank_tiled") { c->use_tiled = value != 0; c->generation++; return 0; }
     if (n == "match_planes") { if (value != 1 && value != 2) return fail(c, MOCHA_ERR_ARG, "match_planes must be 1 or 2"); c->match_planes = value; c->generation++; return 0; }
     if (n == "select2") { c->select2 = value != 0; c->generation++; return 0; }
-    if (n == "match_pass") { c->match_pass = value != 0; c->generation++; return 0; }
+    if (n == "match_pass") { if (value < 0 || value > 2) return fail(c, MOCHA_ERR_ARG, "match_pass must be 0, 1 or 2"); c->match_pass = value; c->generation++; return 0; }
+    if (n == "match_nt") { c->match_nt = value != 0; c->generation++; return 0; }
     if (n == "match_pass_variant") { c->match_pass_variant = value; c->generation++; return 0; }
     if (n == "match_pass_max_q") { c->match_pass_max_q = value; c->generation++; return 0; }
     if (n == "attention_kv") {

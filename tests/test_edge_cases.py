@@ -240,6 +240,40 @@ def test_lazy_selection_is_the_staged_selection(model, Q, N):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("Q,N", [(9, 300), (128, 4096), (200, 1000), (300, 2500)])
+def test_coarse_pass_variants_give_the_same_search(model, Q, N):
+    """Round 5: the bf16 bank's coarse pass has three builds - round 4's LDS-DMA kernel (match_nt: non-temporal bank loads, the default for one
+    query tile), mocha_match_pass256 on the row-major bank (match_pass = 1) and on its operand-order image (match_pass = 2, variant 16:
+    non-temporal), each with one or two query planes.  Different K splits and summation orders of the same products; the selection re-evaluates
+    every row inside the coarse bound exactly, so indices are EQUAL and distances agree to fp32 rounding - ragged Q and N, banks smaller and
+    larger than a 256-row tile, Q past match_pass_max_q falling back to the round-4 kernel."""
+    from mocha_sigasia2023_amd import ContextBank
+    g = torch.Generator(device="cuda"); g.manual_seed(31 * Q + N)
+    bank = torch.randn((N, 90 * 256), device="cuda", generator=g)
+    q = torch.randn((Q, 90 * 256), device="cuda", generator=g)
+    for k in range(min(Q, 6)):                                   # near-duplicates inside the one-plane bound
+        row = (k * 7919) % N
+        q[k] = bank[row] + 1e-3 * q[k]
+        bank[(row + 1) % N] = bank[row] + 2e-3 * torch.randn((90 * 256,), device="cuda", generator=g)
+    base = dict(match_pass=0, match_nt=1, match_planes=1, match_pass_variant=0)
+    ref = None
+    try:
+        for opts in (dict(), dict(match_nt=0), dict(match_pass=1), dict(match_pass=1, match_pass_variant=3), dict(match_pass=2), dict(match_pass=2, match_pass_variant=16),
+                     dict(match_planes=2), dict(match_pass=1, match_planes=2), dict(match_pass=2, match_planes=2, match_pass_variant=16)):
+            for k, v in {**base, **opts}.items():
+                model.set_option(k, v)
+            cb = ContextBank(model, bank, bank.view(N, 90, 256), bf16=True)
+            d, i = cb.query(q)
+            if ref is None:
+                ref = (d[:, 0].clone(), i[:, 0].clone())
+            assert torch.equal(i[:, 0], ref[1]), (opts, torch.nonzero(i[:, 0] != ref[1]).flatten().tolist())
+            assert torch.allclose(d[:, 0], ref[0], rtol=2e-6, atol=1e-6), opts
+    finally:
+        for k, v in base.items():
+            model.set_option(k, v)
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("dup", ["identical", "perturbed"])
 def test_selection_with_more_candidates_than_its_list_holds(model, dup):
     """mocha_match_select2 keeps at most 64 candidates per pass; a query with MORE rows inside the coarse pass's error bound

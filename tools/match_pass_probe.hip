@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&Bt, match_tile32_elems(N, D) * 2)); CK(hipMalloc(&sink, 64));
     CK(launch_tile32_bf16(B, Bt, N, D, 0)); CK(hipDeviceSynchronize());
     struct Cfg { const char* name; int variant; int planes = 1; int tiled = 0; };          // variant < 0: the round-4 kernel; -2 / -3: pure stream (plain / nt)
-    const Cfg cfgs[] = {{"stream 1 KB/instr", -2}, {"stream 1 KB/instr nt", -3}, {"old dma<4,1> ksplit 8", -1},
+    const Cfg cfgs[] = {{"stream 1 KB/instr", -2}, {"stream 1 KB/instr nt", -3}, {"old dma<4,1> ksplit 8", -1}, {"old dma<4,1> nt bank", -4},
                         {"p256 pfs5 tiled", 5, 1, 1}, {"p256 pfs6 tiled", 6, 1, 1}, {"p256 pfs5 tiled nt", 5 + 16, 1, 1}, {"p256 pfs5 tiled FILL", 5 + 256, 1, 1},
                         {"p256 pfs5 tiled nt FILL", 5 + 16 + 256, 1, 1}, {"p256 2pl pfs3 tiled", 3, 2, 1},
                         {"p256 pfs3", 3}, {"p256 pfs4", 4}, {"p256 pfs5", 5}, {"p256 pfs6", 6},
@@ -87,14 +87,14 @@ int main(int argc, char** argv) {
         auto launch = [&]() {
             if (c.variant == -2) stream_read<false><<<2048, 256>>>((const pu32x4*)B, (size_t)N * D / 8, sink);
             else if (c.variant == -3) stream_read<true><<<2048, 256>>>((const pu32x4*)B, (size_t)N * D / 8, sink);
-            else if (c.variant < 0) CK(launch_match_gemm_bf16(A, B, S, Q, N, D, k_old, 0, c.planes, nullptr));
+            else if (c.variant < 0) CK(launch_match_gemm_bf16(A, B, S, Q, N, D, k_old, 0, c.planes, nullptr, c.variant == -4 ? 1 : 0));
             else CK(launch_match_pass256(A, B, S, Q, N, D, k_new, 0, c.variant, c.planes, c.tiled ? Bt : nullptr));
         };
         launch(); CK(hipDeviceSynchronize());
         // correctness against the first configuration (not for fill-only runs)
         double err = -1.0;
         if (c.planes != ref_planes) { have_ref = false; ref_planes = c.planes; }
-        if (!(c.variant >= 0 && (c.variant & 256)) && c.variant > -2) {
+        if (c.variant >= 0 ? !(c.variant & 256) : (c.variant == -1 || c.variant == -4)) {
             const int ks = c.variant < 0 ? k_old : k_new;
             slab_sum<<<(unsigned)(((size_t)Q * N + 255) / 256), 256>>>(S, ks, (size_t)Q * N, have_ref ? got : ref, (size_t)Q * N);
             CK(hipDeviceSynchronize());
