@@ -494,7 +494,7 @@ hipError_t attention_x3_init() {
 }
 // AttnParams::split_max (default 192): (window, head) pairs up to which the twelve-wave variant is launched (head dim 256: the
 // decoder's four heads, 48 windows; whole decoder 109 vs 116 us at one window, 236 vs 244 at 32, equal at 64 windows, slower
-// from 96 - tools/attn_split_ab.py)
+// from 96 - tools/ab/attn_split_ab.py)
 
 hipError_t launch_attention_x3(const AttnParams& p, hipStream_t s) {
     if (p.B <= 0) return hipSuccess;

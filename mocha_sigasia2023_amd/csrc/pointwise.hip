@@ -729,7 +729,7 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_instnorm(const float* __rest
 // a handful of windows: four workgroups per window
 // Windows up to which a window's 256 channels go over four workgroups (option "inorm_split_max").  Round 4: EVERY batch - the variant built
 // for a handful of windows is also the faster one at 585 / 1 170 (mvn 77 -> 59 us, adain 43 -> 40, in_cha 43 -> 40; eight workgroups
-// per window: no further gain; tools/inorm_ab.py): four times the workgroups overlap each other's load -> reduce -> store phases.
+// per window: no further gain; tools/ab/inorm_ab.py): four times the workgroups overlap each other's load -> reduce -> store phases.
 // (per context since round 5: InormExtra::split_max / launch_adain's split_max; default: every batch)
 
 hipError_t launch_instnorm(const float* x, float* out, float* mean_out, const float* gm, const float* gs, float* zn,
@@ -823,60 +823,64 @@ hipError_t launch_adain(const float* x, const float* gb, int gb_stride, float* x
 // Why float64: AdaIN's (1 + gamma) multiplies the normalised activations and the attention's mapping norm divides by |1 + gamma| s + eps:
 // where 1 + gamma is within ~1e-4 of zero the fp32 rounding of gamma (1e-6 absolute) moves that channel of the queries by per cent
 // - the largest single contribution to the reference's own fp32 error on structured inputs (tools/precision_study.py, part 2).
-// 64 x 64 tile per 256-thread workgroup, 4 x 4 outputs per thread, K staged through LDS 32 deep.  ~20 us for 585 windows.
+// 64 x 64 (or 32 x 32) tile per 256-thread workgroup, K staged through LDS 32 deep with the next tile's operands in registers.
 // ---------------------------------------------------------------------------------------
-template <int ACT /* 0 none, 2 LeakyReLU(0.2) */>
+// RT x RT outputs per thread: RT = 4 is the 64 x 64 tile, RT = 2 a 32 x 32 tile - four times the workgroups for launches that would not
+// put one 64 x 64 tile on every CU (585 windows x 1024 columns: 160 tiles; the kernel is a chain of short K tiles with two barriers each,
+// so co-resident workgroups, not the tile's arithmetic intensity, set its time)
+template <int ACT /* 0 none, 2 LeakyReLU(0.2) */, int RT>
 __global__ __launch_bounds__(256) void mocha_linear_f64(const double* __restrict__ X, int ldx, int xcol, const double* __restrict__ W,
                                                         const double* __restrict__ bias, double* __restrict__ y64, float* __restrict__ y32,
                                                         int ldy, int M, int N, int K) {
-    constexpr int KT = 32, LDT = 64 + 2;
+    constexpr int KT = 32, TILE = 16 * RT, LDT = TILE + 2;
+    constexpr int KPT = 2 * RT;                                           // consecutive k a loader thread takes: TILE rows x 32 k over 256 threads
     __shared__ double Xs[KT][LDT];
     __shared__ double Ws[KT][LDT];
     const int l = blockIdx.z;
-    const int r0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int r0 = blockIdx.y * TILE, n0 = blockIdx.x * TILE;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const double* Xl = X + (size_t)l * xcol;
     const double* Wl = W + (size_t)l * N * K;
-    double acc[4][4] = {};
-    const int lr = threadIdx.x >> 2, lk = (threadIdx.x & 3) * 8;          // loader: row / column lr of the tile, 8 consecutive k
+    double acc[RT][RT] = {};
+    const int lr = threadIdx.x / (KT / KPT), lk = (threadIdx.x % (KT / KPT)) * KPT;      // loader: row / column lr of the tile, KPT consecutive k
     // rows / columns past the edge read the last valid one (their products are never stored): no predicated loads in the loop
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     const int xrow = (r0 + lr) < M ? (r0 + lr) : M - 1, wrow = (n0 + lr) < N ? (n0 + lr) : N - 1;
     const f64x2* xp = reinterpret_cast<const f64x2*>(Xl + (size_t)xrow * ldx + lk);
     const f64x2* wp = reinterpret_cast<const f64x2*>(Wl + (size_t)wrow * K + lk);
-    f64x2 xr[4], wr[4];
+    f64x2 xr[RT], wr[RT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xr[i] = xp[i]; wr[i] = wp[i]; }
+    for (int i = 0; i < RT; ++i) { xr[i] = xp[i]; wr[i] = wp[i]; }
     for (int k0 = 0; k0 < K; k0 += KT) {
         __syncthreads();                                                  // the previous tile has been read
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RT; ++i) {
             Xs[lk + 2 * i][lr] = xr[i][0]; Xs[lk + 2 * i + 1][lr] = xr[i][1];
             Ws[lk + 2 * i][lr] = wr[i][0]; Ws[lk + 2 * i + 1][lr] = wr[i][1];
         }
         __syncthreads();
         if (k0 + KT < K) {                                                // the next tile's operands travel while this one is multiplied
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { xr[i] = xp[(k0 + KT) / 2 + i]; wr[i] = wp[(k0 + KT) / 2 + i]; }
+            for (int i = 0; i < RT; ++i) { xr[i] = xp[(k0 + KT) / 2 + i]; wr[i] = wp[(k0 + KT) / 2 + i]; }
         }
 #pragma unroll 8
         for (int kk = 0; kk < KT; ++kk) {
-            double xa[4], wb[4];
+            double xa[RT], wb[RT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { xa[i] = Xs[kk][ty * 4 + i]; wb[i] = Ws[kk][tx * 4 + i]; }
+            for (int i = 0; i < RT; ++i) { xa[i] = Xs[kk][ty * RT + i]; wb[i] = Ws[kk][tx * RT + i]; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < RT; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fma(xa[i], wb[j], acc[i][j]);
+                for (int j = 0; j < RT; ++j) acc[i][j] = fma(xa[i], wb[j], acc[i][j]);
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + ty * 4 + i;
+    for (int i = 0; i < RT; ++i) {
+        const int r = r0 + ty * RT + i;
         if (r >= M) continue;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nn = n0 + tx * 4 + j;
+        for (int j = 0; j < RT; ++j) {
+            const int nn = n0 + tx * RT + j;
             if (nn >= N) continue;
             double v = acc[i][j] + (bias ? bias[(size_t)l * N + nn] : 0.0);
             if (ACT == 2) v = v > 0.0 ? v : 0.2 * v;
@@ -886,13 +890,54 @@ __global__ __launch_bounds__(256) void mocha_linear_f64(const double* __restrict
     }
 }
 
+// A handful of rows (one streamed window, the CVAE branch's decoder calls: M <= 16): one wave per (row, two output columns), lanes stride K,
+// wave reduction - a single round of loads instead of a chain of K tiles with two barriers each (M = 1: 2 x ~16 us on the tiled kernel)
+template <int ACT>
+__global__ __launch_bounds__(256) void mocha_linear_f64_rows(const double* __restrict__ X, int ldx, int xcol, const double* __restrict__ W,
+                                                             const double* __restrict__ bias, double* __restrict__ y64, float* __restrict__ y32,
+                                                             int ldy, int N, int K) {
+    const int l = blockIdx.z, m = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 8 + 2 * wave;
+    if (n >= N) return;
+    const int n1 = n + 1 < N ? n + 1 : n;
+    const double* x = X + (size_t)m * ldx + (size_t)l * xcol;
+    const double* w0 = W + ((size_t)l * N + n) * K;
+    const double* w1 = W + ((size_t)l * N + n1) * K;
+    double a0 = 0.0, a1 = 0.0;
+    for (int k = lane; k < K; k += 64) { const double xv = x[k]; a0 = fma(xv, w0[k], a0); a1 = fma(xv, w1[k], a1); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); }
+    if (lane < 2 && n + lane < N) {
+        double v = (lane ? a1 : a0) + (bias ? bias[(size_t)l * N + n + lane] : 0.0);
+        if (ACT == 2) v = v > 0.0 ? v : 0.2 * v;
+        if (y64) y64[(size_t)m * ldy + (size_t)l * N + n + lane] = v;
+        if (y32) y32[(size_t)m * ldy + (size_t)l * N + n + lane] = (float)v;
+    }
+}
+
+int linear_f64_small_tiles = -1;     // diagnostic override: 1 = always 32 x 32 tiles, 0 = always 64 x 64, -1 = by grid size
+
 hipError_t launch_linear_f64(const double* X, int ldx, int xcol, const double* W, const double* bias, double* y64, float* y32, int ldy,
                              int M, int N, int K, int L, int act, hipStream_t s) {
     if (M <= 0) return hipSuccess;
     if (N < 1 || K < 32 || (K & 31) || L < 1 || (act != 0 && act != 2) || (!y64 && !y32) || (ldx & 1) || (xcol & 1)) return hipErrorInvalidValue;      // 16-byte row loads
-    const dim3 grid((N + 63) / 64, (M + 63) / 64, L);
-    if (act == 2) hipLaunchKernelGGL(mocha_linear_f64<2>, grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);
-    else hipLaunchKernelGGL(mocha_linear_f64<0>, grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);
+    if (M <= 16) {
+        const dim3 grid((N + 7) / 8, M, L);
+        if (act == 2) hipLaunchKernelGGL(mocha_linear_f64_rows<2>, grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, N, K);
+        else hipLaunchKernelGGL(mocha_linear_f64_rows<0>, grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, N, K);
+        return hipGetLastError();
+    }
+    const long long big = (long long)((N + 63) / 64) * ((M + 63) / 64) * L;
+    const bool small = linear_f64_small_tiles >= 0 ? linear_f64_small_tiles != 0 : big < 512;
+    if (small) {
+        const dim3 grid((N + 31) / 32, (M + 31) / 32, L);
+        if (act == 2) hipLaunchKernelGGL((mocha_linear_f64<2, 2>), grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);
+        else hipLaunchKernelGGL((mocha_linear_f64<0, 2>), grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);
+    } else {
+        const dim3 grid((N + 63) / 64, (M + 63) / 64, L);
+        if (act == 2) hipLaunchKernelGGL((mocha_linear_f64<2, 4>), grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);
+        else hipLaunchKernelGGL((mocha_linear_f64<0, 4>), grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);
+    }
     return hipGetLastError();
 }
 

@@ -57,7 +57,12 @@ def test_cached_bank_constants_equal_the_per_call_flow(model, B):
         out[cache] = (Y.clone(), idx.clone(), sites)
     model.set_option("bank_dec_cache", 1)
     assert torch.equal(out[1][1], out[0][1])
-    assert torch.equal(out[1][0], out[0][0]), float((out[1][0] - out[0][0]).abs().max())
+    if B > 16:
+        assert torch.equal(out[1][0], out[0][0]), float((out[1][0] - out[0][0]).abs().max())
+    else:
+        # up to 16 rows the per-call style MLP runs on the few-rows float64 kernel (another summation order than the bank build's tiled one):
+        # gamma / beta agree to float64 rounding, i.e. to the last fp32 bit except on a rounding boundary
+        assert float((out[1][0] - out[0][0]).abs().max()) <= 1e-6 * max(1.0, float(out[0][0].abs().max()))
     names = {c: {k.split("|")[0] for k in out[c][2]} for c in (0, 1)}           # profile keys are "site|kernel"
     assert "dec.in_cha" in names[0] and "dec.style1" in names[0]               # recomputed per call ...
     assert "dec.in_cha" not in names[1] and "dec.style1" not in names[1]       # ... and not at all with the cache

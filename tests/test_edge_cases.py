@@ -31,6 +31,7 @@ def test_empty_batches_return_empty(model):
     assert model.encoder(T0).shape == (0, 90, 256)
     assert model.decoder(T0, T0).shape == (0, 90, 256)
     assert model.to_mot(T0).shape == (0, 60, 24, 15)
+    assert model.style_constants(T0).shape == (0, 1024)
     assert model(X0, X0).shape == (0, 60, 24, 15)
     assert mean_variance_norm(T0.permute(0, 2, 1)).shape == (0, 256, 90)
     enc, cnt, nm = model.encode(X0, mean, std)
@@ -425,7 +426,8 @@ def test_null_pointers_come_back_as_error_codes(model):
     ctx = model._ctx
     cases = [("mocha_embed", (_ptr(None), 2, _ptr(tok), 1, _stream())), ("mocha_embed", (_ptr(x), 2, _ptr(None), 1, _stream())),
              ("mocha_encoder", (_ptr(tok), 2, _ptr(None), _stream())), ("mocha_decoder", (_ptr(tok), _ptr(None), 2, _ptr(tok), _stream())),
-             ("mocha_to_mot", (_ptr(None), 2, _ptr(x), _stream())), ("mocha_forward", (_ptr(x), _ptr(x), 2, _ptr(None), _stream())),
+             ("mocha_to_mot", (_ptr(None), 2, _ptr(x), _stream())), ("mocha_style_constants", (_ptr(tok), 2, _ptr(None), _stream())),
+             ("mocha_style_constants", (_ptr(None), 2, _ptr(tok), _stream())), ("mocha_forward", (_ptr(x), _ptr(x), 2, _ptr(None), _stream())),
              ("mocha_encode", (_ptr(x), 2, _ptr(None), _ptr(None), _ptr(None), _ptr(None), _ptr(None), _stream()))]
     for name, args in cases:
         with pytest.raises(RuntimeError, match="null argument"):

@@ -3,7 +3,7 @@
 alternating on one box, and on the streamed window (configs[4], fp32 bank)."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import ContextBank, Generator, StreamingCharacterizer, synthetic, synthetic_state_dict
 dev = torch.device("cuda:0")
 model = Generator(device=dev).load_state_dict(synthetic_state_dict(1777, 1.0)).eval()

@@ -4,7 +4,7 @@ the HIP features vs what the matcher returns, on a synthetic clip pair whose ban
 Context matching)."""
 import os
 import sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, weights
 from oracle import mocha_oracle as O
 sd = weights.synthetic_state_dict(21, 1.2)

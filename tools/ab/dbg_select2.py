@@ -1,6 +1,6 @@
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, weights
 dev = torch.device("cuda:0")
 NB, V, W, D = 16384, 22, 285, 23040

@@ -2,7 +2,7 @@
 """A/B: embed_front's grid cap (workgroups that each pay the per-lane plane constants) and its 3-waves-per-SIMD build, at the demo step."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import Generator, synthetic, synthetic_state_dict
 dev = torch.device("cuda:0")
 V, W = 22, int(os.environ.get("W", 585))

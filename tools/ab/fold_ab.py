@@ -2,7 +2,7 @@
 """A/B of the decoder projection folding (mocha_set_option fold_decoder): error against the oracle and step time."""
 import os
 import sys, time, torch, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import Generator, ContextBank, synthetic, synthetic_state_dict
 from oracle import mocha_oracle as O
 dev = torch.device('cuda:0')

@@ -2,7 +2,7 @@
 """A/B: instance-norm kernels with a window's channels over four workgroups (the small-batch variant) at the demo step's batch sizes."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import Generator, synthetic, synthetic_state_dict
 dev = torch.device("cuda:0")
 V, W = 22, 585

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of the demo-pair step: three calls (encode cha, bank, characterize src) vs mocha_characterize_pair."""
 import sys, time, torch
-sys.path.insert(0, __file__.rsplit('/', 2)[0])
+sys.path.insert(0, __file__.rsplit('/', 3)[0])
 from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, synthetic_state_dict
 dev = torch.device('cuda:0')
 for V, layout in ((22, 'mixamo'), (24, 'mocha')):

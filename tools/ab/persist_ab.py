@@ -2,7 +2,7 @@
 """A/B of the persistent plane GEMM (option "gemm_persistent" = workgroups; 0 = mocha_gemm_x3): the demo step and its GEMM sites, alternating."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import Generator, synthetic, synthetic_state_dict
 dev = torch.device("cuda:0")
 V, W = 22, 585

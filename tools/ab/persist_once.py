@@ -2,7 +2,7 @@
 """A few demo steps with the plane GEMM's persistent instance on (argv[1] = workgroups) or off (0), for rocprofv3 passes."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import Generator, synthetic, synthetic_state_dict
 dev = torch.device("cuda:0")
 V, W = 22, 585

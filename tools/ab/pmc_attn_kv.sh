@@ -12,7 +12,7 @@ for set in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WA
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum"; do
   i=$((i+1))
   for kv in 0 1; do
-    rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p${i}_kv$kv -o w -- python3 $R/tools/decoder_once.py 585 $kv > $out/p${i}_kv$kv.stdout 2> $out/p${i}_kv$kv.stderr
+    rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p${i}_kv$kv -o w -- python3 $R/tools/ab/decoder_once.py 585 $kv > $out/p${i}_kv$kv.stdout 2> $out/p${i}_kv$kv.stderr
   done
 done
 python3 - $out <<'PY'

@@ -5,8 +5,8 @@ cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/pmc_persist; rm -rf $out; mkdir -p $out
 for pers in 0 768; do
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $out/p$pers -o p -- python3 $R/tools/persist_once.py $pers > $out/p$pers.out 2>&1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/t$pers -o t -- python3 $R/tools/persist_once.py $pers > $out/t$pers.out 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --kernel-trace --output-format csv -d $out/p$pers -o p -- python3 $R/tools/ab/persist_once.py $pers > $out/p$pers.out 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/t$pers -o t -- python3 $R/tools/ab/persist_once.py $pers > $out/t$pers.out 2>&1
 done
 python3 - $out <<'PY'
 import csv, sys, glob, collections

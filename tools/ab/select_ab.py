@@ -3,7 +3,7 @@
 128 x 4096 bf16 (configs[3] per GPU), 585 x 585 fp32 (the demo pair) and 1024 x 4096 bf16 (configs[2]); per-kernel HIP events."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import ContextBank, Generator, synthetic_state_dict
 dev = torch.device("cuda:0")
 model = Generator(device=dev).load_state_dict(synthetic_state_dict(1, 1.0)).eval()

@@ -3,7 +3,7 @@
 select_once.py <Q> <N> <select2 0|1>"""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import ContextBank, Generator, synthetic_state_dict
 Q, N, sel = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 dev = torch.device("cuda:0")

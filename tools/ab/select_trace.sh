@@ -5,9 +5,9 @@ cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/select_trace; rm -rf $out; mkdir -p $out
 for sel in 0 1; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/t$sel -o t -- python3 $R/tools/select_once.py 128 4096 $sel > $out/t$sel.out 2>&1
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/p$sel -o p -- python3 $R/tools/select_once.py 128 4096 $sel > $out/p$sel.out 2>&1
-  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum --kernel-trace --output-format csv -d $out/c$sel -o c -- python3 $R/tools/select_once.py 128 4096 $sel > $out/c$sel.out 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/t$sel -o t -- python3 $R/tools/ab/select_once.py 128 4096 $sel > $out/t$sel.out 2>&1
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/p$sel -o p -- python3 $R/tools/ab/select_once.py 128 4096 $sel > $out/p$sel.out 2>&1
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum --kernel-trace --output-format csv -d $out/c$sel -o c -- python3 $R/tools/ab/select_once.py 128 4096 $sel > $out/c$sel.out 2>&1
 done
 python3 - $out <<'PY'
 import csv, sys, glob, collections

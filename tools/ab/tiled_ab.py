@@ -3,7 +3,7 @@
 the Infinity Cache) and inside characterize(128 windows) (cold: other kernels run between two passes); also 1 024 x 4 096 and a ragged bank."""
 import os, sys
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import ContextBank, Generator, synthetic, synthetic_state_dict
 dev = torch.device("cuda:0")
 model = Generator(layout="mixamo", device=dev).load_state_dict(synthetic_state_dict(1777, 1.0, "mixamo")).eval()

@@ -2,7 +2,7 @@
 """Experiment: do two independent encode chains overlap usefully on two HIP streams (two contexts)?"""
 import os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from mocha_sigasia2023_amd import Generator, synthetic, synthetic_state_dict
 dev = torch.device("cuda:0")

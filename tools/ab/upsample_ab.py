@@ -3,7 +3,7 @@
 of the weight blocks zero), folded into two 2-tap launches (K = 128, N = 128 each)."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from mocha_sigasia2023_amd import Generator, synthetic, synthetic_state_dict
 dev = torch.device("cuda:0")
 V = 22
