@@ -581,7 +581,7 @@ __device__ __forceinline__ f32x4 group_sum4(f32x4 v, f32x4* red, int q, int g) {
 }
 
 template <int QW>
-__device__ __forceinline__ void inorm_stats(const f32x4* xv, int cnt, int n, f32x4* red, int q, int g, f32x4& mean, f32x4& den) {
+__device__ __forceinline__ void inorm_stats(const f32x4* xv, int cnt, int n, f32x4* red, int q, int g, f32x4& mean, f32x4& den, f32x4* sd = nullptr) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < IN_MAXT; ++i)
@@ -592,7 +592,9 @@ __device__ __forceinline__ void inorm_stats(const f32x4* xv, int cnt, int n, f32
     for (int i = 0; i < IN_MAXT; ++i)
         if (i < cnt) { const f32x4 d = xv[i] - mean; qq += d * d; }
     qq = group_sum4<QW>(qq, red, q, g) / (float)(n - 1);
-    den[0] = sqrtf(qq[0]) + 1e-5f; den[1] = sqrtf(qq[1]) + 1e-5f; den[2] = sqrtf(qq[2]) + 1e-5f; den[3] = sqrtf(qq[3]) + 1e-5f;
+    const f32x4 sq = {sqrtf(qq[0]), sqrtf(qq[1]), sqrtf(qq[2]), sqrtf(qq[3])};
+    den = sq + 1e-5f;
+    if (sd) *sd = sq;                                        // the std itself: den - eps loses it when s << eps
 }
 
 template <int QW>
@@ -774,17 +776,16 @@ __global__ __launch_bounds__(QW * IN_NG) void mocha_adain(const float* __restric
     f32x4 gamma1 = reinterpret_cast<const f32x4*>(gb + (size_t)gr * gb_stride)[q];
     const f32x4 beta = reinterpret_cast<const f32x4*>(gb + (size_t)gr * gb_stride + 256)[q];
     gamma1 += 1.f;
-    f32x4 mean, den;
-    inorm_stats<QW>(xv, cnt, n, red, ql, g, mean, den);
+    f32x4 mean, den, sd;
+    inorm_stats<QW>(xv, cnt, n, red, ql, g, mean, den, &sd);
     f32x4* ab = reinterpret_cast<f32x4*>(xad + (size_t)b * n * 256) + q;
     f32x4* qb = reinterpret_cast<f32x4*>(qin + (size_t)b * n * 256) + q;
     if (closed) {
         f32x4 a1, a2;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float s = den[k] - 1e-5f;                  // exact: den = s + eps was rounded once, s is recovered to an ulp of den
             a1[k] = gamma1[k] / den[k];
-            a2[k] = gamma1[k] / fmaf(fabsf(gamma1[k]), s, 1e-5f * den[k]);
+            a2[k] = gamma1[k] / fmaf(fabsf(gamma1[k]), sd[k], 1e-5f * den[k]);
         }
 #pragma unroll
         for (int i = 0; i < IN_MAXT; ++i)
