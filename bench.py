@@ -315,7 +315,26 @@ def comm_record(model, backend, world):
             "torch_side_channel_backend": backend, "test_hooks_in_env": hooks}
 
 
-def projected_scaling_record(a, model, dev, V):
+def pipelined_pair_record(a, sd, layout, dev, V, W, src, cha, mean, std, contexts=2):
+    """Extra (never the headline): the SAME demo step with consecutive steps overlapped - `contexts` Generators on their own streams take the
+    steps in turn (independent steps; include/mocha_hip.h: several contexts of one process may be driven concurrently).  K steps are K steps;
+    only their kernels interleave."""
+    from mocha_sigasia2023_amd import Generator
+    models = [Generator(layout=layout, device=dev).load_state_dict(sd).eval() for _ in range(contexts)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(contexts)]
+    def run(n):
+        for i in range(n):
+            with torch.cuda.stream(streams[i % contexts]):
+                models[i % contexts].characterize_pair(src, cha, mean, std)
+    with torch.no_grad():
+        run(2 * contexts); torch.cuda.synchronize()
+        t0 = time.perf_counter(); run(a.steps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    del models
+    return {"contexts": contexts, "value": W * a.steps / dt, "ms_per_step": dt / a.steps * 1e3,
+            "note": "consecutive demo steps on alternating contexts / streams; the headline runs them one after the other"}
+
+
+def projected_scaling_record(a, model, dev, V, sd=None, layout=None):
     """N = 1 line only: what one GPU of the FINAL tree does with every per-rank share of BASELINE configs[3] (the 1024 windows of seed 1
     against the 4096-entry bf16 bank: 1024 / 512 / 256 / 128 windows = the shares at N = 1 / 2 / 4 / 8), measured back to back on this GPU,
     and the strong-scaling figures that follow from them if nothing else changes (no collective inside a step; the bank broadcast is a
@@ -335,6 +354,10 @@ def projected_scaling_record(a, model, dev, V):
         bank_nm = torch.randn((NB, 90 * 256), device=dev, generator=g)
         bank_enc = torch.randn((NB, 90, 256), device=dev, generator=g)
         bank = ContextBank(model, bank_nm, bank_enc, bf16=True)
+        pipe = None
+        if sd is not None:
+            from mocha_sigasia2023_amd import BatchPipeline
+            pipe = BatchPipeline(sd, bank_nm, bank_enc, layout=layout, device=dev, contexts=3, bf16=True)
         shares = {}
         for n_gpus in (1, 2, 4, 8):
             share = W // n_gpus
@@ -350,14 +373,27 @@ def projected_scaling_record(a, model, dev, V):
             shares[str(n_gpus)] = {"windows_per_gpu": share, "ms_per_step": dt * 1e3, "frames_per_s_per_gpu": share / dt,
                                    "projected_whole_job_frames_per_s": n_gpus * share / dt,
                                    "modelled_bank_broadcast_ms": (2.0 * bank_bytes / n_gpus / (XGMI_LINK_GBS * 1e9) * 1e3) if n_gpus > 1 else 0.0}
-        del bank, bank_nm, bank_enc, full
+            if pipe is not None:                       # the same share with consecutive steps overlapped on three contexts (BatchPipeline)
+                for _ in range(6):
+                    pipe.characterize(src, mean, std)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(3 * reps):
+                    pipe.characterize(src, mean, std)
+                torch.cuda.synchronize(); dtp = (time.perf_counter() - t0) / (3 * reps)
+                shares[str(n_gpus)]["pipelined_3_contexts"] = {"ms_per_step": dtp * 1e3, "frames_per_s_per_gpu": share / dtp,
+                                                               "projected_whole_job_frames_per_s": n_gpus * share / dtp}
+        del bank, bank_nm, bank_enc, full, pipe
     base = shares["1"]["projected_whole_job_frames_per_s"]
     for k, v in shares.items():
         v["projected_strong_scaling_efficiency"] = v["projected_whole_job_frames_per_s"] / (int(k) * base)
+        if "pipelined_3_contexts" in v:
+            v["pipelined_3_contexts"]["projected_strong_scaling_efficiency_vs_serial_n1"] = v["pipelined_3_contexts"]["projected_whole_job_frames_per_s"] / (int(k) * base)
     return {"workload": "BASELINE configs[3]: 1024 windows x 4096-entry bank (bf16 cnt) split over N GPUs, per-rank share run on THIS GPU",
             "is_projection_from_one_gpu": True, "by_n_gpus": shares,
             "note": "per-rank step time of each share measured on one GPU of this tree; whole-job = N x share / time (no in-step collective); the "
-                    "bank broadcast (755 MB fp32 rows + entries, scatter + all-gather) is modelled at 153 GB/s per link and paid once"}
+                    "bank broadcast (755 MB fp32 rows + entries, scatter + all-gather) is modelled at 153 GB/s per link and paid once; "
+                    "pipelined_3_contexts: the same shares with consecutive steps overlapped on three contexts / streams (BatchPipeline) - "
+                    "a mid-size step is a latency chain that leaves most of the chip idle, independent steps fill each other's gaps"}
 
 
 def bank4k_record(a, model, dev, V, rank, world, backend):
@@ -929,7 +965,8 @@ def main():
                 out["ours"] = ours_record(model, dev)
                 out["post"] = post_record(model, dev, W)
                 out["bank_build"] = bank_build_record(model, dev, V)
-                out["projected_scaling"] = projected_scaling_record(a, model, dev, V)
+                out["projected_scaling"] = projected_scaling_record(a, model, dev, V, sd, layout)
+                out["pipelined_steps"] = pipelined_pair_record(a, sd, layout, dev, V, W, src, cha, mean, std)
                 if V != 24:
                     sd24 = synthetic_state_dict(seed=1777, gain=1.0, layout="mocha")
                     m24 = Generator(layout="mocha", device=dev).load_state_dict(sd24).eval()

@@ -10,6 +10,10 @@
   preprocess/generate_database_bin.py:228-246); ``collect_windows`` — the bank scripts' step-1 windowing over the
   clips of one character (collect_CVAE_feature_action.py:104-133); ``build_bank_from_database`` chains them with the
   device featurisation and ``build_bank``: database.bin -> windows -> X -> encoded / cnt -> the reference's ``.npz`` files.
+* ``BatchPipeline`` — consecutive batches overlapped: a few contexts of one process, each with its own stream, characterize
+  alternate batches against the same bank.  A mid-size batch (the per-GPU share of BASELINE configs[3]: 128 windows) is a latency
+  chain of ~37 launches that leaves most of the chip idle; independent batches fill each other's gaps (128 windows: 121 -> 160 k
+  frames/s with three contexts, profiles/r05/f_mid_pipeline.txt).
 * ``ShardedContextBank`` — each rank scans its own block of bank rows and the per-query (distance, index) pairs are
   all-gathered (8 bytes per query and rank); every rank then holds the global winner.  Cuts the HBM-bound scan of a
   streamed query by the number of GPUs; the ``encoded`` features are replicated so the gather stays local.
@@ -184,6 +188,45 @@ def reduce_matches(dist_local: torch.Tensor, idx_global: torch.Tensor):
     best_d = d.min(dim=0).values
     cand = torch.where(d == best_d[None], i, torch.full_like(i, torch.iinfo(i.dtype).max))
     return best_d, cand.min(dim=0).values
+
+
+class BatchPipeline:
+    """Overlap consecutive batches of ``ContextBank.characterize`` (test_fullframework.py:188-194, 438-443, 465-467 on many clips).
+
+    ``contexts`` Generators with the same weights, each on its own HIP stream, take the batches in turn; the bank's rows are
+    borrowed by every context (one copy of ``cnt_nm`` / ``encoded``; the derived data - centroid, norms, bf16 copy, decoder
+    constants - per context).  The windows of a batch are independent of every other batch's, so nothing is exchanged.
+    ``characterize`` returns as soon as the work is enqueued; ``join()`` makes the caller's stream wait for everything
+    submitted so far (call it before reading results on the caller's stream, or synchronise the device)."""
+
+    def __init__(self, state_dict, cha_cnt_nm, cha_encoded, layout: str = "mocha", device="cuda:0", contexts: int = 3,
+                 bf16: bool = False, config=None, options=None):
+        if contexts < 1:
+            raise ValueError("contexts must be >= 1")
+        self.device = torch.device(device)
+        self.models = [Generator(config, layout=layout, device=self.device).load_state_dict(state_dict).eval() for _ in range(contexts)]
+        for m in self.models:
+            for k, v in (options or {}).items():
+                m.set_option(k, v)
+        self.banks = [ContextBank(m, cha_cnt_nm, cha_encoded, bf16=bf16) for m in self.models]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(contexts)]
+        self._next = 0
+
+    def characterize(self, src_X, cnt_mean, cnt_std, return_index: bool = False, raw: bool = False):
+        k = self._next % len(self.models)
+        self._next += 1
+        st = self.streams[k]
+        st.wait_stream(torch.cuda.current_stream(self.device))          # the inputs were produced on the caller's stream
+        with torch.cuda.stream(st):
+            out = self.banks[k].characterize(src_X, cnt_mean, cnt_std, return_index=return_index, raw=raw)
+        for t in (out if isinstance(out, tuple) else (out,)):
+            t.record_stream(torch.cuda.current_stream(self.device))     # allocated on the side stream, read on the caller's after join()
+        return out
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.device)
+        for st in self.streams:
+            cur.wait_stream(st)
 
 
 class ShardedContextBank:

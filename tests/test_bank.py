@@ -70,3 +70,24 @@ def test_build_bank_and_roundtrip(tmp_path):
     nm = (z["cnt"] - z["cnt_mean"][None]) / std[None]
     idx = ContextBank(model, torch.from_numpy(nm).cuda(), torch.from_numpy(z["encoded"]).cuda()).query(torch.from_numpy(nm[:5]).cuda(), return_distance=False)
     assert idx[:, 0].cpu().tolist() == [0, 1, 2, 3, 4]
+
+
+@pytest.mark.gpu
+def test_batch_pipeline_equals_serial_calls():
+    """BatchPipeline: three contexts on their own streams take alternate batches against one borrowed bank; every batch's poses and
+    indices are those of the serial call, bit for bit (the same kernels on the same inputs; nothing is shared but read-only rows)."""
+    from mocha_sigasia2023_amd import BatchPipeline, ContextBank, Generator
+    dev = torch.device("cuda:0")
+    sd = weights.synthetic_state_dict(5, 1.0)
+    model = Generator(device=dev).load_state_dict(sd).eval()
+    mean, std = (torch.from_numpy(a).to(dev) for a in synthetic.cnt_norm(7))
+    enc, _, nm = model.encode(torch.from_numpy(synthetic.pose_windows(3, 70)).to(dev), mean, std)
+    serial = ContextBank(model, nm, enc)
+    pipe = BatchPipeline(sd, nm, enc, device=dev, contexts=3)
+    batches = [torch.from_numpy(synthetic.pose_windows(20 + i, 5 + 9 * i)).to(dev) for i in range(7)]
+    outs = [pipe.characterize(x, mean, std, return_index=True) for x in batches]
+    pipe.join()
+    torch.cuda.synchronize()
+    for x, (Y, idx) in zip(batches, outs):
+        Ys, ids = serial.characterize(x, mean, std, return_index=True)
+        assert torch.equal(idx, ids) and torch.equal(Y, Ys)
