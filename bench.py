@@ -396,7 +396,7 @@ def projected_scaling_record(a, model, dev, V, sd=None, layout=None):
                     "a mid-size step is a latency chain that leaves most of the chip idle, independent steps fill each other's gaps"}
 
 
-def bank4k_record(a, model, dev, V, rank, world, backend):
+def bank4k_record(a, model, dev, V, rank, world, backend, sd=None, layout=None):
     """BASELINE configs[2] / [3]: 1024 synthetic source windows against a 4096-entry character bank stored bf16 for matching; with N
     GPUs the windows are split by shard_bounds (128 per GPU at N = 8: strong scaling) and rank 0's bank reaches every rank
     through the C ABI (mocha_bank_broadcast: RCCL scatter + all-gather over xGMI), timed on its own.  One step = encode, z-score, 1-NN
@@ -469,6 +469,26 @@ def bank4k_record(a, model, dev, V, rank, world, backend):
     # ... and a per-window fingerprint of the poses (sum |Y| of 16 windows spread over all shards): a split that mixed windows up
     # would keep the index CRC when the indices happen to coincide, not this
     fp_all = D.all_gather_rows(Y.abs().sum(dim=(1, 2, 3)), W).cpu().numpy()
+    # extra: the same per-rank share with consecutive steps overlapped on three contexts / streams (BatchPipeline over the bank every rank
+    # now holds); the poses of the last step must equal the serial ones
+    pipelined = None
+    if sd is not None and not os.environ.get("MOCHA_BENCH_NO_PIPELINE"):
+        from mocha_sigasia2023_amd import BatchPipeline
+        with torch.no_grad():
+            p_nm, p_enc = bank.tensors()
+            pipe = BatchPipeline(sd, p_nm, p_enc, layout=layout, device=dev, contexts=3, bf16=True)
+            for _ in range(6):
+                pipe.characterize(src, mean, std)
+            torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3 * a.steps):
+                Yp = pipe.characterize(src, mean, std)
+            torch.cuda.synchronize(); D.barrier(); torch.cuda.synchronize()
+            e_p = D.max_over_ranks(time.perf_counter() - t0, dev)
+            same = bool(torch.equal(Yp, Y))
+            del pipe, p_nm, p_enc
+        pipelined = {"contexts": 3, "value": W * 3 * a.steps / e_p, "ms_per_step": e_p / (3 * a.steps) * 1e3, "poses_equal_serial_on_rank0": same,
+                     "note": "consecutive steps of every rank overlapped on three contexts / streams (BatchPipeline); `value` above runs them one after the other"}
     del bank, bank_nm, bank_enc
     if rank != 0:
         return None
@@ -484,7 +504,8 @@ def bank4k_record(a, model, dev, V, rank, world, backend):
             "bank_broadcast": bcast, "bank_broadcast_ms": bcast["ms"] if bcast else None, "bank_bytes": 2 * NB * 90 * 256 * 4,
             "idx_crc32": crc, "idx_crc32_n1_known": known, "idx_matches_n1": (crc == known) if known is not None else None,
             "idx_head": idx_all[:8].tolist(), "idx_distinct": int(len(np.unique(idx_all))),
-            "max_abs_Y": y_abs, "y_fingerprint": [float(v) for v in fp_all[:: W // 16][:16]]}
+            "max_abs_Y": y_abs, "y_fingerprint": [float(v) for v in fp_all[:: W // 16][:16]],
+            "pipelined_3_contexts": pipelined}
 
 
 def bank4k(a):
@@ -499,8 +520,9 @@ def bank4k(a):
     fail_rank_hook(rank)
     V = a.joints
     layout = "mocha" if V == 24 else "mixamo"
-    model = Generator(layout=layout, device=dev).load_state_dict(synthetic_state_dict(1777, 1.0, layout)).eval()
-    rec = bank4k_record(a, model, dev, V, rank, world, backend)
+    sd = synthetic_state_dict(1777, 1.0, layout)
+    model = Generator(layout=layout, device=dev).load_state_dict(sd).eval()
+    rec = bank4k_record(a, model, dev, V, rank, world, backend, sd, layout)
     rccl = comm_record(model, backend, world) if torch.distributed.is_initialized() else None
     if rank == 0:
         rec = dict({"metric": METRIC[V]}, **rec, higher_is_better=True, vs_baseline=None, data="synthetic", rccl=rccl)
@@ -882,7 +904,7 @@ def main():
     bank4k_rec = None
     if dist_on and world > 1 and not a.no_bank4k and not bcast_err:
         with torch.no_grad():
-            bank4k_rec = bank4k_record(a, model, dev, V, rank, world, backend)
+            bank4k_rec = bank4k_record(a, model, dev, V, rank, world, backend, sd, layout)
 
     out = None
     if rank == 0:

@@ -378,6 +378,11 @@ int64_t mocha_generation(const mocha_ctx* ctx);
 int mocha_graph_constants(mocha_ctx* ctx, float* A_j /*3*V*V host*/, float* A_b /*2*6*6 host*/,
                           float* pool /*V*6 host*/, float* unpool /*6*V host*/);
 
+/* Copies of the current bank's rows into caller buffers, (N, 90*256) fp32 each, either may be NULL: what a rank that RECEIVED its bank
+ * (mocha_bank_broadcast fills context-owned buffers) hands to further contexts of its process (mocha_bank_set ... MOCHA_BANK_BORROW on each:
+ * BatchPipeline).  Enqueued on `stream`. */
+int mocha_bank_export(mocha_ctx* ctx, float* cnt_nm, float* encoded, void* stream);
+
 /* The current bank as the context holds it (device pointers, nothing is copied): the rows it matches against and gathers
  * from, and what the library derived from them - the centroid (90*256), the squared norms of the centred rows (N), the
  * centred bf16 copy (NULL for an fp32 bank).  Any out pointer may be NULL.  For tests that compare the ranks of a

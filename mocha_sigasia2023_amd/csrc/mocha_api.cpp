@@ -2466,6 +2466,16 @@ int mocha_bank_view(mocha_ctx* c, const float** cnt_nm, const float** encoded, c
     return 0;
 }
 
+int mocha_bank_export(mocha_ctx* c, float* cnt_nm, float* encoded, void* stream) {
+    int rc = ready(c, 0); if (rc) return rc;
+    if (!c->bank_cnt || !c->bank_enc || c->bank_N <= 0) return fail(c, MOCHA_ERR_STATE, "no bank: call mocha_bank_set or mocha_bank_broadcast first");
+    const size_t bytes = (size_t)c->bank_N * 90 * 256 * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    if (cnt_nm) HIPCHK(c, hipMemcpyAsync(cnt_nm, c->bank_cnt, bytes, hipMemcpyDeviceToDevice, s));
+    if (encoded) HIPCHK(c, hipMemcpyAsync(encoded, c->bank_enc, bytes, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 int mocha_profile_start(mocha_ctx* c) {
     if (!c) return MOCHA_ERR_ARG;
     for (auto& r : c->prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }

@@ -406,6 +406,18 @@ class ContextBank:
         model._bank = self
         return self
 
+    def tensors(self):
+        """(cnt_nm (N, 23040), encoded (N, 90, 256)) as device tensors: the bank's own, or - for a bank that arrived by
+        ``mocha_bank_broadcast`` and lives in the context - copies made once (``mocha_bank_export``)."""
+        if self.cnt_nm is None:
+            if getattr(self.model, "_bank", None) is not self:
+                raise RuntimeError("a received bank lives in the context and was replaced by another bank: broadcast it again")
+            nm = torch.empty((self.N, NTOK * DIM), dtype=torch.float32, device=self.model.device)
+            enc = torch.empty((self.N, NTOK, DIM), dtype=torch.float32, device=self.model.device)
+            self.model._ctx.call("mocha_bank_export", _ptr(nm), _ptr(enc), _stream())
+            return nm, enc
+        return self.cnt_nm, self.encoded
+
     def activate(self):
         """Make this bank the context's current bank (borrowed buffers unless copy=True)."""
         if self.cnt_nm is None:

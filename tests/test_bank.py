@@ -91,3 +91,13 @@ def test_batch_pipeline_equals_serial_calls():
     for x, (Y, idx) in zip(batches, outs):
         Ys, ids = serial.characterize(x, mean, std, return_index=True)
         assert torch.equal(idx, ids) and torch.equal(Y, Ys)
+    # a bank that lives in the context (as after mocha_bank_broadcast on a non-root rank) hands its rows on through mocha_bank_export
+    owned = ContextBank(model, nm, enc, copy=True)
+    got = ContextBank.received(model, owned.N)
+    nm2, enc2 = got.tensors()
+    torch.cuda.synchronize()
+    assert torch.equal(nm2, nm.reshape(nm2.shape)) and torch.equal(enc2, enc)
+    pipe2 = BatchPipeline(sd, nm2, enc2, device=dev, contexts=2)
+    Y2, i2 = pipe2.characterize(batches[3], mean, std, return_index=True)
+    pipe2.join(); torch.cuda.synchronize()
+    assert torch.equal(Y2, outs[3][0]) and torch.equal(i2, outs[3][1])
