@@ -349,10 +349,16 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * mocha_step_graph read them in place through frame_index instead of recomputing them per call from a gathered copy
  * (needs "style_f64", "fold_decoder", decoder_dim_head == dim, "attention_bf16x3", no "attention_kv"; otherwise, and with 0, the
  * per-call flow).  Takes effect at the next mocha_bank_set.
- * "match_pass" (default 1): the bf16 bank's one-plane coarse pass for up to "match_pass_max_q" (default 256) queries as
- * mocha_match_pass256 (match_pass.hip: 128 x 256 tiles, bank operands straight into registers, K split 16); 0 = round 4's
- * mocha_match_gemm_bf16_dma.  Same products summed over other K slices: the selection's exact re-evaluation makes the answer the same.
- * "match_pass_variant": that kernel's prefetch depth / non-temporal bit (diagnostic).
+ * "match_pass" (default 0 = round 4's mocha_match_gemm_bf16_dma): 1 / 2 = the bf16 bank's coarse pass for up to "match_pass_max_q"
+ * (default 256) queries as mocha_match_pass256 (match_pass.hip: 128 x 256 tiles, bank operands straight into registers, K split 16) on
+ * the row-major bank / on an operand-order image built at the first such call (+ 2 B per bank value).  Same products summed over other K
+ * slices: the selection's exact re-evaluation makes the answer the same.  Measured no faster at 128 queries, 13 us faster at 256 from the
+ * image.  "match_pass_variant": that kernel's prefetch depth / non-temporal bit (diagnostic).
+ * "match_nt" (default 1): the round-4 kernel's bank loads carry the non-temporal hint when a launch reads the bank once (Q <= 128).
+ * "pair_overlap" (default 1): mocha_characterize_pair computes the transient bank's decoder constants on the context's internal stream
+ * beside the matching chain (forked / joined with events; bit-identical, -0.6 % of the demo step).
+ * "gemm_tile64_below" (default 0): mid-size plane-GEMM launches of 128-multiple width with fewer 64 x 128 tiles than this take 64 x 64
+ * tiles (measured no gain); widths that are multiples of 64 only always do at mid size.
  * Every option that changes which kernels a step launches bumps mocha_generation(ctx). */
 int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
 

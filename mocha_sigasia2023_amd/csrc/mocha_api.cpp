@@ -164,6 +164,7 @@ struct mocha_ctx {
     // launch tuning, per context (round 4 kept these as process-wide globals: a second context, or another host thread, changed them underfoot)
     int inorm_split_max = 1 << 30, embed_max_wgs = 512, gemm_persistent = 768, gemm_persistent_max_n = 512; bool embed_sums = true;
     int gemm_tile64_below = 0;         // plane GEMM: 64 x 64 tiles for mid-size 128-multiple launches with fewer 64 x 128 tiles than this (measured: no gain; gemm_x3.hip)
+    bool pair_overlap = true;          // characterize_pair: the transient bank's decoder constants on the internal stream, beside the matching
     bool adain_closed = true;          // mocha_adain: qin from the first statistics in closed form (pointwise.hip); 0 = the literal two-pass order
     bool style_f64 = true;             // the style MLP in float64 (mocha_linear_f64); 0 = the fp32 GEMM engines
     std::map<std::string, double*> w64;                     // float64 copies of the style MLP's weights
@@ -1735,11 +1736,38 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     // character windows first: rows [0, B_cha) of every buffer are the bank, rows [B_cha, B) the queries
     if ((rc = run_embed(c, cha_X, B_cha, WS(c, "x5"), true, s, raw, src_X, B_src))) return rc;
     if ((rc = run_encoder(c, WS(c, "x5"), B, WS(c, "enc_s"), s))) return rc;
-    const InormExtra iex0 = IEX(c);
-    LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * 2,
-           launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), B, 90, s, &iex0));
-    if (cha_encoded) HIPCHK(c, hipMemcpyAsync(cha_encoded, WS(c, "enc_s"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
-    if (cha_cnt_nm) HIPCHK(c, hipMemcpyAsync(cha_cnt_nm, WS(c, "qnm"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+    // The transient bank's decoder constants (IN(entry), gamma / beta of the character windows) depend on the encoder's output alone and
+    // are needed by the decoder only: with "pair_overlap" they run on the context's internal stream BESIDE the matching chain (cnt, centroid,
+    // norms, plane image, coarse GEMM, selection - small latency-bound launches), forked / joined with events (capture-safe, as for_chunks).
+    const float *kin_t = nullptr, *gb_t = nullptr;
+    bool forked = false;
+    if (B_src > 0 && dec_cache_ok(c)) {
+        hipStream_t cs = s;
+        if (c->pair_overlap && c->aux) {
+            HIPCHK(c, hipEventRecord(c->ev_fork, s));
+            HIPCHK(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+            cs = c->aux; forked = true;
+        }
+        rc = build_dec_consts(c, WS(c, "enc_s"), B_cha, WS(c, "kin"), WS(c, "gb"), reinterpret_cast<double*>(WS(c, "smean64")),
+                              reinterpret_cast<double*>(WS(c, "s1d")), B_cha, cs);
+        if (forked) {                                     // join even when a launch failed: the caller's stream must not be left forked
+            const hipError_t ej = hipEventRecord(c->ev_join, c->aux);
+            if (!rc && ej != hipSuccess) rc = fail(c, MOCHA_ERR_HIP, "hipEventRecord: %s", hipGetErrorString(ej));
+        }
+        if (rc) { if (forked) (void)hipStreamWaitEvent(s, c->ev_join, 0); return rc; }
+        kin_t = WS(c, "kin"); gb_t = WS(c, "gb");
+    }
+    auto join = [&]() -> int { if (forked) { forked = false; HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); } return 0; };
+    // everything between the fork and the join runs in a lambda: an early error return must not skip the join
+    rc = [&]() -> int {
+        const InormExtra iex0 = IEX(c);
+        LAUNCH(c, s, "mocha_instnorm", "mvn", 0.0, B * 90.0 * 256 * 4 * 2,
+               launch_instnorm(WS(c, "enc_s"), nullptr, nullptr, cnt_mean, cnt_std, WS(c, "qnm"), B, 90, s, &iex0));
+        if (cha_encoded) HIPCHK(c, hipMemcpyAsync(cha_encoded, WS(c, "enc_s"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+        if (cha_cnt_nm) HIPCHK(c, hipMemcpyAsync(cha_cnt_nm, WS(c, "qnm"), (size_t)B_cha * T * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }();
+    if (rc) { (void)join(); return rc; }
     if (B_src == 0) return 0;
     // transient bank: swap the context's bank state out, borrow the workspace rows, restore afterwards
     // (everything bank_set_impl derives from a bank has a pair_* twin: norms, centroid, packed plane image - the user's
@@ -1759,17 +1787,10 @@ static int characterize_pair_impl(mocha_ctx* c, const float* src_X, int B_src, c
     c->bank_x3 = sv.x3; c->bank_x3_cap = sv.x3_cap; c->bank_x3_valid = sv.x3_valid; c->bank16f_valid = sv.v16;
     c->bank_cnt = sv.cnt; c->bank_enc = sv.enc; c->bank_N = sv.N; c->bank_is_bf16 = sv.bf16; c->bank_norm = sv.norm; c->bank_norm_cap = sv.norm_cap;
     c->bank_center = sv.center;
+    { const int rj = join(); if (!rc) rc = rj; }          // the decoder constants are complete (the caller's stream is never left forked)
     if (rc) return rc;
-    // decoder on the matched character rows: the transient bank's encoded rows are rows [0, B_cha) of the workspace; the first kernel
-    // of the decoder gathers them through the indices
-    const float *kin_t = nullptr, *gb_t = nullptr;
-    if (dec_cache_ok(c)) {
-        // the transient bank's decoder constants (part of the bank build, as mocha_bank_set does for a user's bank): in the workspace rows the
-        // un-cached flow would have filled per source window
-        if ((rc = build_dec_consts(c, WS(c, "enc_s"), B_cha, WS(c, "kin"), WS(c, "gb"), reinterpret_cast<double*>(WS(c, "smean64")),
-                                   reinterpret_cast<double*>(WS(c, "s1d")), B_cha, s))) return rc;
-        kin_t = WS(c, "kin"); gb_t = WS(c, "gb");
-    }
+    // decoder on the matched character rows: the transient bank's encoded rows are rows [0, B_cha) of the workspace, their decoder
+    // constants (as mocha_bank_set makes them for a user's bank) rows [0, B_cha) of "kin" / "gb"; read in place through the indices
     if ((rc = run_decoder(c, WS(c, "enc_s") + (size_t)B_cha * T, nullptr, B_src, WS(c, "dec"), s, WS(c, "enc_s"), ix, B_cha, kin_t, gb_t))) return rc;
     return run_to_mot(c, WS(c, "dec"), B_src, Y, s, raw);
 }
@@ -2402,6 +2423,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "embed_sums") { c->embed_sums = value != 0; c->generation++; return 0; }
     if (n == "embed_front_max_wgs") { c->embed_max_wgs = value; c->generation++; return 0; }
     if (n == "inorm_split_max") { c->inorm_split_max = value < 0 ? 0 : value; c->generation++; return 0; }
+    if (n == "pair_overlap") { c->pair_overlap = value != 0; c->generation++; return 0; }
     if (n == "adain_closed_form") { c->adain_closed = value != 0; c->generation++; return 0; }
     if (n == "style_f64") { c->style_f64 = value != 0; c->bank_dec_valid = false; c->generation++; return 0; }     // cached bank constants: rebuilt at the next mocha_bank_set
     if (n == "bank_dec_cache") { c->bank_dec_cache = value != 0; if (!value) c->bank_dec_valid = false; c->generation++; return 0; }     // takes effect at the next mocha_bank_set
