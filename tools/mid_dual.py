@@ -9,7 +9,7 @@ V = 22
 g = torch.Generator(device=dev); g.manual_seed(2)
 nm = torch.randn((4096, 23040), device=dev, generator=g); enc = torch.randn((4096, 90, 256), device=dev, generator=g)
 m_, s_ = synthetic.cnt_norm(7); mean, std = torch.from_numpy(m_).to(dev), torch.from_numpy(s_).to(dev)
-for W in (128, 256):
+for W in (int(a) for a in (sys.argv[1:] or ["128", "256"])):
     X = torch.from_numpy(synthetic.pose_windows(1, W, V)).to(dev)
     ref = None
     for dual, dmin in ((0, 128), (1, 64), (0, 128), (1, 64)):
