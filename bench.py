@@ -291,7 +291,8 @@ def cpu_baseline(sd, V, n, mean, std, full=0):
 # tests/test_multirank_standin.py (N-rank CRC == a 1-rank run of the same build) and test_fullsize_parity.py (indices vs float64 search).
 BANK4K_IDX_CRC32_N1 = {"545d209a9ac5cbed": {22: 4269089464, 24: 2772088534},      # profiles/r04/h_bank4k_v2{2,4}.json
                        "58ae42e49ecb4b74": {22: 4269089464, 24: 2772088534},      # profiles/r05/k_bank4k_v2{2,4}.json (unchanged by round 5's numerics)
-                       "ad527b6ce6c3a29e": {22: 4269089464, 24: 2772088534}}      # the final tree (same kernels + pair_overlap host change)
+                       "ad527b6ce6c3a29e": {22: 4269089464, 24: 2772088534},      # + pair_overlap host change
+                       "4701c3d0797f58db": {22: 4269089464, 24: 2772088534}}      # the final tree: profiles/r05/q_bank4k_v2{2,4}.json
 XGMI_LINK_GBS = 153.0            # one xGMI link, one direction (MI355X: 7 links per GPU, point-to-point)
 
 

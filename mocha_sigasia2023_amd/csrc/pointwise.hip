@@ -916,8 +916,6 @@ __global__ __launch_bounds__(256) void mocha_linear_f64_rows(const double* __res
     }
 }
 
-int linear_f64_small_tiles = -1;     // diagnostic override: 1 = always 32 x 32 tiles, 0 = always 64 x 64, -1 = by grid size
-
 hipError_t launch_linear_f64(const double* X, int ldx, int xcol, const double* W, const double* bias, double* y64, float* y32, int ldy,
                              int M, int N, int K, int L, int act, hipStream_t s) {
     if (M <= 0) return hipSuccess;
@@ -929,7 +927,7 @@ hipError_t launch_linear_f64(const double* X, int ldx, int xcol, const double* W
         return hipGetLastError();
     }
     const long long big = (long long)((N + 63) / 64) * ((M + 63) / 64) * L;
-    const bool small = linear_f64_small_tiles >= 0 ? linear_f64_small_tiles != 0 : big < 512;
+    const bool small = big < 512;                                   // fewer than 512 tiles of 64 x 64: 32 x 32 tiles (4 x the workgroups)
     if (small) {
         const dim3 grid((N + 31) / 32, (M + 31) / 32, L);
         if (act == 2) hipLaunchKernelGGL((mocha_linear_f64<2, 2>), grid, dim3(256), 0, s, X, ldx, xcol, W, bias, y64, y32, ldy, M, N, K);
