@@ -217,6 +217,9 @@ class BatchPipeline:
         self._next += 1
         st = self.streams[k]
         st.wait_stream(torch.cuda.current_stream(self.device))          # the inputs were produced on the caller's stream
+        for t in (src_X, cnt_mean, cnt_std):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(st)                                     # read on the side stream: the caller may drop them right after this call
         with torch.cuda.stream(st):
             out = self.banks[k].characterize(src_X, cnt_mean, cnt_std, return_index=return_index, raw=raw)
         for t in (out if isinstance(out, tuple) else (out,)):
