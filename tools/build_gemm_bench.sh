@@ -1,5 +1,5 @@
 #!/bin/bash
-# builds tools/bin/gemm_bench (and, with an argument, an ablation of gemm_x3.hip: build_gemm_bench.sh -DX3_MAXSUM=0 -> tools/bin/gemm_bench_abl)
+# builds tools/bin/gemm_bench, tools/bin/gemm_bench_f16 (the two-plane fp16 experiment, tools/experiments/gemm_f16x2_r05.hip, in place of gemm_x3.hip) (and, with an argument, an ablation of gemm_x3.hip: build_gemm_bench.sh -DX3_MAXSUM=0 -> tools/bin/gemm_bench_abl)
 set -e
 cd "$(dirname "$0")/.."
 make -C mocha_sigasia2023_amd/csrc -j4 >/dev/null
@@ -8,6 +8,8 @@ H="/opt/rocm/bin/hipcc --offload-arch=gfx950"
 $H -O3 -std=c++17 -w -I mocha_sigasia2023_amd/csrc -c tools/gemm_bench.hip -o tools/bin/gemm_bench.o
 C=mocha_sigasia2023_amd/csrc
 $H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_x3.o -o tools/bin/gemm_bench
+$H -O3 -fPIC -std=c++17 -w -I $C -c tools/experiments/gemm_f16x2_r05.hip -o tools/bin/gemm_f16x2.o
+$H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2.o -o tools/bin/gemm_bench_f16
 if [ -n "$1" ]; then
   $H -O3 -fPIC -std=c++17 -w "$@" -c $C/gemm_x3.hip -o tools/bin/gemm_x3_abl.o
   $H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_x3_abl.o -o tools/bin/gemm_bench_abl

@@ -83,6 +83,7 @@ int main(int argc, char** argv) {
                          p.T_full = sh.T_full; p.tshift = sh.tshift; p.Cc = sh.Cc; p.T_src = sh.T_src; p.ascale = sh.R > 1 ? 0.25f : 1.f; }
         if (sh.M == 585 && sh.N == 585) { p.ksplit = 16; p.slab_stride = (long long)sh.M * sh.N; }
         if (getenv("MOCHA_BENCH_TILE64")) p.tile64_below = atoi(getenv("MOCHA_BENCH_TILE64"));      // 64 x 64 tiles for mid-size launches (gemm_x3.hip: x3_tile64)
+        if (getenv("MOCHA_BENCH_PERSISTENT")) p.persistent = atoi(getenv("MOCHA_BENCH_PERSISTENT"));      // 0: every launch on the one-shot grid (mocha_gemm_x3)
         if (getenv("MOCHA_BENCH_ALRELU")) p.a_lrelu = 1;               // LeakyReLU on the A operand as it is split: what an A-operand prologue costs the K loop
         const bool x3 = mode == 36 && gemm_x3_supports(p);
         auto run = [&]() { return x3 ? launch_gemm_x3(p, 0) : launch_gemm(p, 0); };
