@@ -911,6 +911,32 @@ def main():
         model.set_option("gemm_bf16x3", 1)
         model.set_option("attention_bf16x3", 1)
 
+    # extra (not the headline): the same step with the encoder's, decoder's and to_mot's plane GEMMs on two fp16 planes / three passes
+    # (mocha_set_option("gemm_f16x2", 1), csrc/gemm_h2.hip); the poses are compared with the default engine's of the same inputs
+    f16x2 = None
+    if world == 1 and not a.no_extras:
+        with torch.no_grad():
+            Y0, i0 = model.characterize_pair(src, cha, mean, std, return_index=True)
+            model.set_option("gemm_f16x2", 1)
+            Y1, i1 = model.characterize_pair(src, cha, mean, std, return_index=True)
+            same = (i0 == i1)
+            dY = float((Y1 - Y0)[same].abs().max()) if bool(same.any()) else None
+            for _ in range(a.warmup):
+                step()
+            sync_all()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                step()
+            sync_all()
+            e4 = time.perf_counter() - t0
+        f16x2 = {"value": W * a.steps / e4, "ms_per_step": e4 / a.steps * 1e3, "same_matches": float(same.float().mean()),
+                 "max_abs_dY_vs_default_engine": dY, "max_abs_Y": float(Y0.abs().max()),
+                 "note": "same step with mocha_set_option(gemm_f16x2=1): the encoder's, decoder's and to_mot's plane GEMMs as two fp16 planes, "
+                         "three v_mfma_f32_32x32x16_f16 passes per product (22-bit operands, fp32 accumulation; GEMM error against float64 below "
+                         "both fp32 engines': tests/test_gemm_f16x2.py) - opt-in, NOT the headline's arithmetic; the embedding GEMMs, the "
+                         "attention and the matcher stay on three bf16 planes"}
+        model.set_option("gemm_f16x2", 0)
+
     # N > 1: BASELINE configs[3] beside the weak-scaled headline - the same 1024 windows split over the ranks, the 4096-entry bank
     # through mocha_bank_broadcast (collective: every rank takes part; the record comes back on rank 0)
     bank4k_rec = None
@@ -988,6 +1014,7 @@ def main():
             "sustained": sustained,
             "dual_stream": dual,
             "exact_f32_engine": exact_f32,
+            "f16x2_engine": f16x2,
         }
         if world == 1 and not a.no_extras:
             # extra records measured in the same process (not the headline): the matcher's own roofline on the shapes the

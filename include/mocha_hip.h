@@ -359,12 +359,21 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * beside the matching chain (forked / joined with events; bit-identical, -0.6 % of the demo step).
  * "gemm_tile64_below" (default 0): mid-size plane-GEMM launches of 128-multiple width with fewer 64 x 128 tiles than this take 64 x 64
  * tiles (measured no gain); widths that are multiples of 64 only always do at mid size.
+ * "gemm_f16x2" (default 0): the encoder's, decoder's and to_mot's batch-size GEMMs as TWO fp16 planes per operand and THREE
+ * v_mfma_f32_32x32x16_f16 passes per product instead of three bf16 planes and six passes (gemm_h2.hip): x = fp16(S x) + fp16(residual)
+ * carries 22 bits, a b ~ a0 b0 + a0 b1 + a1 b0, fp32 accumulation.  Per product 2^-22 instead of an fp32 multiply's 2^-24; a whole dot
+ * product comes out CLOSER to float64 than on either fp32 engine (the accumulator's roundings dominate; tests/test_gemm_f16x2.py) at
+ * 0.65-0.75 of the time.  Power-of-two scales: per weight row at pack time; per launch for the activations, from a bound the producing
+ * launch leaves in device memory (or one the arithmetic implies) - rows more than five decades below a tensor's largest magnitude keep
+ * fewer digits than fp32 would.  Launches without such a bound (the embedding, calls on caller-supplied activations) stay on the bf16
+ * planes; the attention and the matcher always do.  The current bank's bound is taken at the next mocha_bank_set.
  * Every option that changes which kernels a step launches bumps mocha_generation(ctx). */
 int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
 
 /* y (M,N) = x (M,K) · w (N,K)^T + bias (N, may be NULL): nn.Linear (net/transformer.py:28-32, 57-61) as a stand-alone
  * operator on device pointers, for tests and tooling that want one of the two GEMM engines directly.
- * engine 0: the kernel the path would pick for this shape under the current options; 1: exact-f32 MFMA; 2: bf16 x 3 planes
+ * engine 0: the kernel the path would pick for this shape under the current options; 1: exact-f32 MFMA; 2: bf16 x 3 planes;
+ * 3: fp16 x 2 planes / three passes (option "gemm_f16x2"'s engine; the activation bound is measured on every call; N % 64, K % 32)
  * (MOCHA_ERR_ARG if the shape is outside that engine: K % 32, N % 128, at least 768 row tiles ... see gemm_x3_supports).
  * With engine 2 (or 0 resolving to it) w is packed into the engine's image on every call (w may change between calls);
  * the call synchronises the stream once to free that image.  K % 32 == 0. */

@@ -179,6 +179,22 @@ struct mocha_ctx {
     bool gemm_x3 = true;
     bool attn_x3 = true;               // the Generator's attention as plane products on the bf16 pipe (attention_x3.hip)
     std::map<std::tuple<const float*, int, int>, unsigned short*> x3w;
+    // fp32 GEMMs on the fp16 matrix pipe with two planes / three passes (gemm_h2.hip; option "gemm_f16x2", default off): packed images and
+    // per-row inverse scales of the weights (made on first use), and the activation bounds the launches scale by: device scalars in `amax`,
+    // AMAX_SLOTS per workspace set and stage (0 encoder, 1 decoder, 2 to_mot; a stage zeroes its slots when it starts, so a later stage may
+    // read an earlier one's), `amax_ok` = the slot was really written by a launch of that engine (host-side bookkeeping)
+    bool gemm_h2 = false;
+    struct H2Img { unsigned short* img; float* w_inv; };
+    std::map<std::tuple<const float*, int, int>, H2Img> h2w;
+    static constexpr int AMAX_SLOTS = 40, AMAX_STAGES = 3;
+    static constexpr int AMAX_USED[3] = {2 + 4 * 8, 3 * 8, 5};         // slots a stage can take (depth <= 8): what its start zeroes
+    float* amax = nullptr;                                            // MAX_SETS x AMAX_STAGES x AMAX_SLOTS bounds of H2_AMAX_FLOATS floats (kernels.h), then the two below
+    std::vector<char> amax_ok = std::vector<char>(MAX_SETS * AMAX_STAGES * AMAX_SLOTS, 0);
+    int amax_stage = 0, amax_next = 0;
+    float* amax_in = nullptr;                                         // constant: the bound of an instance-normalised token, (n - 1) / sqrt(n) < 9.5 for 90 tokens
+    float* amax_bank = nullptr; bool amax_bank_ok = false;            // the current bank's encoded rows (mocha_bank_set)
+    const float* amax_enc_of[MAX_SETS] = {nullptr, nullptr, nullptr}; float* amax_enc[MAX_SETS] = {nullptr, nullptr, nullptr};   // encoder output pointer -> its slot
+    const float* amax_dec_of[MAX_SETS] = {nullptr, nullptr, nullptr}; float* amax_dec[MAX_SETS] = {nullptr, nullptr, nullptr};   // decoder output pointer -> its slot
     bool fold_decoder = true;          // decoder key / value projections folded into the query / output weights
     int upsample_split_min = 256;      // windows from which that conv runs as two 2-tap launches (no zero weight blocks)
     bool fold_upsample = true;         // to_mot: the k=5 temporal conv over the x4-upsampled frames as a 3-tap conv over the SOURCE frames with per-phase summed weights
@@ -478,8 +494,87 @@ void x3_drop_images(mocha_ctx* c) {
     c->x3w.clear();
 }
 
+// packed two-plane fp16 image + per-row inverse scales of (W, N, K) for gemm_h2.hip; made on first use like x3_image
+int h2_image(mocha_ctx* c, hipStream_t s, const GemmParams& p, mocha_ctx::H2Img* out) {
+    *out = mocha_ctx::H2Img{nullptr, nullptr};
+    const auto key = std::make_tuple(p.W, p.N, p.K);
+    auto it = c->h2w.find(key);
+    if (it != c->h2w.end()) { *out = it->second; return 0; }
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return 0;
+    float *d = nullptr, *wi = nullptr;
+    int rc = dev_alloc(c, &d, (gemm_h2_packed_elems(p.N, p.K) + 1) / 2);
+    if (!rc) rc = dev_alloc(c, &wi, (size_t)p.N);
+    if (rc) return rc;
+    HIPCHK(c, launch_pack_h2(p.W, p.N, p.K, reinterpret_cast<unsigned short*>(d), wi, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    c->h2w[key] = mocha_ctx::H2Img{reinterpret_cast<unsigned short*>(d), wi};
+    *out = c->h2w[key];
+    return 0;
+}
+void h2_drop_images(mocha_ctx* c) {
+    if (!c->h2w.empty()) c->generation++;
+    for (auto& kv : c->h2w) { dev_free(c, reinterpret_cast<float*>(kv.second.img)); dev_free(c, kv.second.w_inv); }
+    c->h2w.clear();
+}
+// activation bounds of the two-plane fp16 engine (see mocha_ctx::amax): a stage's slots are zeroed when the stage starts
+int amax_alloc(mocha_ctx* c) {                                       // once, when the option is switched on (never inside a capture)
+    if (c->amax) return 0;
+    const size_t n = (size_t)mocha_ctx::MAX_SETS * mocha_ctx::AMAX_STAGES * mocha_ctx::AMAX_SLOTS;
+    int rc = dev_alloc(c, &c->amax, (n + 2) * H2_AMAX_FLOATS);
+    if (rc) return rc;
+    c->amax_in = c->amax + n * H2_AMAX_FLOATS; c->amax_bank = c->amax_in + H2_AMAX_FLOATS;
+    const float k = 9.5f;
+    HIPCHK(c, hipMemset(c->amax, 0, (n + 2) * H2_AMAX_FLOATS * sizeof(float)));
+    HIPCHK(c, hipMemcpy(c->amax_in, &k, sizeof(float), hipMemcpyHostToDevice));
+    return 0;
+}
+int amax_begin(mocha_ctx* c, int stage, hipStream_t s) {
+    if (!c->gemm_h2 || !c->amax) return 0;
+    c->amax_stage = stage; c->amax_next = 0;
+    const size_t base = ((size_t)c->cur * mocha_ctx::AMAX_STAGES + stage) * mocha_ctx::AMAX_SLOTS;
+    std::fill(c->amax_ok.begin() + base, c->amax_ok.begin() + base + mocha_ctx::AMAX_SLOTS, 0);
+    HIPCHK(c, hipMemsetAsync(c->amax + base * H2_AMAX_FLOATS, 0, (size_t)mocha_ctx::AMAX_USED[stage] * H2_AMAX_FLOATS * sizeof(float), s));
+    return 0;
+}
+float* amax_slot(mocha_ctx* c) {                                      // a fresh (zero) bound of the current stage, or null when the engine is off
+    if (!c->gemm_h2 || !c->amax || c->amax_next >= mocha_ctx::AMAX_USED[c->amax_stage]) return nullptr;
+    return c->amax + (((size_t)c->cur * mocha_ctx::AMAX_STAGES + c->amax_stage) * mocha_ctx::AMAX_SLOTS + c->amax_next++) * H2_AMAX_FLOATS;
+}
+ptrdiff_t amax_index(const mocha_ctx* c, const float* slot) {         // slot number inside the arena, or -1 (amax_in / amax_bank / foreign)
+    if (!c->amax || !slot || slot < c->amax) return -1;
+    const ptrdiff_t i = (slot - c->amax) / H2_AMAX_FLOATS;
+    return i < (ptrdiff_t)c->amax_ok.size() ? i : -1;
+}
+const float* amax_use(const mocha_ctx* c, const float* slot) {        // the bound if a launch wrote it (or it is one of the two outside the arena), else null
+    if (!c->gemm_h2 || !slot || !c->amax) return nullptr;
+    const ptrdiff_t i = amax_index(c, slot);
+    if (i >= 0) return c->amax_ok[i] ? slot : nullptr;
+    return slot;                                                     // amax_in / amax_bank: the caller checked
+}
+int amax_measure(mocha_ctx* c, hipStream_t s, const float* x, long long n, float** slot) {      // *slot = max |x| (mocha_absmax)
+    *slot = amax_slot(c);
+    if (!*slot) return 0;
+    LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * n, launch_absmax(x, n, *slot, s));
+    c->amax_ok[amax_index(c, *slot)] = 1;
+    return 0;
+}
+
 int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p0) {
     GemmParams p = p0; p.tile64_below = c->gemm_tile64_below; p.persistent = c->gemm_persistent; p.persistent_max_n = c->gemm_persistent_max_n;
+    if (c->gemm_h2 && p.a_amax && gemm_h2_supports(p)) {
+        mocha_ctx::H2Img img;
+        int rc = h2_image(c, s, p, &img);
+        if (rc) return rc;
+        if (img.img) {
+            GemmParams q = p; q.Wh2 = img.img; q.w_inv = img.w_inv;
+            const double fl = 2.0 * p.M * (double)p.N * p.K;
+            const double by = 4.0 * ((double)p.M * p.K / (p.gather ? p.ntaps : 1) * (p.R) + (double)p.N * p.K + (double)p.M * p.N + (p.residual ? (double)p.M * p.N : 0.0));
+            LAUNCH(c, s, "mocha_gemm_h2", site, fl, by, launch_gemm_h2(q, s));
+            { const ptrdiff_t i = amax_index(c, p.c_amax); if (i >= 0) c->amax_ok[i] = 1; }
+            return 0;
+        }
+    }
     const double flops = 2.0 * p.M * (double)p.N * p.K;
     // algorithmic bytes: every operand once - activations, weights, the output, and the residual matrix where the epilogue adds one
     const double bytes = 4.0 * ((double)p.M * p.K / (p.gather ? p.ntaps : 1) * (p.R) + (double)p.N * p.K + (double)p.M * p.N * p.ksplit +
@@ -590,17 +685,22 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
 }
 
 // one transformer layer's attention output projection + FF (net/transformer.py:91-94), shared by enc/dec
+// ao_amax: a bound on |ao| (device scalar, two-plane fp16 engine) or null; *out_amax: the slot the last GEMM wrote the output's largest magnitude to
 int run_out_ff(mocha_ctx* c, const std::string& p, const float* ao, int inner, const float* resid, int M, int mlp,
-               float* out, hipStream_t s, const char* wo = ".Wo") {
+               float* out, hipStream_t s, const char* wo = ".Wo", const float* ao_amax = nullptr, float** out_amax = nullptr) {
     GemmParams o = plain(ao, inner, DW(c, p + wo), WS(c, "xb"), 256, M, 256, inner);
     o.bias = DW(c, p + ".bo"); o.residual = resid; o.ldr = 256;
+    o.a_amax = amax_use(c, ao_amax); o.c_amax = amax_slot(c);
     GEMM(c, s, "xf.out_proj", o);
     GemmParams f1 = plain(WS(c, "xb"), 256, DW(c, p + ".W1"), WS(c, "hff"), mlp, M, mlp, 256);
     f1.bias = DW(c, p + ".b1"); f1.act = 1;
+    f1.a_amax = amax_use(c, o.c_amax); f1.c_amax = amax_slot(c);
     GEMM(c, s, "xf.ff1", f1);
     GemmParams f2 = plain(WS(c, "hff"), mlp, DW(c, p + ".W2"), out, 256, M, 256, mlp);
     f2.bias = DW(c, p + ".b2"); f2.residual = WS(c, "xb"); f2.ldr = 256;
+    f2.a_amax = amax_use(c, f1.c_amax); f2.c_amax = amax_slot(c);
     GEMM(c, s, "xf.ff2", f2);
+    if (out_amax) *out_amax = f2.c_amax;
     return 0;
 }
 
@@ -608,19 +708,27 @@ int run_out_ff(mocha_ctx* c, const std::string& p, const float* ao, int inner, c
 int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStream_t s) {
     const int M = b * 90, H = c->cfg.enc_heads, DH = c->cfg.enc_dim_head, inner = H * DH;
     const float* x = tokens;
+    // two-plane fp16 engine: every launch scales its activations by a bound on them - the tokens' largest magnitude is measured, every
+    // GEMM's epilogue leaves its output's, and the attention's rows are convex combinations of value rows (a slice of qkv)
+    int rc0 = amax_begin(c, 0, s); if (rc0) return rc0;
+    float* x_amax = nullptr;
+    if (c->gemm_h2) { rc0 = amax_measure(c, s, tokens, (long long)M * 256, &x_amax); if (rc0) return rc0; }
+    c->amax_enc_of[c->cur] = nullptr;
     for (int l = 0; l < c->cfg.enc_depth; ++l) {
         const std::string p = "enc" + std::to_string(l);
         GemmParams q = plain(x, 256, DW(c, p + ".Wqkv"), WS(c, "qkv"), 3 * inner, M, 3 * inner, 256);
+        q.a_amax = amax_use(c, x_amax); q.c_amax = amax_slot(c);
         GEMM(c, s, "enc.qkv", q);
         AttnParams a{WS(c, "qkv"), WS(c, "qkv") + inner, WS(c, "qkv") + 2 * inner, WS(c, "ao"),
                      3 * inner, 3 * inner, 3 * inner, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5)};
         LAUNCH(c, s, attn_kernel_name(c, DH), "enc.attn", 4.0 * b * H * 90.0 * 90 * DH,
                4.0 * M * 4 * inner, attention(c, a, s));
         float* out = (l == c->cfg.enc_depth - 1) ? encoded : WS(c, "xa");
-        int rc = run_out_ff(c, p, WS(c, "ao"), inner, x, M, c->cfg.enc_mlp, out, s);
+        int rc = run_out_ff(c, p, WS(c, "ao"), inner, x, M, c->cfg.enc_mlp, out, s, ".Wo", q.c_amax, &x_amax);
         if (rc) return rc;
         x = out;
     }
+    if (amax_use(c, x_amax)) { c->amax_enc_of[c->cur] = encoded; c->amax_enc[c->cur] = x_amax; }
     return 0;
 }
 
@@ -696,6 +804,18 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
     // Folded decoder at batch size: keys IN(cha) and values cha are the same for every head and layer - the instance norm writes them once
     // as pre-split bf16 plane images (InormExtra::kvimg) and every layer's attention reads those (attention_kv.hip); no fp32 copies
     const bool use_kv = c->fold_decoder && DH == 256 && c->attn_x3 && c->attn_kv && H >= 2 && H % 2 == 0 && (long long)b * H > c->attn_split_max;
+    // two-plane fp16 engine: the attention's rows are convex combinations of the value rows - the matched bank entries (their largest
+    // magnitude is taken at mocha_bank_set) or the character windows this call encoded; the query GEMM's operand is an instance-normalised
+    // token (|z| <= (n - 1) / sqrt(n)); without a bound a launch stays on the bf16 planes
+    { int rc = amax_begin(c, 1, s); if (rc) return rc; }
+    const float* v_amax = nullptr;
+    if (c->gemm_h2) {
+        const float* vsrc = gather_table ? gather_table : cha;
+        if (vsrc && vsrc == c->bank_enc && c->amax_bank_ok) v_amax = c->amax_bank;
+        else if (vsrc && vsrc == c->amax_enc_of[c->cur]) v_amax = amax_use(c, c->amax_enc[c->cur]);
+    }
+    float* x_amax = nullptr;
+    c->amax_dec_of[c->cur] = nullptr;
     if (!cached) {
         InormExtra ex = IEX(c);
         if (gather_table) { ex.table = gather_table; ex.row_idx = gather_idx; ex.table_rows = gather_rows; ex.copy_out = use_kv ? nullptr : WS(c, "sel"); }
@@ -723,6 +843,7 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
             // value projections fold into the query and output weights (exact algebra, net/transformer.py:62-76), so the
             // attention reads IN(cha) / cha directly for every head and two of the four projection GEMMs disappear.
             GemmParams gq = plain(WS(c, "qin"), 256, DW(c, p + ".Wqk"), qb, inner, M, inner, 256);
+            gq.a_amax = c->gemm_h2 ? c->amax_in : nullptr;
             GEMM(c, s, "dec.q", gq);
             if (use_kv) {
                 AttnKvParams a{qb, WS(c, "ao"), reinterpret_cast<const unsigned short*>(WS(c, "kvimg")), inner, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5), c->attn_kv_pairs ? 1 : 0};
@@ -735,8 +856,9 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
                    attention(c, a, s));
             }
             float* out = (l == c->cfg.dec_depth - 1) ? outp : WS(c, "xa");
-            int rc = run_out_ff(c, p, WS(c, "ao"), inner, WS(c, "xad"), M, c->cfg.dec_mlp, out, s, ".Wvo");
+            int rc = run_out_ff(c, p, WS(c, "ao"), inner, WS(c, "xad"), M, c->cfg.dec_mlp, out, s, ".Wvo", use_kv ? nullptr : v_amax, &x_amax);
             if (rc) return rc;
+            if (l == c->cfg.dec_depth - 1 && amax_use(c, x_amax)) { c->amax_dec_of[c->cur] = outp; c->amax_dec[c->cur] = x_amax; }
             x = out;
             continue;
         }
@@ -762,17 +884,28 @@ int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s
     const int V = c->cfg.V, M = b * 90;
     const int nn = (V + 1) * c->cfg.C_in;
     if (denorm && !c->pose_norm) return fail(c, MOCHA_ERR_STATE, "de-normalised output needs mocha_set_pose_norm first");
+    // two-plane fp16 engine: LeakyReLU and the column-normalised adjacency mixes (body_front, joint_expand: non-negative coefficients that sum
+    // to at most one per output) do not raise the largest magnitude, so each GEMM's bound is its predecessor's output bound
+    { int rc = amax_begin(c, 2, s); if (rc) return rc; }
+    float* t_amax = nullptr;
+    if (c->gemm_h2) {
+        if (tokens == c->amax_dec_of[c->cur] && amax_use(c, c->amax_dec[c->cur])) t_amax = c->amax_dec[c->cur];
+        else { int rc = amax_measure(c, s, tokens, (long long)M * 256, &t_amax); if (rc) return rc; }
+    }
     LAUNCH(c, s, "mocha_body_front", "mot.body_front", b * 90.0 * 512 * 12, b * 90.0 * (256 + 512) * 4, launch_body_front(tokens, DW(c, "A_b"), WS(c, "xA"), b * 15, s));
     GemmParams g1 = plain(WS(c, "xA"), 512, DW(c, "mot.Wgb"), WS(c, "t1"), 256, M, 256, 512);
     g1.rowbias = DW(c, "mot.rbb"); g1.rb_mod = 6;
+    g1.a_amax = amax_use(c, t_amax); g1.c_amax = amax_slot(c);
     GEMM(c, s, "mot.gcn_body", g1);
     GemmParams g2 = plain(WS(c, "t1"), 256, DW(c, "mot.Wtb"), WS(c, "x5"), 256, M, 256, 768);
     g2.gather = 1; g2.T_out = 15; g2.V = 6; g2.ntaps = 3; g2.pad = 1; g2.stride = 1; g2.R = 1; g2.T_full = 15;
     g2.tshift = 0; g2.Cc = 256; g2.T_src = 15; g2.bias = DW(c, "mot.btb");
+    g2.a_amax = amax_use(c, g1.c_amax); g2.c_amax = amax_slot(c);
     GEMM(c, s, "mot.tcn_body", g2);
     // joint block gcn conv at body-part resolution (upsample + unpool only copy rows):  lrelu -> 256 -> 3*64
     GemmParams g3 = plain(WS(c, "x5"), 256, DW(c, "mot.Wg2"), WS(c, "g"), 192, M, 192, 256);
     g3.a_lrelu = 1; g3.bias = DW(c, "mot.bg2");
+    g3.a_amax = amax_use(c, g2.c_amax); g3.c_amax = amax_slot(c);
     GEMM(c, s, "mot.gcn_joint", g3);
     LAUNCH(c, s, "mocha_joint_expand", "mot.joint_expand", b * 15.0 * V * 64 * 36, b * 15.0 * (6 * 192 + V * 64) * 4, launch_joint_expand(WS(c, "g"), DW(c, "AU"), WS(c, "y2c"), b * 15, V, s));
     // temporal conv k=5 over the x4-upsampled frames, read through the gather (t >> 2)
@@ -781,6 +914,7 @@ int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s
         GemmParams g4 = plain(WS(c, "y2c"), 64, DW(c, "mot.Wt2p"), WS(c, "z"), 256, b * 15 * V, 256, 192);
         g4.gather = 1; g4.T_out = 15; g4.V = V; g4.ntaps = 3; g4.pad = 2; g4.stride = 4; g4.tstep = 4; g4.R = 1; g4.T_full = 60;
         g4.tshift = 2; g4.Cc = 64; g4.T_src = 15; g4.bias = DW(c, "mot.bt2p");
+        g4.a_amax = amax_use(c, g3.c_amax);
         if (b >= c->upsample_split_min) {
             // large batches: two launches of two taps each instead of one with a third of its weight blocks zero
             GemmParams ga = g4; ga.W = DW(c, "mot.Wt2a"); ga.N = 128; ga.K = 128; ga.ntaps = 2;
@@ -1098,6 +1232,7 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = gemm_init();
     if (e == hipSuccess) e = gemm_x3_init();
+    if (e == hipSuccess) e = gemm_h2_init();
     if (e == hipSuccess) e = attention_x3_init();
     if (e == hipSuccess) e = match_mfma_init();
     if (e == hipSuccess) e = match_refine_init();
@@ -1162,6 +1297,7 @@ int mocha_finalize_weights(mocha_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
     x3_drop_images(c);                              // re-loaded weights keep their device addresses
+    h2_drop_images(c);
     const Skeleton& sk = c->sk;
     const int V = sk.V;
     int rc = 0;
@@ -1448,6 +1584,7 @@ int mocha_decoder(mocha_ctx* c, const float* src_enc, const float* cha_enc, int 
     int rc = ready(c, B); if (rc) return rc;
     NEED_PTRS(c, B, "mocha_decoder", src_enc, cha_enc, out);
     const size_t ts = 90 * 256;
+    for (int i = 0; i < mocha_ctx::MAX_SETS; ++i) c->amax_enc_of[i] = c->amax_dec_of[i] = nullptr;     // external activations: no carried bounds
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         return run_decoder(c, src_enc + b0 * ts, cha_enc + b0 * ts, b, out + b0 * ts, s);
     });
@@ -1473,6 +1610,7 @@ int mocha_to_mot(mocha_ctx* c, const float* tokens, int B, float* Y, void* strea
     int rc = ready(c, B); if (rc) return rc;
     NEED_PTRS(c, B, "mocha_to_mot", tokens, Y);
     const size_t ts = 90 * 256, ys = (size_t)60 * c->cfg.V * c->cfg.C_in;
+    for (int i = 0; i < mocha_ctx::MAX_SETS; ++i) c->amax_enc_of[i] = c->amax_dec_of[i] = nullptr;     // external activations: no carried bounds
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         return run_to_mot(c, tokens + b0 * ts, b, Y + b0 * ys, s);
     });
@@ -1551,6 +1689,15 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
         LAUNCH(c, s, "mocha_rownorm2_bf16", "bank.norms", 2.0 * N * D, 2.0 * N * D, launch_rownorm2_bf16(c->bank_bf16, c->bank_norm, N, (int)D, s));
     } else {
         LAUNCH(c, s, "mocha_rownorm2", "bank.norms", 2.0 * N * D, 4.0 * N * D, launch_rownorm2(c->bank_cnt, c->bank_center, c->bank_norm, N, (int)D, s));
+    }
+    // two-plane fp16 engine: the decoder's attention rows are bounded by the matched entries' largest magnitude, taken once here
+    if (current) {
+        c->amax_bank_ok = false;
+        if (c->gemm_h2) {
+            HIPCHK(c, hipMemsetAsync(c->amax_bank, 0, H2_AMAX_FLOATS * sizeof(float), s));
+            LAUNCH(c, s, "mocha_absmax", "bank.absmax", 0.0, 4.0 * N * D, launch_absmax(c->bank_enc, (long long)N * D, c->amax_bank, s));
+            c->amax_bank_ok = true;
+        }
     }
     // few-query matching against a large fp32 bank scans its centred bf16 copy (half the bytes) and re-ranks exactly
     if (current) c->bank16f_valid = false;
@@ -2166,6 +2313,7 @@ int mocha_cvae_finalize(mocha_ctx* c) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipDeviceSynchronize());
     x3_drop_images(c);
+    h2_drop_images(c);
     for (auto& kv : c->cvae_host) {
         int rc = upload_to(c, c->cw, c->cwsize, kv.first, kv.second.data); if (rc) return rc;
     }
@@ -2443,6 +2591,13 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     }
     if (n == "attention_kv_pairs") { c->attn_kv_pairs = value != 0; c->generation++; return 0; }
     if (n == "gemm_bf16x3") { c->gemm_x3 = value != 0; c->generation++; return 0; }
+    if (n == "gemm_f16x2") {                        // encoder / decoder / to_mot GEMMs on two fp16 planes, three passes (gemm_h2.hip); the bank's bound: next mocha_bank_set
+        HIPCHK(c, hipSetDevice(c->device));
+        if (value) { int rc = amax_alloc(c); if (rc) return rc; }
+        c->gemm_h2 = value != 0; c->amax_bank_ok = false;
+        for (int i = 0; i < mocha_ctx::MAX_SETS; ++i) c->amax_enc_of[i] = c->amax_dec_of[i] = nullptr;
+        c->generation++; return 0;
+    }
     if (n == "attention_bf16x3") { c->attn_x3 = value != 0; c->generation++; return 0; }
     return fail(c, MOCHA_ERR_ARG, "unknown option '%s'", name);
 }
@@ -2450,13 +2605,29 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
 int mocha_linear(mocha_ctx* c, const float* x, const float* w, const float* bias, float* y, int64_t M, int N, int K, int engine,
                  void* stream) {
     if (!c || !x || !w || !y) return fail(c, MOCHA_ERR_ARG, "null argument");
-    if (M < 0 || N < 1 || K < 32 || K % 32 != 0 || M > (1ll << 30) || engine < 0 || engine > 2)
-        return fail(c, MOCHA_ERR_ARG, "mocha_linear: M=%lld N=%d K=%d engine=%d (K %% 32 == 0, engine 0..2)", (long long)M, N, K, engine);
+    if (M < 0 || N < 1 || K < 32 || K % 32 != 0 || M > (1ll << 30) || engine < 0 || engine > 3)
+        return fail(c, MOCHA_ERR_ARG, "mocha_linear: M=%lld N=%d K=%d engine=%d (K %% 32 == 0, engine 0..3)", (long long)M, N, K, engine);
     if (M == 0) return 0;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     GemmParams p = plain(x, K, w, y, N, (int)M, N, K);
     p.bias = bias;
+    if (engine == 3) {                              // two fp16 planes, three passes: the activation bound is measured here (mocha_absmax)
+        if (!gemm_h2_supports(p)) return fail(c, MOCHA_ERR_ARG, "mocha_linear: M=%lld N=%d K=%d is outside the f16x2 engine", (long long)M, N, K);
+        void* img = nullptr; float* aux = nullptr;       // aux: [N] inverse weight scales, then the activation bound (H2_AMAX_FLOATS)
+        HIPCHK(c, hipMalloc(&img, gemm_h2_packed_elems(N, K) * sizeof(unsigned short)));
+        const size_t n4 = ((size_t)N + 3) / 4 * 4;
+        hipError_t e = hipMalloc((void**)&aux, (n4 + H2_AMAX_FLOATS) * sizeof(float));
+        if (e == hipSuccess) e = hipMemsetAsync(aux + n4, 0, H2_AMAX_FLOATS * sizeof(float), s);
+        if (e == hipSuccess) e = launch_pack_h2(w, N, K, (unsigned short*)img, aux, s);
+        if (e == hipSuccess) e = launch_absmax(x, (long long)M * K, aux + n4, s);
+        p.Wh2 = (const unsigned short*)img; p.w_inv = aux; p.a_amax = aux + n4;
+        if (e == hipSuccess) e = launch_gemm_h2(p, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(img); if (aux) (void)hipFree(aux);
+        if (e != hipSuccess) return fail(c, MOCHA_ERR_HIP, "mocha_linear: %s", hipGetErrorString(e));
+        return 0;
+    }
     const bool x3 = engine == 2 || (engine == 0 && c->gemm_x3 && gemm_x3_supports(p));
     if (!x3) {
         const double flops = 2.0 * M * (double)N * K;

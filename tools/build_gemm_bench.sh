@@ -7,10 +7,10 @@ mkdir -p tools/bin
 H="/opt/rocm/bin/hipcc --offload-arch=gfx950"
 $H -O3 -std=c++17 -w -I mocha_sigasia2023_amd/csrc -c tools/gemm_bench.hip -o tools/bin/gemm_bench.o
 C=mocha_sigasia2023_amd/csrc
-$H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_x3.o -o tools/bin/gemm_bench
+$H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_x3.o $C/gemm_h2.o -o tools/bin/gemm_bench
 $H -O3 -fPIC -std=c++17 -w -I $C -c tools/experiments/gemm_f16x2_r05.hip -o tools/bin/gemm_f16x2.o
-$H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2.o -o tools/bin/gemm_bench_f16
+$H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2.o $C/gemm_h2.o -o tools/bin/gemm_bench_f16
 if [ -n "$1" ]; then
   $H -O3 -fPIC -std=c++17 -w "$@" -c $C/gemm_x3.hip -o tools/bin/gemm_x3_abl.o
-  $H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_x3_abl.o -o tools/bin/gemm_bench_abl
+  $H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_x3_abl.o $C/gemm_h2.o -o tools/bin/gemm_bench_abl
 fi

@@ -27,8 +27,8 @@ int main(int argc, char** argv) {
     int B = argc > 1 ? atoi(argv[1]) : 585;
     int iters = argc > 2 ? atoi(argv[2]) : 20;
     int check = argc > 3 ? atoi(argv[3]) : 1;
-    int mode = argc > 4 ? atoi(argv[4]) : 0;      // 0 = exact f32 MFMA (gemm_f32.hip), 36 = bf16 x 3 planes (gemm_x3.hip)
-    CK(gemm_init()); CK(gemm_x3_init());
+    int mode = argc > 4 ? atoi(argv[4]) : 0;      // 0 = exact f32 MFMA (gemm_f32.hip), 36 = bf16 x 3 planes (gemm_x3.hip), 22 = fp16 x 2 planes (gemm_h2.hip)
+    CK(gemm_init()); CK(gemm_x3_init()); CK(gemm_h2_init());
     std::vector<Shape> shapes = {
         {"enc.qkv      ", B * 90, 1536, 256, 0},
         {"xf.out512    ", B * 90, 256, 512, 0},
@@ -86,7 +86,21 @@ int main(int argc, char** argv) {
         if (getenv("MOCHA_BENCH_PERSISTENT")) p.persistent = atoi(getenv("MOCHA_BENCH_PERSISTENT"));      // 0: every launch on the one-shot grid (mocha_gemm_x3)
         if (getenv("MOCHA_BENCH_ALRELU")) p.a_lrelu = 1;               // LeakyReLU on the A operand as it is split: what an A-operand prologue costs the K loop
         const bool x3 = mode == 36 && gemm_x3_supports(p);
-        auto run = [&]() { return x3 ? launch_gemm_x3(p, 0) : launch_gemm(p, 0); };
+        const bool h2 = mode == 22 && gemm_h2_supports(p);
+        float* daux = nullptr;                                         // [N] inverse weight scales | bias [N] | activation bound | output bound (H2_AMAX_FLOATS each)
+        float* dres = nullptr;
+        const bool epi = getenv("MOCHA_BENCH_EPI") != nullptr;        // bias + residual epilogue (out_proj / ff2); the float64 check is skipped
+        CK(hipMalloc(&daux, ((size_t)2 * sh.N + 2 * H2_AMAX_FLOATS) * 4)); CK(hipMemset(daux, 0, ((size_t)2 * sh.N + 2 * H2_AMAX_FLOATS) * 4));
+        if (epi) { CK(hipMalloc(&dres, nc * 4)); CK(hipMemset(dres, 0, nc * 4)); p.bias = daux + sh.N; p.residual = dres; p.ldr = sh.N; }
+        if (h2) {
+            unsigned short* dWh = nullptr;
+            CK(hipMalloc(&dWh, gemm_h2_packed_elems(sh.N, sh.K) * 2)); CK(launch_pack_h2(dW, sh.N, sh.K, dWh, daux, 0));
+            CK(launch_absmax(dA, (long long)na, daux + 2 * sh.N, 0));
+            p.Wh2 = dWh; p.w_inv = daux; p.a_amax = daux + 2 * sh.N;
+            if (getenv("MOCHA_BENCH_CAMAX")) p.c_amax = daux + 2 * sh.N + H2_AMAX_FLOATS;      // the epilogue's atomic maximum of what it stores
+        }
+        const bool rezero = h2 && p.c_amax && getenv("MOCHA_BENCH_REZERO");      // the output bound starts from zero at every launch, as in the pipeline
+        auto run = [&]() { if (rezero) (void)hipMemsetAsync(p.c_amax, 0, H2_AMAX_FLOATS * 4, 0); return h2 ? launch_gemm_h2(p, 0) : x3 ? launch_gemm_x3(p, 0) : launch_gemm(p, 0); };
         long long* dstamp = nullptr;
         if (getenv("MOCHA_BENCH_STAMPS") && x3) { CK(hipMalloc(&dstamp, (size_t)65536 * 32)); CK(hipMemset(dstamp, 0, (size_t)65536 * 32)); p.wsub = (const float*)dstamp; }
         for (int i = 0; i < 3; ++i) CK(run());
@@ -97,7 +111,7 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
         double tf = 2.0 * sh.M * sh.N * sh.K / (ms * 1e-3) / 1e12;
         double err = -1, rms = -1;
-        if (check && !sh.gather && p.ksplit == 1 && (double)sh.M * sh.N * sh.K < 3e11) {
+        if (check && !epi && !sh.gather && p.ksplit == 1 && (double)sh.M * sh.N * sh.K < 3e11) {
             CK(hipMalloc(&dR, nc * 8));
             hipLaunchKernelGGL(ref_gemm, dim3((sh.N + 15) / 16, (sh.M + 15) / 16), dim3(16, 16), 0, 0, dA, dW, dR, sh.M, sh.N, sh.K);
             std::vector<float> hc(nc); std::vector<double> hr(nc);
@@ -140,8 +154,8 @@ int main(int argc, char** argv) {
                    n, pro / n, loop / n, loop / n / (sh.K / 16), epi / n, life_us, (pro + loop + epi) / n / life_us / 1e3, span_us, n * life_us / 768.0 / span_us);
             CK(hipFree(dstamp));
         }
-        printf("%s M=%7d N=%5d K=%5d  %9.1f us  %7.2f TFLOP/s  (%.1f%% of 157.3)  %s maxerr=%.3g rms=%.3g\n", sh.name, sh.M, sh.N, sh.K, ms * 1e3, tf, tf / 157.3 * 100, x3 ? "x3 " : "f32", err, rms);
-        CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); if (dWs) CK(hipFree(dWs));
+        printf("%s M=%7d N=%5d K=%5d  %9.1f us  %7.2f TFLOP/s  (%.1f%% of 157.3)  %s maxerr=%.3g rms=%.3g\n", sh.name, sh.M, sh.N, sh.K, ms * 1e3, tf, tf / 157.3 * 100, h2 ? "h2 " : x3 ? "x3 " : "f32", err, rms);
+        CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); if (dWs) CK(hipFree(dWs)); CK(hipFree(daux)); if (dres) CK(hipFree(dres)); if (p.Wh2) CK(hipFree((void*)p.Wh2));
     }
     return 0;
 }

@@ -11,6 +11,8 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 model = Generator(device=dev).load_state_dict(synthetic_state_dict(1777, 1.0)).eval()
 if a.chunk: model.reserve(a.chunk)
+for kv in filter(None, os.environ.get("MOCHA_OPTS", "").split(",")):           # e.g. MOCHA_OPTS=gemm_f16x2=1
+    k, v = kv.split("="); model.set_option(k, int(v))
 W = a.windows
 src = torch.from_numpy(synthetic.pose_windows(1, W)).to(dev); cha = torch.from_numpy(synthetic.pose_windows(2, W)).to(dev)
 m_, s_ = synthetic.cnt_norm(7); mean, std = torch.from_numpy(m_).to(dev), torch.from_numpy(s_).to(dev)
