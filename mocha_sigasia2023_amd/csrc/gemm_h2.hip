@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void mocha_h2_wscale(const float* __restrict__
     if (lane == 0) { float inv; (void)h2_scale(m, &inv); w_inv[n] = inv; }
 }
 
-// largest magnitude of n floats -> out (a bound as described in kernels.h: H2_AMAX_FLOATS, zeroed by the caller)
-__global__ __launch_bounds__(256) void mocha_absmax(const float* __restrict__ x, long long n, float* __restrict__ out) {
+// mul * (largest magnitude of n floats) + add -> out (a bound as described in kernels.h: H2_AMAX_FLOATS, zeroed by the caller; mul > 0, add >= 0:
+// the bound of a linear map of x with row L1 norm <= mul and bias magnitudes <= add)
+__global__ __launch_bounds__(256) void mocha_absmax(const float* __restrict__ x, long long n, float* __restrict__ out, float mul, float add) {
     float m = 0.f;
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
@@ -115,13 +116,14 @@ __global__ __launch_bounds__(256) void mocha_absmax(const float* __restrict__ x,
     __shared__ float wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) h2_amax_store(out, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])));
+    if (threadIdx.x == 0) h2_amax_store(out, fmaf(mul, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])), add));
 }
-hipError_t launch_absmax(const float* x, long long n, float* out, hipStream_t s) {
+hipError_t launch_absmax(const float* x, long long n, float* out, hipStream_t s, float mul, float add) {
     if (n <= 0) return hipSuccess;
     if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return hipErrorInvalidValue;
     const long long wgs = std::min<long long>((n / 4 + 255) / 256 + 1, 1024);
-    hipLaunchKernelGGL(mocha_absmax, dim3((unsigned)wgs), dim3(256), 0, s, x, n, out);
+    if (!(mul > 0.f) || !(add >= 0.f)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mocha_absmax, dim3((unsigned)wgs), dim3(256), 0, s, x, n, out, mul, add);
     return hipGetLastError();
 }
 

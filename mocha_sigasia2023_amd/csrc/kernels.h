@@ -72,7 +72,7 @@ bool gemm_h2_supports(const GemmParams& p);
 size_t gemm_h2_packed_elems(int N, int K);
 hipError_t launch_pack_h2(const float* W, int N, int K, unsigned short* out, float* w_inv /*N*/, hipStream_t s);
 hipError_t launch_gemm_h2(const GemmParams& p, hipStream_t s);      // needs p.Wh2, p.w_inv, p.a_amax
-hipError_t launch_absmax(const float* x, long long n, float* out /*H2_AMAX_FLOATS, zeroed by the caller*/, hipStream_t s);
+hipError_t launch_absmax(const float* x, long long n, float* out /*H2_AMAX_FLOATS, zeroed by the caller*/, hipStream_t s, float mul = 1.f, float add = 0.f);   // out = max(out, mul * max|x| + add)
 
 
 // ---------------------------------------------------------------------------------------

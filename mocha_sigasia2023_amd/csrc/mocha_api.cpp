@@ -186,8 +186,8 @@ struct mocha_ctx {
     bool gemm_h2 = false;
     struct H2Img { unsigned short* img; float* w_inv; };
     std::map<std::tuple<const float*, int, int>, H2Img> h2w;
-    static constexpr int AMAX_SLOTS = 40, AMAX_STAGES = 3;
-    static constexpr int AMAX_USED[3] = {2 + 4 * 8, 3 * 8, 5};         // slots a stage can take (depth <= 8): what its start zeroes
+    static constexpr int AMAX_SLOTS = 40, AMAX_STAGES = 4;             // stages: 0 encoder, 1 decoder, 2 to_mot, 3 embedding
+    static constexpr int AMAX_USED[4] = {2 + 4 * 8, 3 * 8, 5, 5};      // slots a stage can take (depth <= 8): what its start zeroes
     float* amax = nullptr;                                            // MAX_SETS x AMAX_STAGES x AMAX_SLOTS bounds of H2_AMAX_FLOATS floats (kernels.h), then the two below
     std::vector<char> amax_ok = std::vector<char>(MAX_SETS * AMAX_STAGES * AMAX_SLOTS, 0);
     int amax_stage = 0, amax_next = 0;
@@ -195,6 +195,8 @@ struct mocha_ctx {
     float* amax_bank = nullptr; bool amax_bank_ok = false;            // the current bank's encoded rows (mocha_bank_set)
     const float* amax_enc_of[MAX_SETS] = {nullptr, nullptr, nullptr}; float* amax_enc[MAX_SETS] = {nullptr, nullptr, nullptr};   // encoder output pointer -> its slot
     const float* amax_dec_of[MAX_SETS] = {nullptr, nullptr, nullptr}; float* amax_dec[MAX_SETS] = {nullptr, nullptr, nullptr};   // decoder output pointer -> its slot
+    const float* amax_tok_of[MAX_SETS] = {nullptr, nullptr, nullptr}; float* amax_tok[MAX_SETS] = {nullptr, nullptr, nullptr};   // embedding output pointer -> its slot
+    float emb_l1 = 0.f, emb_bmax = 0.f;                               // largest row L1 norm / bias magnitude of the input 1x1 conv (model.py:44): |conv(x)| <= emb_l1 max|x| + emb_bmax
     bool fold_decoder = true;          // decoder key / value projections folded into the query / output weights
     int upsample_split_min = 256;      // windows from which that conv runs as two 2-tap launches (no zero weight blocks)
     bool fold_upsample = true;         // to_mot: the k=5 temporal conv over the x4-upsampled frames as a 3-tap conv over the SOURCE frames with per-phase summed weights
@@ -620,6 +622,19 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     const int V = c->cfg.V;
     const int nn = (V + 1) * c->cfg.C_in;
     if (raw && !c->pose_norm) return fail(c, MOCHA_ERR_STATE, "raw input needs mocha_set_pose_norm first");
+    // two-plane fp16 engine (z-scored input, fused path): |u| <= |conv1(x)| <= emb_l1 max|x| + emb_bmax (LeakyReLU, the column-normalised
+    // adjacency x pool mix and the 4-frame means do not raise a magnitude) - one pass over the poses gives the first launch's bound,
+    // every GEMM's epilogue the next one's; the tokens' bound goes on to the encoder
+    { int rc = amax_begin(c, 3, s); if (rc) return rc; }
+    float* u_amax = nullptr;
+    c->amax_tok_of[c->cur] = nullptr;
+    if (c->gemm_h2 && !raw && c->fold_joint && c->gemm_x3 && c->embed_sums && c->emb_l1 > 0.f && (u_amax = amax_slot(c))) {
+        const long long per = 60ll * V * c->cfg.C_in;
+        LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * b * per, launch_absmax(X, b * per, u_amax, s, c->emb_l1, c->emb_bmax));
+        if (X2 && b2 > 0) LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * b2 * per, launch_absmax(X2, b2 * per, u_amax, s, c->emb_l1, c->emb_bmax));
+        c->amax_ok[amax_index(c, u_amax)] = 1;
+    }
+    float* x5_amax = nullptr;
     if (c->fold_joint && c->gemm_x3 && c->embed_sums) {
         // conv1 + lrelu + adjacency + joint->part pool, and the 4-frame sums of the five taps, in one kernel: the frame rows stay in LDS
         LAUNCH(c, s, "mocha_embed_sums_x3", "emb.front_sums", b * 60.0 * V * 64 * (2.0 * 15 + 2.0 * 18) + b * 90.0 * 960 * 4,
@@ -635,6 +650,7 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
         }
         GemmParams gf = plain(WS(c, "u"), 960, DW(c, "emb.Wc"), WS(c, "x5"), 256, b * 90, 256, 960);
         gf.rowbias = DW(c, "emb.rbc"); gf.rb_mod = 6;
+        gf.a_amax = amax_use(c, u_amax); gf.c_amax = x5_amax = amax_slot(c);
         GEMM(c, s, "emb.joint_block", gf);
     } else {
     // conv1 + lrelu + adjacency + joint->part pool (commuted)                  model.py:44-46
@@ -675,12 +691,15 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     LAUNCH(c, s, "mocha_body_front", "emb.body_front", b * 90.0 * 512 * 12, b * 90.0 * (256 + 512) * 4, launch_body_front(WS(c, "x5"), DW(c, "A_b"), WS(c, "xA"), b * 15, s));
     GemmParams g3 = plain(WS(c, "xA"), 512, DW(c, "emb.Wgb"), WS(c, "t1"), 256, b * 90, 256, 512);
     g3.rowbias = DW(c, "emb.rbb"); g3.rb_mod = 6;
+    g3.a_amax = amax_use(c, x5_amax); g3.c_amax = amax_slot(c);        // body_front: LeakyReLU + a column-normalised mix of x5
     GEMM(c, s, "emb.gcn_body", g3);
     GemmParams g4 = plain(WS(c, "t1"), 256, DW(c, "emb.Wtb"), tokens, 256, b * 90, 256, 768);
     g4.gather = 1; g4.T_out = 15; g4.V = 6; g4.ntaps = 3; g4.pad = 1; g4.stride = 1; g4.R = 1; g4.T_full = 15;
     g4.tshift = 0; g4.Cc = 256; g4.T_src = 15; g4.bias = DW(c, "emb.btb");
     if (add_pos) { g4.rowbias = DW(c, "pos_emb"); g4.rb_mod = 90; }           // model.py:88
+    g4.a_amax = amax_use(c, g3.c_amax); g4.c_amax = amax_slot(c);
     GEMM(c, s, "emb.tcn_body", g4);
+    if (amax_use(c, g4.c_amax)) { c->amax_tok_of[c->cur] = tokens; c->amax_tok[c->cur] = g4.c_amax; }
     return 0;
 }
 
@@ -712,7 +731,10 @@ int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStr
     // GEMM's epilogue leaves its output's, and the attention's rows are convex combinations of value rows (a slice of qkv)
     int rc0 = amax_begin(c, 0, s); if (rc0) return rc0;
     float* x_amax = nullptr;
-    if (c->gemm_h2) { rc0 = amax_measure(c, s, tokens, (long long)M * 256, &x_amax); if (rc0) return rc0; }
+    if (c->gemm_h2) {
+        if (tokens == c->amax_tok_of[c->cur] && amax_use(c, c->amax_tok[c->cur])) x_amax = c->amax_tok[c->cur];      // the embedding's last GEMM left it
+        else { rc0 = amax_measure(c, s, tokens, (long long)M * 256, &x_amax); if (rc0) return rc0; }
+    }
     c->amax_enc_of[c->cur] = nullptr;
     for (int l = 0; l < c->cfg.enc_depth; ++l) {
         const std::string p = "enc" + std::to_string(l);
@@ -1331,6 +1353,17 @@ int mocha_finalize_weights(mocha_ctx* c) {
     up("pos_emb", W(c, "pos_emb"));
     up("emb.W1", W(c, "mot_embedding.1.weight"));
     up("emb.b1", W(c, "mot_embedding.1.bias"));
+    {
+        const auto& w1 = W(c, "mot_embedding.1.weight"); const auto& b1 = W(c, "mot_embedding.1.bias");
+        const size_t cin = w1.size() / b1.size();
+        double l1 = 0, bm = 0;
+        for (size_t o = 0; o < b1.size(); ++o) {
+            double a = 0;
+            for (size_t i = 0; i < cin; ++i) a += std::fabs((double)w1[o * cin + i]);
+            l1 = std::max(l1, a); bm = std::max(bm, std::fabs((double)b1[o]));
+        }
+        c->emb_l1 = (float)(l1 * (1.0 + 1e-6)); c->emb_bmax = (float)(bm * (1.0 + 1e-6));       // rounded up: a bound
+    }
     up("emb.Wg", repack_gcn_adjfirst(W(c, "mot_embedding.2.blk.gcn.conv.weight"), 3, 256, 64));
     {
         const auto& bg = W(c, "mot_embedding.2.blk.gcn.conv.bias");
@@ -1540,6 +1573,7 @@ int mocha_encoder(mocha_ctx* c, const float* tokens, int B, float* encoded, void
     int rc = ready(c, B); if (rc) return rc;
     NEED_PTRS(c, B, "mocha_encoder", tokens, encoded);
     const size_t ts = 90 * 256;
+    for (int i = 0; i < mocha_ctx::MAX_SETS; ++i) c->amax_tok_of[i] = nullptr;      // caller-supplied tokens (the reference adds pos_emb itself): measured, not carried
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         return run_encoder(c, tokens + b0 * ts, b, encoded + b0 * ts, s);
     });
@@ -1584,7 +1618,7 @@ int mocha_decoder(mocha_ctx* c, const float* src_enc, const float* cha_enc, int 
     int rc = ready(c, B); if (rc) return rc;
     NEED_PTRS(c, B, "mocha_decoder", src_enc, cha_enc, out);
     const size_t ts = 90 * 256;
-    for (int i = 0; i < mocha_ctx::MAX_SETS; ++i) c->amax_enc_of[i] = c->amax_dec_of[i] = nullptr;     // external activations: no carried bounds
+    for (int i = 0; i < mocha_ctx::MAX_SETS; ++i) c->amax_enc_of[i] = c->amax_dec_of[i] = c->amax_tok_of[i] = nullptr;     // external activations: no carried bounds
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         return run_decoder(c, src_enc + b0 * ts, cha_enc + b0 * ts, b, out + b0 * ts, s);
     });
@@ -1610,7 +1644,7 @@ int mocha_to_mot(mocha_ctx* c, const float* tokens, int B, float* Y, void* strea
     int rc = ready(c, B); if (rc) return rc;
     NEED_PTRS(c, B, "mocha_to_mot", tokens, Y);
     const size_t ts = 90 * 256, ys = (size_t)60 * c->cfg.V * c->cfg.C_in;
-    for (int i = 0; i < mocha_ctx::MAX_SETS; ++i) c->amax_enc_of[i] = c->amax_dec_of[i] = nullptr;     // external activations: no carried bounds
+    for (int i = 0; i < mocha_ctx::MAX_SETS; ++i) c->amax_enc_of[i] = c->amax_dec_of[i] = c->amax_tok_of[i] = nullptr;     // external activations: no carried bounds
     return for_chunks(c, B, (hipStream_t)stream, [&](int b0, int b, hipStream_t s) -> int {
         return run_to_mot(c, tokens + b0 * ts, b, Y + b0 * ys, s);
     });
@@ -2595,7 +2629,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
         HIPCHK(c, hipSetDevice(c->device));
         if (value) { int rc = amax_alloc(c); if (rc) return rc; }
         c->gemm_h2 = value != 0; c->amax_bank_ok = false;
-        for (int i = 0; i < mocha_ctx::MAX_SETS; ++i) c->amax_enc_of[i] = c->amax_dec_of[i] = nullptr;
+        for (int i = 0; i < mocha_ctx::MAX_SETS; ++i) c->amax_enc_of[i] = c->amax_dec_of[i] = c->amax_tok_of[i] = nullptr;
         c->generation++; return 0;
     }
     if (n == "attention_bf16x3") { c->attn_x3 = value != 0; c->generation++; return 0; }

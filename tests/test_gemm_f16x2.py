@@ -105,7 +105,7 @@ def test_rejected_shapes():
 @pytest.mark.timeout(900)
 def test_network_with_the_option_on():
     """Demo pair at full size (585 + 585 windows), against a bank, and Generator.forward: the option moves the encoder's, decoder's and
-    to_mot's plane GEMMs to mocha_gemm_h2; same matches, poses within 2e-5 of the default engine."""
+    to_mot's (and, for z-scored input, the embedding's) plane GEMMs to mocha_gemm_h2; same matches, poses within 2e-5 of the default engine."""
     W, V = 585, 22
     sd = weights.synthetic_state_dict(1777, 1.0, "mixamo")
     model = Generator(layout="mixamo", device=dev()).load_state_dict(sd).eval()
@@ -122,7 +122,8 @@ def test_network_with_the_option_on():
         assert ("mocha_gemm_h2" in names) == bool(flag), names
         if flag:
             sites = {k.split("|")[0] for k in prof["sites"] if k.endswith("|mocha_gemm_h2")}
-            assert {"enc.qkv", "xf.out_proj", "xf.ff1", "xf.ff2", "dec.q", "mot.gcn_body", "mot.tcn_body", "mot.gcn_joint", "mot.tcn_joint"} <= sites, sites
+            assert {"emb.joint_block", "emb.gcn_body", "emb.tcn_body", "enc.qkv", "xf.out_proj", "xf.ff1", "xf.ff2", "dec.q", "mot.gcn_body", "mot.tcn_body",
+                    "mot.gcn_joint", "mot.tcn_joint"} <= sites, sites
         enc, _, nm = model.encode(cha, mean, std)
         bank = ContextBank(model, nm, enc)
         Yb, ib = bank.characterize(src, mean, std, return_index=True)

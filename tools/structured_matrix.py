@@ -39,8 +39,9 @@ ENGINE_SETS = {
     "gemm_f32": {"gemm_bf16x3": 0},
     "all_f32": {"gemm_bf16x3": 0, "attention_bf16x3": 0},
     "r4_gemm_f32": {"adain_closed_form": 0, "style_f64": 0, "gemm_bf16x3": 0},
+    "f16x2": {"gemm_f16x2": 1},          # two fp16 planes / three passes (gemm_h2.hip); needs --windows >= 40 (smaller batches run the few-rows kernels)
 }
-ALL_OPTIONS = {"adain_closed_form": 1, "style_f64": 1, "gemm_bf16x3": 1, "attention_bf16x3": 1}
+ALL_OPTIONS = {"adain_closed_form": 1, "style_f64": 1, "gemm_bf16x3": 1, "attention_bf16x3": 1, "gemm_f16x2": 0}
 
 
 def _spiky(r, n):
