@@ -36,6 +36,9 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef H2_WPE
+#define H2_WPE 3          // workgroups (of four waves) per CU the register budget is set for; 4 was tried: see tools/experiments/README.md
+#endif
 static constexpr int NPL = 2;                            // planes per operand
 __device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) { const f32x2 v = {a, b}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, h16x2)); }
 __device__ __forceinline__ float f16_lo(unsigned p) { return (float)__builtin_bit_cast(h16x2, p)[0]; }
@@ -179,7 +182,7 @@ __device__ __forceinline__ void h2_amax_out(float* c_amax, float m, int lane, in
 // block), where a padded 128-wide tile would idle half the pipe.  (A 128 x 256 tile, TN = 4, was measured and not kept:
 // tools/experiments/gemm_x3_tile_128x256.patch.txt.)
 template <bool LRELU, bool GATHER, int TM, int TN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void mocha_gemm_h2(GemmParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_WPE))) void mocha_gemm_h2(GemmParams p) {
     constexpr int TILE_M = TM * 64;
     constexpr int TILE_N = XT<TN>::TILE_N, B_HALF = XT<TN>::B_HALF, B_PLANE = XT<TN>::B_PLANE, STAGE = XT<TN>::STAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned short h2_sm[];          // [2][STAGE]

@@ -164,3 +164,52 @@ def test_parity_with_the_oracle(gain, layout):
           f"|oracle32 - f64| {float((Y32 - Y64).abs().max()):.2e} (max |Y| {scale:.3g})")
     assert e[1][0] < 1e-4 * scale
     assert e[1][1] <= max(e[0][1] * 1.1, 2e-6 * scale)
+
+
+def test_option_across_the_call_surface():
+    """The option on the other routes into the same kernels: chunked batches (three chunks of 64), two streams (two workspace sets, each with
+    its own bounds), un-normalised poses (the embedding then stays on the bf16 planes), a bf16-matched bank; repeated calls are
+    bit-identical; inputs 1000 x larger / smaller than usual (the bounds, hence the scales, follow - a scale of one would lose them)."""
+    V = 22
+    sd = weights.synthetic_state_dict(99, 1.0, "mixamo")
+    mean, std = synthetic.cnt_norm(7)
+    src = torch.from_numpy(synthetic.pose_windows(5, 160, V)).to(dev()); cha = torch.from_numpy(synthetic.pose_windows(6, 160, V)).to(dev())
+
+    def run(setup, f16):
+        model = Generator(layout="mixamo", device=dev()).load_state_dict(sd).eval()
+        setup(model)
+        model.set_option("gemm_f16x2", f16)
+        enc, _, nm = model.encode(cha, mean, std)
+        bank = ContextBank(model, nm, enc, bf16=True)
+        Y1, i1 = bank.characterize(src, mean, std, return_index=True)
+        Y2, i2 = bank.characterize(src, mean, std, return_index=True)
+        assert torch.equal(Y1, Y2) and torch.equal(i1, i2)
+        return Y1.cpu().numpy(), i1.cpu().numpy(), model
+
+    base = run(lambda m: None, 0)
+    for name, setup in (("plain", lambda m: None), ("chunks of 64", lambda m: m.reserve(64)),
+                        ("two streams", lambda m: (m.set_option("dual_stream", 1), m.set_option("dual_min", 64)))):
+        Y, idx, model = run(setup, 1)
+        same = idx == base[1]
+        assert same.mean() > 0.99 and np.abs(Y[same] - base[0][same]).max() < 2e-5, name
+    # scaled inputs through Generator.forward (no matching in between): relative agreement with the default engine at every magnitude
+    model = base[2]
+    for k in (1e-3, 1.0, 1e3):
+        res = {}
+        for f16 in (0, 1):
+            model.set_option("gemm_f16x2", f16)
+            res[f16] = model(src[:64] * k, cha[:64] * k).cpu().double()
+        model.set_option("gemm_f16x2", 0)
+        d = float((res[1] - res[0]).abs().max()) / max(1e-30, float(res[0].abs().max()))
+        print(f"[f16x2] forward on inputs x {k:g}: relative difference to the default engine {d:.2e}")
+        assert d < 2e-5, (k, d)
+    # un-normalised poses: raw entry points with the option on
+    model.set_option("gemm_f16x2", 1)
+    nn = (V + 1) * 15
+    xm = np.zeros(nn, dtype=np.float32); xs = np.ones(nn, dtype=np.float32)
+    model.set_pose_norm(xm, xs, xm, xs)
+    raw = torch.cat([torch.zeros((64, 60, 1, 15), device=dev()), src[:64]], 2).contiguous()
+    e1, _, _ = model.encode(raw, mean, std, raw=True)
+    model.set_option("gemm_f16x2", 0)
+    e0, _, _ = model.encode(raw, mean, std, raw=True)
+    assert float((e1 - e0).abs().max()) < 2e-5 * max(1.0, float(e0.abs().max()))
