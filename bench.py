@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--launch-timeout", type=float, default=3600.0,
                     help="seconds after which `--gpus N`'s own launcher stops ranks that have not finished (0 = never)")
     ap.add_argument("--no-bank4k", action="store_true", help="N > 1: skip the configs[3] sub-record of the default line")
+    ap.add_argument("--options", default="", help="context options for the measured model, name=value[,name=value...] (mocha_set_option); "
+                    "recorded in config.options - e.g. gemm_f16x2=1 (the opt-in two-plane fp16 GEMM engine: NOT the default line's arithmetic)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra records of the default N=1 line (matcher roofline, bank4k, streaming)")
     return ap.parse_args()
@@ -295,6 +297,14 @@ BANK4K_IDX_CRC32_N1 = {"545d209a9ac5cbed": {22: 4269089464, 24: 2772088534},    
                        "4701c3d0797f58db": {22: 4269089464, 24: 2772088534},      # profiles/r05/q_bank4k_v2{2,4}.json
                        "776b690774403d41": {22: 4269089464, 24: 2772088534}}      # the final tree (+ the opt-in gemm_h2.hip): profiles/r05/t_bank4k_v2{2,4}.json
 XGMI_LINK_GBS = 153.0            # one xGMI link, one direction (MI355X: 7 links per GPU, point-to-point)
+
+
+def parse_options(text):
+    out = {}
+    for kv in filter(None, (text or "").split(",")):
+        k, v = kv.split("=")
+        out[k.strip()] = int(v)
+    return out
 
 
 def comm_record(model, backend, world):
@@ -535,7 +545,11 @@ def bank4k(a):
     layout = "mocha" if V == 24 else "mixamo"
     sd = synthetic_state_dict(1777, 1.0, layout)
     model = Generator(layout=layout, device=dev).load_state_dict(sd).eval()
+    for k, v in parse_options(a.options).items():
+        model.set_option(k, v)
     rec = bank4k_record(a, model, dev, V, rank, world, backend, sd, layout)
+    if parse_options(a.options):
+        rec["config"]["options"] = parse_options(a.options)
     rccl = comm_record(model, backend, world) if torch.distributed.is_initialized() else None
     if rank == 0:
         rec = dict({"metric": METRIC[V]}, **rec, higher_is_better=True, vs_baseline=None, data="synthetic", rccl=rccl)
@@ -779,6 +793,9 @@ def main():
     model = Generator(layout=layout, device=dev).load_state_dict(sd).eval()
     if a.chunk:
         model.reserve(a.chunk)
+    opts = parse_options(a.options)
+    for k, v in opts.items():
+        model.set_option(k, v)
 
     # ---- inputs, resident in HBM before the timed region
     src = torch.from_numpy(synthetic.pose_windows(1777 + 10 * rank, W, V)).to(dev)
@@ -915,7 +932,7 @@ def main():
     # extra (not the headline): the same step with the encoder's, decoder's and to_mot's plane GEMMs on two fp16 planes / three passes
     # (mocha_set_option("gemm_f16x2", 1), csrc/gemm_h2.hip); the poses are compared with the default engine's of the same inputs
     f16x2 = None
-    if world == 1 and not a.no_extras:
+    if world == 1 and not a.no_extras and not opts.get("gemm_f16x2"):
         with torch.no_grad():
             Y0, i0 = model.characterize_pair(src, cha, mean, std, return_index=True)
             model.set_option("gemm_f16x2", 1)
@@ -964,13 +981,16 @@ def main():
         traffic, traffic_src = pmc_traffic_for(dom)
         # mocha_gemm_x3 computes every fp32 product as six bf16 MFMA passes: it is priced on the bf16 pipe with the FLOPs it
         # executes (6 x the algorithmic fp32 FLOPs); the fp32-equivalent rate is given beside it
-        on_bf16 = dom.startswith("mocha_gemm_x3")
-        exe = ach * X3_PASSES if on_bf16 else ach
+        on_h2 = dom.startswith("mocha_gemm_h2")        # --options gemm_f16x2=1: two fp16 planes, three passes, same pipe peak as bf16
+        on_bf16 = dom.startswith("mocha_gemm_x3") or on_h2
+        exe = ach * (3 if on_h2 else X3_PASSES) if on_bf16 else ach
         peak = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_F32_MFMA_TFLOPS
         roofline = {
             "kernel": dom, "bound": "mfma", "achieved": exe, "peak": peak, "unit": "TFLOP/s",
             "frac": exe / peak,
-            "pipe": ("bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate): each fp32 operand as three bf16 planes, six passes per "
+            "pipe": ("fp16 MFMA (v_mfma_f32_32x32x16_f16, fp32 accumulate): each fp32 operand as two fp16 planes (22 bits), three passes per "
+                     "product; 'achieved' counts the executed fp16 FLOPs") if on_h2 else
+                    ("bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulate): each fp32 operand as three bf16 planes, six passes per "
                      "product; 'achieved' counts the executed bf16 FLOPs") if on_bf16 else "f32 MFMA (v_mfma_f32_32x32x2_f32)",
             "fp32_equivalent": {"achieved": ach, "f32_mfma_peak": PEAK_F32_MFMA_TFLOPS, "frac": ach / PEAK_F32_MFMA_TFLOPS},
             # the honest reading of `frac` for an emulated product: the USEFUL (algorithmic fp32) FLOPs against the peak of the pipe
@@ -1002,8 +1022,9 @@ def main():
             "metric": METRIC[V],
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"demo pair (BASELINE configs[1]): {W} src x {W} cha windows, T=60, V={V}, C=15, "
+            "dtype": "f32" if not opts.get("gemm_f16x2") else "f32 in / out / accumulate; GEMM operands as two fp16 planes = 22 bits (--options gemm_f16x2=1)",
+            "data": "synthetic",
+            "config": {"options": opts, "workload": f"demo pair (BASELINE configs[1]): {W} src x {W} cha windows, T=60, V={V}, C=15, "
                                    f"bank build + encode/match/decode/to_mot per step "
                                    f"({'encode + ContextBank + characterize' if step is step_three_calls else 'characterize_pair'})",
                        "windows_per_gpu": W,
