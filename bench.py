@@ -492,7 +492,7 @@ def bank4k_record(a, model, dev, V, rank, world, backend, sd=None, layout=None):
         with torch.no_grad():
             try:                                      # set-up is local: a failure on one rank must not leave the others in a barrier
                 p_nm, p_enc = bank.tensors()
-                pipe = BatchPipeline(sd, p_nm, p_enc, layout=layout, device=dev, contexts=3, bf16=True)
+                pipe = BatchPipeline(sd, p_nm, p_enc, layout=layout, device=dev, contexts=3, bf16=True, options=parse_options(a.options))
                 for _ in range(6):
                     pipe.characterize(src, mean, std)
                 torch.cuda.synchronize()
