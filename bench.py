@@ -295,7 +295,8 @@ BANK4K_IDX_CRC32_N1 = {"545d209a9ac5cbed": {22: 4269089464, 24: 2772088534},    
                        "58ae42e49ecb4b74": {22: 4269089464, 24: 2772088534},      # profiles/r05/k_bank4k_v2{2,4}.json (unchanged by round 5's numerics)
                        "ad527b6ce6c3a29e": {22: 4269089464, 24: 2772088534},      # + pair_overlap host change
                        "4701c3d0797f58db": {22: 4269089464, 24: 2772088534},      # profiles/r05/q_bank4k_v2{2,4}.json
-                       "776b690774403d41": {22: 4269089464, 24: 2772088534}}      # the final tree (+ the opt-in gemm_h2.hip): profiles/r05/t_bank4k_v2{2,4}.json
+                       "776b690774403d41": {22: 4269089464, 24: 2772088534},      # + the opt-in gemm_h2.hip: profiles/r05/t_bank4k_v2{2,4}.json
+                       "147d1ee70460bdde": {22: 4269089464, 24: 2772088534}}      # the final tree: profiles/r05/v_bank4k_v2{2,4}.json
 XGMI_LINK_GBS = 153.0            # one xGMI link, one direction (MI355X: 7 links per GPU, point-to-point)
 
 

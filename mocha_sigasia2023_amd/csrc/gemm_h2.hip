@@ -52,12 +52,12 @@ __device__ __forceinline__ void f16_split4(const f32x4 v, u32x2 (&out)[2]) {
 static constexpr int F16_PA[3] = {1, 0, 0}, F16_PB[3] = {0, 1, 0};      // a1 b0, a0 b1, a0 b0 (low-order products first)
 
 static constexpr int XN = 128, XK = 16;                  // tile width, K step; tile height = 64 TM rows
-static constexpr int XA_HALF = 128 * 8 + 32;            // bf16 per k half of an A plane (2 KB + 64 B)
-static constexpr int XA_PLANE = 2 * XA_HALF;            // 2176 bf16
-static constexpr int XB_PLANE = 128 * 16;               // 2048 bf16, [k half][row][8]
+static constexpr int XA_HALF = 128 * 8 + 32;            // fp16 per k half of an A plane (2 KB + 64 B)
+static constexpr int XA_PLANE = 2 * XA_HALF;            // 2176 fp16
+static constexpr int XB_PLANE = 128 * 16;               // 2048 fp16, [k half][row][8]
 static constexpr int XB_OFF = NPL * XA_PLANE;             // B planes follow the A planes of a stage
-static constexpr int X_STAGE = XB_OFF + NPL * XA_PLANE;   // 13 056 bf16 = 26 112 B (the B planes use the padded A layout in LDS)
-static constexpr int XW_BLOCK = NPL * XB_PLANE;           // packed weights per (n tile, k step): 6144 bf16 = 12 KB
+static constexpr int X_STAGE = XB_OFF + NPL * XA_PLANE;   // 8 704 fp16 = 17 408 B (the B planes use the padded A layout in LDS)
+static constexpr int XW_BLOCK = NPL * XB_PLANE;           // packed weights per (n tile, k step): 4 096 fp16 = 8 KB
 // tile width 64 TN: the B planes of a stage hold 64 TN rows per k half (TN = 2: the layout above; TN = 1: one 64-row half of a packed block)
 template <int TN> struct XT {
     static constexpr int TILE_N = 64 * TN;
@@ -109,12 +109,16 @@ __global__ __launch_bounds__(256) void mocha_h2_wscale(const float* __restrict__
 // the bound of a linear map of x with row L1 norm <= mul and bias magnitudes <= add)
 __global__ __launch_bounds__(256) void mocha_absmax(const float* __restrict__ x, long long n, float* __restrict__ out, float mul, float add) {
     float m = 0.f;
-    const long long n4 = n >> 2;
+    // 16-byte loads from the first aligned element on; the up to three elements in front of it and behind the last quad one by one
+    const long long head = std::min<long long>(n, (long long)((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) >> 2);
+    const float* xa = x + head;
+    const long long n4 = (n - head) >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 v = reinterpret_cast<const f32x4*>(xa)[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
-    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+    if (blockIdx.x == 0 && threadIdx.x < head) m = fmaxf(m, fabsf(x[threadIdx.x]));
+    if (blockIdx.x == 0 && threadIdx.x < ((n - head) & 3)) m = fmaxf(m, fabsf(xa[n4 * 4 + threadIdx.x]));
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     __shared__ float wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(256) void mocha_absmax(const float* __restrict__ x,
 }
 hipError_t launch_absmax(const float* x, long long n, float* out, hipStream_t s, float mul, float add) {
     if (n <= 0) return hipSuccess;
-    if ((reinterpret_cast<uintptr_t>(x) & 15) != 0) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(x) & 3) != 0) return hipErrorInvalidValue;
     const long long wgs = std::min<long long>((n / 4 + 255) / 256 + 1, 1024);
     if (!(mul > 0.f) || !(add >= 0.f)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(mocha_absmax, dim3((unsigned)wgs), dim3(256), 0, s, x, n, out, mul, add);
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
             for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(st + q * XA_PLANE + a_wr + i * 64 * 8) = pl[q];
         }
     };
-    // ---- W: linear copy of the packed 12 KB block of (nt, step) into the stage
+    // ---- W: linear copy of the packed 8 KB block of (nt, step) into the stage
     const int wblock = TN == 1 ? nt >> 1 : nt;           // the packed image is in 128-column blocks; a 64-wide tile takes one half of one
     const __amdgpu_buffer_rsrc_t rsW = make_rsrc(p.Wh2 + ((size_t)wblock * steps_total + s0) * XW_BLOCK);
     auto dma_w = [&](int s, unsigned short* st) __attribute__((always_inline)) {
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
                                                          (((j * 4 + wave) >> 1) & 1) * B_HALF + ((j * 4 + wave) & 1) * 512), 16,
                                                          (unsigned)(j * 256 + tid) * 16u, (unsigned)s * (XW_BLOCK * 2u), 0, 0);
         } else {
-            // six 1 KB pieces (plane, k half) of this tile's 64-row half: waves 0 and 1 copy two, waves 2 and 3 one
+            // four 1 KB pieces (plane, k half) of this tile's 64-row half: one per wave
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int pc = j * 4 + wave;                 // (plane, k half) = (pc >> 1, pc & 1)
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
             for (int i = 0; i < TN; ++i) b[q][i] = *reinterpret_cast<const h16x8*>(cur + q * B_PLANE + fb + i * 32 * 8);
         };
         rd_a(1); rd_b(0); rd_a(0); rd_b(1);                             // in the order the products below consume them
-        // Hand-interleaved issue order (fenced so that the scheduler keeps it): after every MFMA two of the 44 VALU instructions that
+        // Hand-interleaved issue order (fenced so that the scheduler keeps it): after every MFMA two (TN = 1: four) of the 12 TM VALU instructions that
         // split step s + 1's activations (an MFMA holds the vector issue port for 8 of its 32 cycles), the plane writes as soon as a
         // row's planes are complete, the fetch of step s + 2 when the registers are free.  Low-order products first, a0·b0 last.
         float x[4 * TM];
@@ -571,11 +575,6 @@ static void h2_launch(const GemmParams& p, hipStream_t s) {
         else hipLaunchKernelGGL((mocha_gemm_h2<false, false, TM, TN>), grid, dim3(256), h2_lds_bytes<TN>(), s, p);
     }
 }
-
-// Default: 768 workgroups (three per CU) walk the tiles of launches up to 512 columns wide - out_proj / ff1 / ff2 / the embedding and to_mot
-// GEMMs 2-3 % faster, demo step 5.59 against 5.62 ms; the 1536-wide qkv projection is 5 % SLOWER that way and stays on mocha_gemm_h2
-// (profiles/r04/d_persist_ab.txt, d_persist_selective_ab.txt)
-// GemmParams::persistent (workgroups, a multiple of 8; 0 = never) / persistent_max_n: per context, options "gemm_persistent[_max_n]"
 
 hipError_t launch_gemm_h2(const GemmParams& p, hipStream_t s) {
     if (p.M <= 0 || p.N <= 0) return hipSuccess;

@@ -187,10 +187,10 @@ struct mocha_ctx {
     struct H2Img { unsigned short* img; float* w_inv; };
     std::map<std::tuple<const float*, int, int>, H2Img> h2w;
     static constexpr int AMAX_SLOTS = 40, AMAX_STAGES = 4;             // stages: 0 encoder, 1 decoder, 2 to_mot, 3 embedding
-    static constexpr int AMAX_USED[4] = {2 + 4 * 8, 3 * 8, 5, 5};      // slots a stage can take (depth <= 8): what its start zeroes
+    static constexpr int AMAX_USED[4] = {2 + 4 * 8, 1 + 3 * 8, 5, 5};      // slots a stage can take (depth <= 8): what its start zeroes
     float* amax = nullptr;                                            // MAX_SETS x AMAX_STAGES x AMAX_SLOTS bounds of H2_AMAX_FLOATS floats (kernels.h), then the two below
     std::vector<char> amax_ok = std::vector<char>(MAX_SETS * AMAX_STAGES * AMAX_SLOTS, 0);
-    int amax_stage = 0, amax_next = 0;
+    int amax_stage = 0, amax_next = 0; bool amax_idle = true;
     float* amax_in = nullptr;                                         // constant: the bound of an instance-normalised token, (n - 1) / sqrt(n) < 9.5 for 90 tokens
     float* amax_bank = nullptr; bool amax_bank_ok = false;            // the current bank's encoded rows (mocha_bank_set)
     const float* amax_enc_of[MAX_SETS] = {nullptr, nullptr, nullptr}; float* amax_enc[MAX_SETS] = {nullptr, nullptr, nullptr};   // encoder output pointer -> its slot
@@ -531,8 +531,11 @@ int amax_alloc(mocha_ctx* c) {                                       // once, wh
     HIPCHK(c, hipMemcpy(c->amax_in, &k, sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
-int amax_begin(mocha_ctx* c, int stage, hipStream_t s) {
-    if (!c->gemm_h2 || !c->amax) return 0;
+// b: windows of this chunk - up to 4 every GEMM of the path runs on the few-rows kernels (gemm_is_skinny), which neither read nor leave
+// bounds: the stage then hands out no slots (no memset / absmax launches in the streamed per-window step)
+int amax_begin(mocha_ctx* c, int stage, hipStream_t s, int b) {
+    c->amax_idle = !c->gemm_h2 || !c->amax || b < 5;
+    if (c->amax_idle) return 0;
     c->amax_stage = stage; c->amax_next = 0;
     const size_t base = ((size_t)c->cur * mocha_ctx::AMAX_STAGES + stage) * mocha_ctx::AMAX_SLOTS;
     std::fill(c->amax_ok.begin() + base, c->amax_ok.begin() + base + mocha_ctx::AMAX_SLOTS, 0);
@@ -540,7 +543,7 @@ int amax_begin(mocha_ctx* c, int stage, hipStream_t s) {
     return 0;
 }
 float* amax_slot(mocha_ctx* c) {                                      // a fresh (zero) bound of the current stage, or null when the engine is off
-    if (!c->gemm_h2 || !c->amax || c->amax_next >= mocha_ctx::AMAX_USED[c->amax_stage]) return nullptr;
+    if (c->amax_idle || !c->gemm_h2 || !c->amax || c->amax_next >= mocha_ctx::AMAX_USED[c->amax_stage]) return nullptr;
     return c->amax + (((size_t)c->cur * mocha_ctx::AMAX_STAGES + c->amax_stage) * mocha_ctx::AMAX_SLOTS + c->amax_next++) * H2_AMAX_FLOATS;
 }
 ptrdiff_t amax_index(const mocha_ctx* c, const float* slot) {         // slot number inside the arena, or -1 (amax_in / amax_bank / foreign)
@@ -625,10 +628,10 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     // two-plane fp16 engine (z-scored input, fused path): |u| <= |conv1(x)| <= emb_l1 max|x| + emb_bmax (LeakyReLU, the column-normalised
     // adjacency x pool mix and the 4-frame means do not raise a magnitude) - one pass over the poses gives the first launch's bound,
     // every GEMM's epilogue the next one's; the tokens' bound goes on to the encoder
-    { int rc = amax_begin(c, 3, s); if (rc) return rc; }
+    { int rc = amax_begin(c, 3, s, b + b2); if (rc) return rc; }
     float* u_amax = nullptr;
     c->amax_tok_of[c->cur] = nullptr;
-    if (c->gemm_h2 && !raw && c->fold_joint && c->gemm_x3 && c->embed_sums && c->emb_l1 > 0.f && (u_amax = amax_slot(c))) {
+    if (c->gemm_h2 && !c->amax_idle && !raw && c->fold_joint && c->gemm_x3 && c->embed_sums && c->emb_l1 > 0.f && (u_amax = amax_slot(c))) {
         const long long per = 60ll * V * c->cfg.C_in;
         LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * b * per, launch_absmax(X, b * per, u_amax, s, c->emb_l1, c->emb_bmax));
         if (X2 && b2 > 0) LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * b2 * per, launch_absmax(X2, b2 * per, u_amax, s, c->emb_l1, c->emb_bmax));
@@ -729,9 +732,9 @@ int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStr
     const float* x = tokens;
     // two-plane fp16 engine: every launch scales its activations by a bound on them - the tokens' largest magnitude is measured, every
     // GEMM's epilogue leaves its output's, and the attention's rows are convex combinations of value rows (a slice of qkv)
-    int rc0 = amax_begin(c, 0, s); if (rc0) return rc0;
+    int rc0 = amax_begin(c, 0, s, b); if (rc0) return rc0;
     float* x_amax = nullptr;
-    if (c->gemm_h2) {
+    if (c->gemm_h2 && !c->amax_idle) {
         if (tokens == c->amax_tok_of[c->cur] && amax_use(c, c->amax_tok[c->cur])) x_amax = c->amax_tok[c->cur];      // the embedding's last GEMM left it
         else { rc0 = amax_measure(c, s, tokens, (long long)M * 256, &x_amax); if (rc0) return rc0; }
     }
@@ -829,12 +832,17 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
     // two-plane fp16 engine: the attention's rows are convex combinations of the value rows - the matched bank entries (their largest
     // magnitude is taken at mocha_bank_set) or the character windows this call encoded; the query GEMM's operand is an instance-normalised
     // token (|z| <= (n - 1) / sqrt(n)); without a bound a launch stays on the bf16 planes
-    { int rc = amax_begin(c, 1, s); if (rc) return rc; }
+    { int rc = amax_begin(c, 1, s, b); if (rc) return rc; }
     const float* v_amax = nullptr;
-    if (c->gemm_h2) {
+    if (c->gemm_h2 && !c->amax_idle) {
         const float* vsrc = gather_table ? gather_table : cha;
         if (vsrc && vsrc == c->bank_enc && c->amax_bank_ok) v_amax = c->amax_bank;
         else if (vsrc && vsrc == c->amax_enc_of[c->cur]) v_amax = amax_use(c, c->amax_enc[c->cur]);
+        else if (cha && !gather_table) {            // caller-supplied character features (mocha_decoder): measured
+            float* slot = nullptr;
+            int rc = amax_measure(c, s, cha, (long long)M * 256, &slot); if (rc) return rc;
+            v_amax = amax_use(c, slot);
+        }
     }
     float* x_amax = nullptr;
     c->amax_dec_of[c->cur] = nullptr;
@@ -865,7 +873,7 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
             // value projections fold into the query and output weights (exact algebra, net/transformer.py:62-76), so the
             // attention reads IN(cha) / cha directly for every head and two of the four projection GEMMs disappear.
             GemmParams gq = plain(WS(c, "qin"), 256, DW(c, p + ".Wqk"), qb, inner, M, inner, 256);
-            gq.a_amax = c->gemm_h2 ? c->amax_in : nullptr;
+            gq.a_amax = c->gemm_h2 && !c->amax_idle ? c->amax_in : nullptr;
             GEMM(c, s, "dec.q", gq);
             if (use_kv) {
                 AttnKvParams a{qb, WS(c, "ao"), reinterpret_cast<const unsigned short*>(WS(c, "kvimg")), inner, inner, b, H, DH, 90, 90, (float)std::pow((double)DH, -0.5), c->attn_kv_pairs ? 1 : 0};
@@ -908,9 +916,9 @@ int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s
     if (denorm && !c->pose_norm) return fail(c, MOCHA_ERR_STATE, "de-normalised output needs mocha_set_pose_norm first");
     // two-plane fp16 engine: LeakyReLU and the column-normalised adjacency mixes (body_front, joint_expand: non-negative coefficients that sum
     // to at most one per output) do not raise the largest magnitude, so each GEMM's bound is its predecessor's output bound
-    { int rc = amax_begin(c, 2, s); if (rc) return rc; }
+    { int rc = amax_begin(c, 2, s, b); if (rc) return rc; }
     float* t_amax = nullptr;
-    if (c->gemm_h2) {
+    if (c->gemm_h2 && !c->amax_idle) {
         if (tokens == c->amax_dec_of[c->cur] && amax_use(c, c->amax_dec[c->cur])) t_amax = c->amax_dec[c->cur];
         else { int rc = amax_measure(c, s, tokens, (long long)M * 256, &t_amax); if (rc) return rc; }
     }

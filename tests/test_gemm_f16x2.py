@@ -96,6 +96,22 @@ def test_outlier_channels_and_the_row_range_limit():
     assert rel["h2"].max() < 2e-5                                                 # the lowest rows: degraded, bounded
 
 
+def test_activation_bound_of_an_unaligned_operand():
+    """mocha_absmax reads 16 bytes at a time from the first aligned element on: an operand that starts 4 bytes off gives the same result."""
+    M, N, K = 8192, 256, 256
+    g = torch.Generator(device="cpu").manual_seed(3)
+    flat = torch.randn((M * K + 5,), generator=g).to(dev())
+    flat[1] = 300.0; flat[M * K] = -700.0                          # the largest magnitudes sit in the unaligned head and tail
+    xv = flat[1:1 + M * K].view(M, K)
+    w = (torch.randn((N, K), generator=g) / 16).to(dev())
+    model = Generator(layout="mixamo", device=dev())
+    assert xv.data_ptr() % 16 == 4
+    y1 = model.linear(xv, w, None, engine=3); y2 = model.linear(xv.clone(), w, None, engine=3)
+    assert torch.equal(y1, y2)
+    ref = xv.double() @ w.double().T
+    assert float((y1.double() - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
 def test_rejected_shapes():
     model = Generator(layout="mixamo", device=dev())
     with pytest.raises(RuntimeError, match="outside the f16x2 engine"):
@@ -213,3 +229,20 @@ def test_option_across_the_call_surface():
     model.set_option("gemm_f16x2", 0)
     e0, _, _ = model.encode(raw, mean, std, raw=True)
     assert float((e1 - e0).abs().max()) < 2e-5 * max(1.0, float(e0.abs().max()))
+
+
+def test_few_window_calls_are_untouched_by_the_option():
+    """Up to four windows every GEMM of the path runs on the few-rows kernels: with the option on such a call launches neither the engine
+    nor its bound kernels / memsets (the streamed per-window step keeps its launch count) and its results are bit-identical."""
+    sd = weights.synthetic_state_dict(7, 1.0, "mixamo")
+    model = Generator(layout="mixamo", device=dev()).load_state_dict(sd).eval()
+    src = torch.from_numpy(synthetic.pose_windows(1, 3, 22)).to(dev()); cha = torch.from_numpy(synthetic.pose_windows(2, 3, 22)).to(dev())
+    out = {}
+    for f16 in (0, 1):
+        model.set_option("gemm_f16x2", f16)
+        model.profile_start()
+        out[f16] = model(src, cha)
+        names = set(model.profile_stop()["kernels"])
+        assert "mocha_gemm_h2" not in names and "mocha_absmax" not in names, names
+    model.set_option("gemm_f16x2", 0)
+    assert torch.equal(out[0], out[1])
