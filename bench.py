@@ -969,7 +969,7 @@ def main():
         with torch.no_grad():
             for _ in range(max(a.warmup, 5)):       # the extras above ran other engines / workloads: bring the board back to this step's state first
                 step()
-            sync_all()
+            torch.cuda.synchronize(dev)              # rank 0 only here: no barrier
             model.profile_start()
             for _ in range(3):
                 step()
