@@ -11,12 +11,14 @@
 //
 // Scales (exact powers of two, so the result does not depend on them while nothing leaves fp16's normal range):
 //   * weights: per output row, from the row's largest magnitude (mocha_h2_wscale at pack time); the epilogue multiplies column n by 1 / S_w[n];
-//   * activations: ONE scale per launch from a bound on |A| the caller passes as a DEVICE scalar (GemmParams::a_amax): the largest
-//     scaled element lands in [2^14, 2^15).  The producing GEMM's epilogue maintains that scalar (GemmParams::c_amax, an atomic max over
-//     what it stores), bounds that follow from the arithmetic serve the other producers (softmax-weighted rows are bounded by the value
-//     rows, an instance-normalised token by (n - 1) / sqrt(n), a column-normalised adjacency mix by its input), mocha_absmax the rest.
-//     fp16 keeps 22 bits over 2^18 of range: rows more than five decades below the tensor's largest lose digits (absolute error
-//     2^-40 of the tensor's largest) - the fp32 engines keep them.
+//   * activations: one scale per WINDOW (the path's independent unit: GemmParams::rows_per_win consecutive rows of the launch), from a bound on
+//     the window's |A| the caller passes as a vector in device memory (GemmParams::a_amax): the window's largest scaled element lands in
+//     [2^14, 2^15).  The producing GEMM's epilogue maintains such a vector (GemmParams::c_amax: per window the largest magnitude it stores),
+//     bounds that follow from the arithmetic serve the other producers - every operator between two GEMMs of the path stays inside a window
+//     (softmax-weighted rows are bounded by the window's value rows, an instance-normalised token by (n - 1) / sqrt(n), a column-normalised
+//     adjacency mix by its input) - mocha_absmax the rest.  A window's result therefore does not depend on the other windows of a batch.
+//     fp16 keeps 22 bits over 2^18 of range: rows more than five decades below THEIR WINDOW's largest magnitude lose digits (absolute
+//     error 2^-40 of that magnitude) - the fp32 engines keep them.
 //
 // Kernel: the one-shot grid of gemm_x3.hip's plane GEMM (that file has the reasoning for the tiling, the LDS image, the loaders and the counted waits)
 // with two planes per operand: 128 x 128 / 64 x 128 / 128 x 64 / 64 x 64 tiles, K step 16, per step and wave 8 ds_read_b128 feed 12
@@ -82,19 +84,6 @@ __host__ __device__ __forceinline__ float h2_scale(float amax, float* inv) {
     return sc;
 }
 
-// A bound in device memory = H2_AMAX_WAYS floats H2_AMAX_STRIDE apart (kernels.h).  Store: one conditional atomic per WORKGROUP into the way
-// blockIdx.x selects - bits of non-negative floats order like unsigned integers; the maximum only grows, so a stale (smaller) value read
-// first can cost an unnecessary atomic but never lose a needed one.  Load: a wave reads all ways and reduces.
-__device__ __forceinline__ void h2_amax_store(float* amax, float m) {
-    float* a = amax + (blockIdx.x % H2_AMAX_WAYS) * H2_AMAX_STRIDE;
-    if (m > *reinterpret_cast<volatile const float*>(a)) atomicMax(reinterpret_cast<unsigned*>(a), __float_as_uint(m));
-}
-__device__ __forceinline__ float h2_amax_load(const float* amax, int lane) {
-    float m = lane < H2_AMAX_WAYS ? amax[lane * H2_AMAX_STRIDE] : 0.f;
-    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(m)));      // (the builtin is an integer one: pass the bits).  NaN entries: fmaxf keeps the other operand; h2_scale maps inf to scale 1
-}
-
 // per weight row: 1 / S_w[n] (one wave per row)
 __global__ __launch_bounds__(256) void mocha_h2_wscale(const float* __restrict__ W, int N, int K, float* __restrict__ w_inv) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -105,32 +94,49 @@ __global__ __launch_bounds__(256) void mocha_h2_wscale(const float* __restrict__
     if (lane == 0) { float inv; (void)h2_scale(m, &inv); w_inv[n] = inv; }
 }
 
-// mul * (largest magnitude of n floats) + add -> out (a bound as described in kernels.h: H2_AMAX_FLOATS, zeroed by the caller; mul > 0, add >= 0:
-// the bound of a linear map of x with row L1 norm <= mul and bias magnitudes <= add)
-__global__ __launch_bounds__(256) void mocha_absmax(const float* __restrict__ x, long long n, float* __restrict__ out, float mul, float add) {
+// out[w] = max(out[w], mul * (largest magnitude of window w's `per` floats) + add) for nwin consecutive windows of x (out zeroed by the caller;
+// mul > 0, add >= 0: the bound of a linear map of x with row L1 norm <= mul and bias magnitudes <= add).  grid = (parts, nwin): a window's floats
+// are cut into `parts` slices; atomic max on the bits of a non-negative float (a handful per address)
+__global__ __launch_bounds__(256) void mocha_absmax(const float* __restrict__ x, long long per, float* __restrict__ out, float mul, float add) {
+    const long long lo = per * blockIdx.x / gridDim.x, hi = per * (blockIdx.x + 1) / gridDim.x;
+    const float* xw = x + (long long)blockIdx.y * per + lo;
+    const long long n = hi - lo;
     float m = 0.f;
     // 16-byte loads from the first aligned element on; the up to three elements in front of it and behind the last quad one by one
-    const long long head = std::min<long long>(n, (long long)((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) >> 2);
-    const float* xa = x + head;
+    const long long head = std::min<long long>(n, (long long)((16 - (reinterpret_cast<uintptr_t>(xw) & 15)) & 15) >> 2);
+    const float* xa = xw + head;
     const long long n4 = (n - head) >> 2;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    for (long long i = threadIdx.x; i < n4; i += 256) {
         const f32x4 v = reinterpret_cast<const f32x4*>(xa)[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
-    if (blockIdx.x == 0 && threadIdx.x < head) m = fmaxf(m, fabsf(x[threadIdx.x]));
-    if (blockIdx.x == 0 && threadIdx.x < ((n - head) & 3)) m = fmaxf(m, fabsf(xa[n4 * 4 + threadIdx.x]));
+    if (threadIdx.x < head) m = fmaxf(m, fabsf(xw[threadIdx.x]));
+    if (threadIdx.x < ((n - head) & 3)) m = fmaxf(m, fabsf(xa[n4 * 4 + threadIdx.x]));
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
     __shared__ float wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) h2_amax_store(out, fmaf(mul, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])), add));
+    if (threadIdx.x == 0) atomicMax(reinterpret_cast<unsigned*>(out + blockIdx.y), __float_as_uint(fmaf(mul, fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3])), add)));
 }
-hipError_t launch_absmax(const float* x, long long n, float* out, hipStream_t s, float mul, float add) {
+hipError_t launch_absmax(const float* x, long long nwin, long long per, float* out, hipStream_t s, float mul, float add) {
+    if (nwin <= 0 || per <= 0) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(x) & 3) != 0 || nwin > 65535 || !(mul > 0.f) || !(add >= 0.f)) return hipErrorInvalidValue;
+    // enough workgroups to fill the chip: one per window when there are many, slices of at least 4 096 floats otherwise
+    long long parts = std::max<long long>(1, std::min<long long>(2048 / nwin, per / 4096));
+    hipLaunchKernelGGL(mocha_absmax, dim3((unsigned)parts, (unsigned)nwin), dim3(256), 0, s, x, per, out, mul, add);
+    return hipGetLastError();
+}
+// out[i] = table[clamp(idx[i])] (the decoder's per-window value bound = its matched entry's)
+__global__ __launch_bounds__(256) void mocha_gather_f32(const float* __restrict__ table, const int32_t* __restrict__ idx, long long rows, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    long long r = idx[i];
+    r = r < 0 ? 0 : r >= rows ? rows - 1 : r;
+    out[i] = table[r];
+}
+hipError_t launch_gather_f32(const float* table, const int32_t* idx, long long rows, float* out, int n, hipStream_t s) {
     if (n <= 0) return hipSuccess;
-    if ((reinterpret_cast<uintptr_t>(x) & 3) != 0) return hipErrorInvalidValue;
-    const long long wgs = std::min<long long>((n / 4 + 255) / 256 + 1, 1024);
-    if (!(mul > 0.f) || !(add >= 0.f)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mocha_absmax, dim3((unsigned)wgs), dim3(256), 0, s, x, n, out, mul, add);
+    hipLaunchKernelGGL(mocha_gather_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, table, idx, rows, out, n);
     return hipGetLastError();
 }
 
@@ -169,15 +175,6 @@ hipError_t launch_pack_h2(const float* W, int N, int K, unsigned short* out, flo
     return hipGetLastError();
 }
 
-// the largest magnitude this workgroup stored -> c_amax (called by all 256 threads; `red` = four floats of LDS nobody else uses any more)
-__device__ __forceinline__ void h2_amax_out(float* c_amax, float m, int lane, int wave, float* red) {
-    if (!c_amax) return;                             // uniform
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if (lane == 0) red[wave] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) h2_amax_store(c_amax, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
-}
-
 // LRELU: LeakyReLU(0.2) on the activations as they are split; GATHER: temporal-conv gather (kernels.h) instead of plain rows.
 // Compile-time so that a K step is one basic block the scheduler can interleave.
 // TM: 32-row MFMA blocks per wave: 2 = the 128-row tile; 1 = a 64-row tile (four waves of 32 x 64) for mid-size launches
@@ -194,8 +191,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    float inv_a;
-    const float sa = h2_scale(h2_amax_load(p.a_amax, lane), &inv_a);       // uniform: from the bound on |A| of this launch
+    __shared__ float h2_rowinv[128];                // 1 / S_a of the tile's rows (their windows' scales)
+    __shared__ unsigned h2_wmax[4];                 // bits of the largest magnitude stored per window the tile touches (at most three: rows_per_win >= 64)
 
     const int n_tiles = (p.N + TILE_N - 1) / TILE_N;
     const int m_tiles = (p.M + TILE_M - 1) / TILE_M;
@@ -240,6 +237,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
             a_off[i] = ((unsigned)(m - m0) * (unsigned)p.lda + lc * 4) * 4u;
         }
     }
+    // windows: row m of the launch belongs to window m / rows_per_win; the tile's rows lie in windows w0 .. w0 + 2 at most, the first row of
+    // window w0 + 1 / w0 + 2 is tile row wb1 / wb2
+    const int w0 = m0 / p.rows_per_win;
+    const int wb1 = (w0 + 1) * p.rows_per_win - m0, wb2 = wb1 + p.rows_per_win;
+    const int nwin = (p.M + p.rows_per_win - 1) / p.rows_per_win;
+    float sa[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = lrow + 64 * i;
+        int w = w0 + (r >= wb1) + (r >= wb2);
+        w = w < nwin ? w : nwin - 1;
+        float inv;
+        sa[i] = h2_scale(p.a_amax[w], &inv);
+        if (lc == 0) h2_rowinv[r] = inv;
+    }
+    if (tid < 4) h2_wmax[tid] = 0u;
     f32x4 rset[2][TM];                              // step t's activations wait in set t & 1, fetched two steps ahead
     auto load_a = [&](int s, f32x4 (&ra)[TM]) __attribute__((always_inline)) {
         const int k0 = (s0 + s) * XK;
@@ -268,7 +281,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
             f32x4 v = ra[i];
             if (LRELU) { v[0] = h2_lrelu(v[0]); v[1] = h2_lrelu(v[1]); v[2] = h2_lrelu(v[2]); v[3] = h2_lrelu(v[3]); }
             u32x2 pl[NPL];
-            f16_split4(v * sa, pl);
+            f16_split4(v * sa[i], pl);
 #pragma unroll
             for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(st + q * XA_PLANE + a_wr + i * 64 * 8) = pl[q];
         }
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
         float hi[2 * TM][2];
         if (FETCH_W) {
 #pragma unroll
-            for (int e = 0; e < 4 * TM; ++e) { x[e] = rset[P ^ 1][e >> 2][e & 3]; if (LRELU) x[e] = fmaxf(x[e], 0.2f * x[e]); x[e] *= sa; }
+            for (int e = 0; e < 4 * TM; ++e) { x[e] = rset[P ^ 1][e >> 2][e & 3]; if (LRELU) x[e] = fmaxf(x[e], 0.2f * x[e]); x[e] *= sa[e >> 2]; }
         }
         auto split_op = [&](int k) __attribute__((always_inline)) {     // op k of 12 TM: pair k / 6 (two values), step k % 6
             const int pr = k / 6, o = k % 6;
@@ -421,8 +434,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
         const unsigned cb = (unsigned)c4 * 16u;
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         const f32x4 bias4 = p.bias ? bload(rsBias, cb, 0u) : zero4;
-        const f32x4 sc4 = bload(rsWinv, cb, 0u) * inv_a;                       // 1 / (S_a S_w[n]) of this thread's column quad
-        float cmax = 0.f;
+        const f32x4 winv4 = bload(rsWinv, cb, 0u);                             // 1 / S_w[n] of this thread's column quad
         const bool pre_res = p.residual != nullptr, pre_rb = !pre_res && p.rowbias != nullptr;
         f32x4 pre[2];
         auto fetch_pre = [&](int k) __attribute__((always_inline)) {
@@ -456,12 +468,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
                     const int r = r0 + RSTEP * it;
                     const int rloc = 64 * h + r;
                     if (m0 + rloc < p.M) {
-                        f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4) * sc4;
+                        f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4) * (winv4 * h2_rowinv[rloc]);
                         if (p.act == 1) { v = mocha_gelu4(v); }
                         else if (p.act == 2) { v[0] = h2_lrelu(v[0]); v[1] = h2_lrelu(v[1]); v[2] = h2_lrelu(v[2]); v[3] = h2_lrelu(v[3]); }
                         else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                         bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
-                        cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        if (p.c_amax) atomicMax(&h2_wmax[(rloc >= wb1) + (rloc >= wb2)], __float_as_uint(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])))));
                     }
                 }
             } else
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
             for (int it = 0; it < NIT; ++it) {
                 const int r = r0 + RSTEP * it;
                 const int rloc = 64 * h + r;
-                f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4) * sc4 + bias4;
+                f32x4 v = *reinterpret_cast<const f32x4*>(stage + r * LDP + c4 * 4) * (winv4 * h2_rowinv[rloc]) + bias4;
                 if (pre_rb) v += pre[(NIT * h + it) & 1];
                 else if (p.rowbias) v += bload(rsRb, (unsigned)((m0 + rloc) % p.rb_mod) * (unsigned)p.N * 4u + cb, 0u);   // a residual too: inline (2 GiB window)
                 if (p.act == 1) { v = mocha_gelu4(v); }
@@ -479,22 +491,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
                 if ((pre_res || pre_rb) && NIT * h + it + 2 < NIT * TM) fetch_pre(NIT * h + it + 2);      // ahead of this store
                 if (m0 + rloc < p.M) {
                     bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
-                    cmax = fmaxf(fmaxf(cmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    if (p.c_amax) atomicMax(&h2_wmax[(rloc >= wb1) + (rloc >= wb2)], __float_as_uint(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])))));
                 }
             }
             if (h + 1 < TM) __syncthreads();
         }
-        __syncthreads();                             // the stage is read out: its first floats take the waves' maxima
-        h2_amax_out(p.c_amax, cmax, lane, wave, stage);
+        if (p.c_amax) {                              // uniform.  The tile's per-window maxima -> the output's bound vector (a few atomics per address per launch)
+            __syncthreads();
+            if (tid < 3 && w0 + tid < nwin && h2_wmax[tid]) atomicMax(reinterpret_cast<unsigned*>(p.c_amax) + w0 + tid, h2_wmax[tid]);
+        }
         return;
     }
 
     // ragged tiles (N not a multiple of 128, unaligned leading dimensions): straight from the accumulators
-    float rmax = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        const int row = m0 + (wm * TM + i) * 32 + l31;
+        const int rloc = (wm * TM + i) * 32 + l31;
+        const int row = m0 + rloc;
         if (row >= p.M) continue;
+        const float inv_a = h2_rowinv[rloc];
+        float rmax = 0.f;
         const float* rbrow = p.rowbias ? p.rowbias + (size_t)(row % p.rb_mod) * p.N : nullptr;
         const float* rsrow = p.residual ? p.residual + (size_t)row * p.ldr : nullptr;
         float* crow = Cz + (size_t)row * p.ldc;
@@ -516,9 +532,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
                     crow[c1] = x;
                     rmax = fmaxf(rmax, fabsf(x));
                 }
+        if (p.c_amax) atomicMax(&h2_wmax[(rloc >= wb1) + (rloc >= wb2)], __float_as_uint(rmax));
     }
-    __syncthreads();                                 // every wave is past its K loop: the operand stages are free
-    h2_amax_out(p.c_amax, rmax, lane, wave, reinterpret_cast<float*>(h2_sm));
+    if (p.c_amax) {
+        __syncthreads();
+        if (tid < 3 && w0 + tid < nwin && h2_wmax[tid]) atomicMax(reinterpret_cast<unsigned*>(p.c_amax) + w0 + tid, h2_wmax[tid]);
+    }
 }
 
 
@@ -559,6 +578,7 @@ bool gemm_h2_supports(const GemmParams& p) {
     if (p.gather && (p.R != 1 || p.Cc % XK != 0)) return false;
     if (p.N % 64 != 0) return false;
     if (gemm_is_skinny(p)) return false;            // a handful of windows: latency-bound, mocha_gemm_skinny
+    if (p.rows_per_win < 64) return false;          // a 128-row tile touches at most three windows
     return true;
 }
 

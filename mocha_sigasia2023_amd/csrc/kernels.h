@@ -43,14 +43,14 @@ struct GemmParams {
     int persistent = 768, persistent_max_n = 512;
     int tile64_below = 0;         // gemm_x3.hip: mid-size launches with fewer 64 x 128 tiles than this take 64 x 64 tiles (option "gemm_tile64_below")
     // gemm_h2.hip (two fp16 planes, three passes; option "gemm_f16x2"): the packed two-plane image of W and 1 / S_w per row (launch_pack_h2);
-    // a_amax: a bound on |A| (after a_lrelu) in DEVICE memory - the launch's activation scale comes from it; c_amax: null, or where the
-    // epilogue leaves the largest magnitude it stores (atomic max) - the next launch's a_amax.  Such a bound is H2_AMAX_WAYS floats
-    // H2_AMAX_STRIDE apart whose maximum counts (H2_AMAX_FLOATS in all, zero = unset): the workgroups of a mid-size launch all finish at
-    // the same moment, and their atomics on ONE address serialise in L2 (measured: + 20 us on a 20 us launch)
+    // rows_per_win: consecutive rows of the launch that form one WINDOW (the path's independent unit; >= 64); a_amax: per window a bound on
+    // |A| (after a_lrelu), a vector in DEVICE memory - the window's activation scale comes from it; c_amax: null, or the vector where the
+    // epilogue leaves, per window, the largest magnitude it stores (atomic max; zeroed by the caller) - a later launch's a_amax
     const unsigned short* Wh2 = nullptr;
     const float* w_inv = nullptr;
     const float* a_amax = nullptr;
     float* c_amax = nullptr;
+    int rows_per_win = 0;
 };
 hipError_t launch_gemm(const GemmParams& p, hipStream_t s);
 bool gemm_is_narrow(const GemmParams& p);
@@ -66,13 +66,13 @@ size_t gemm_x3_packed_elems(int N, int K);
 hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s, const float* wsub = nullptr);   // wsub: K values subtracted from every row
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s);
 // fp32 GEMM on the fp16 matrix pipe (gemm_h2.hip): both operands as two fp16 planes with power-of-two scales, three MFMA passes.
-constexpr int H2_AMAX_WAYS = 32, H2_AMAX_STRIDE = 32, H2_AMAX_FLOATS = H2_AMAX_WAYS * H2_AMAX_STRIDE;
 hipError_t gemm_h2_init();
 bool gemm_h2_supports(const GemmParams& p);
 size_t gemm_h2_packed_elems(int N, int K);
 hipError_t launch_pack_h2(const float* W, int N, int K, unsigned short* out, float* w_inv /*N*/, hipStream_t s);
 hipError_t launch_gemm_h2(const GemmParams& p, hipStream_t s);      // needs p.Wh2, p.w_inv, p.a_amax
-hipError_t launch_absmax(const float* x, long long n, float* out /*H2_AMAX_FLOATS, zeroed by the caller*/, hipStream_t s, float mul = 1.f, float add = 0.f);   // out = max(out, mul * max|x| + add)
+hipError_t launch_absmax(const float* x, long long nwin, long long per, float* out /*nwin, zeroed by the caller*/, hipStream_t s, float mul = 1.f, float add = 0.f);   // out[w] = max(out[w], mul * max|window w of x| + add)
+hipError_t launch_gather_f32(const float* table, const int32_t* idx, long long rows, float* out, int n, hipStream_t s);    // out[i] = table[clamp(idx[i])]
 
 
 // ---------------------------------------------------------------------------------------

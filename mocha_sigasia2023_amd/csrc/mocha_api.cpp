@@ -180,19 +180,21 @@ struct mocha_ctx {
     bool attn_x3 = true;               // the Generator's attention as plane products on the bf16 pipe (attention_x3.hip)
     std::map<std::tuple<const float*, int, int>, unsigned short*> x3w;
     // fp32 GEMMs on the fp16 matrix pipe with two planes / three passes (gemm_h2.hip; option "gemm_f16x2", default off): packed images and
-    // per-row inverse scales of the weights (made on first use), and the activation bounds the launches scale by: device scalars in `amax`,
-    // AMAX_SLOTS per workspace set and stage (0 encoder, 1 decoder, 2 to_mot; a stage zeroes its slots when it starts, so a later stage may
-    // read an earlier one's), `amax_ok` = the slot was really written by a launch of that engine (host-side bookkeeping)
+    // per-row inverse scales of the weights (made on first use), and the PER-WINDOW activation bounds the launches scale by: vectors of
+    // AMAX_WIN floats in `amax` (entry w = window w of the chunk), AMAX_SLOTS per workspace set and stage (0 encoder, 1 decoder, 2 to_mot,
+    // 3 embedding; a stage zeroes the slots it can take when it starts, so a later stage may read an earlier one's), `amax_ok` = the slot was
+    // really written by a launch of that engine or by mocha_absmax (host-side bookkeeping)
     bool gemm_h2 = false;
     struct H2Img { unsigned short* img; float* w_inv; };
     std::map<std::tuple<const float*, int, int>, H2Img> h2w;
     static constexpr int AMAX_SLOTS = 40, AMAX_STAGES = 4;             // stages: 0 encoder, 1 decoder, 2 to_mot, 3 embedding
     static constexpr int AMAX_USED[4] = {2 + 4 * 8, 1 + 3 * 8, 5, 5};      // slots a stage can take (depth <= 8): what its start zeroes
-    float* amax = nullptr;                                            // MAX_SETS x AMAX_STAGES x AMAX_SLOTS bounds of H2_AMAX_FLOATS floats (kernels.h), then the two below
+    static constexpr int AMAX_WIN = 4096;                             // windows per chunk the bound vectors cover (larger chunks: the option stays off for them)
+    float* amax = nullptr;                                            // MAX_SETS x AMAX_STAGES x AMAX_SLOTS vectors of AMAX_WIN floats, then amax_in
     std::vector<char> amax_ok = std::vector<char>(MAX_SETS * AMAX_STAGES * AMAX_SLOTS, 0);
-    int amax_stage = 0, amax_next = 0; bool amax_idle = true;
-    float* amax_in = nullptr;                                         // constant: the bound of an instance-normalised token, (n - 1) / sqrt(n) < 9.5 for 90 tokens
-    float* amax_bank = nullptr; bool amax_bank_ok = false;            // the current bank's encoded rows (mocha_bank_set)
+    int amax_stage = 0, amax_next = 0, amax_b = 0; bool amax_idle = true;
+    float* amax_in = nullptr;                                         // constant vector: the bound of an instance-normalised token, (n - 1) / sqrt(n) < 9.5 for 90 tokens
+    float* amax_bank = nullptr; size_t amax_bank_cap = 0; bool amax_bank_ok = false;     // per entry of the current bank: the largest magnitude of its encoded rows (mocha_bank_set)
     const float* amax_enc_of[MAX_SETS] = {nullptr, nullptr, nullptr}; float* amax_enc[MAX_SETS] = {nullptr, nullptr, nullptr};   // encoder output pointer -> its slot
     const float* amax_dec_of[MAX_SETS] = {nullptr, nullptr, nullptr}; float* amax_dec[MAX_SETS] = {nullptr, nullptr, nullptr};   // decoder output pointer -> its slot
     const float* amax_tok_of[MAX_SETS] = {nullptr, nullptr, nullptr}; float* amax_tok[MAX_SETS] = {nullptr, nullptr, nullptr};   // embedding output pointer -> its slot
@@ -523,50 +525,54 @@ void h2_drop_images(mocha_ctx* c) {
 int amax_alloc(mocha_ctx* c) {                                       // once, when the option is switched on (never inside a capture)
     if (c->amax) return 0;
     const size_t n = (size_t)mocha_ctx::MAX_SETS * mocha_ctx::AMAX_STAGES * mocha_ctx::AMAX_SLOTS;
-    int rc = dev_alloc(c, &c->amax, (n + 2) * H2_AMAX_FLOATS);
+    int rc = dev_alloc(c, &c->amax, (n + 1) * mocha_ctx::AMAX_WIN);
     if (rc) return rc;
-    c->amax_in = c->amax + n * H2_AMAX_FLOATS; c->amax_bank = c->amax_in + H2_AMAX_FLOATS;
-    const float k = 9.5f;
-    HIPCHK(c, hipMemset(c->amax, 0, (n + 2) * H2_AMAX_FLOATS * sizeof(float)));
-    HIPCHK(c, hipMemcpy(c->amax_in, &k, sizeof(float), hipMemcpyHostToDevice));
+    c->amax_in = c->amax + n * mocha_ctx::AMAX_WIN;
+    HIPCHK(c, hipMemset(c->amax, 0, n * mocha_ctx::AMAX_WIN * sizeof(float)));
+    const std::vector<float> k(mocha_ctx::AMAX_WIN, 9.5f);
+    HIPCHK(c, hipMemcpy(c->amax_in, k.data(), k.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
 // b: windows of this chunk - up to 4 every GEMM of the path runs on the few-rows kernels (gemm_is_skinny), which neither read nor leave
 // bounds: the stage then hands out no slots (no memset / absmax launches in the streamed per-window step)
 int amax_begin(mocha_ctx* c, int stage, hipStream_t s, int b) {
-    c->amax_idle = !c->gemm_h2 || !c->amax || b < 5;
+    c->amax_idle = !c->gemm_h2 || !c->amax || b < 5 || b > mocha_ctx::AMAX_WIN;
     if (c->amax_idle) return 0;
-    c->amax_stage = stage; c->amax_next = 0;
+    c->amax_stage = stage; c->amax_next = 0; c->amax_b = b;
     const size_t base = ((size_t)c->cur * mocha_ctx::AMAX_STAGES + stage) * mocha_ctx::AMAX_SLOTS;
     std::fill(c->amax_ok.begin() + base, c->amax_ok.begin() + base + mocha_ctx::AMAX_SLOTS, 0);
-    HIPCHK(c, hipMemsetAsync(c->amax + base * H2_AMAX_FLOATS, 0, (size_t)mocha_ctx::AMAX_USED[stage] * H2_AMAX_FLOATS * sizeof(float), s));
+    // the first b entries of every slot the stage can take: one strided memset
+    HIPCHK(c, hipMemset2DAsync(c->amax + base * mocha_ctx::AMAX_WIN, mocha_ctx::AMAX_WIN * sizeof(float), 0, (size_t)b * sizeof(float),
+                               (size_t)mocha_ctx::AMAX_USED[stage], s));
     return 0;
 }
-float* amax_slot(mocha_ctx* c) {                                      // a fresh (zero) bound of the current stage, or null when the engine is off
+float* amax_slot(mocha_ctx* c) {                                      // a fresh (zero) bound vector of the current stage, or null when the engine is off
     if (c->amax_idle || !c->gemm_h2 || !c->amax || c->amax_next >= mocha_ctx::AMAX_USED[c->amax_stage]) return nullptr;
-    return c->amax + (((size_t)c->cur * mocha_ctx::AMAX_STAGES + c->amax_stage) * mocha_ctx::AMAX_SLOTS + c->amax_next++) * H2_AMAX_FLOATS;
+    return c->amax + (((size_t)c->cur * mocha_ctx::AMAX_STAGES + c->amax_stage) * mocha_ctx::AMAX_SLOTS + c->amax_next++) * mocha_ctx::AMAX_WIN;
 }
-ptrdiff_t amax_index(const mocha_ctx* c, const float* slot) {         // slot number inside the arena, or -1 (amax_in / amax_bank / foreign)
+ptrdiff_t amax_index(const mocha_ctx* c, const float* slot) {         // slot number inside the arena, or -1 (amax_in / foreign)
     if (!c->amax || !slot || slot < c->amax) return -1;
-    const ptrdiff_t i = (slot - c->amax) / H2_AMAX_FLOATS;
+    const ptrdiff_t i = (slot - c->amax) / mocha_ctx::AMAX_WIN;
     return i < (ptrdiff_t)c->amax_ok.size() ? i : -1;
 }
-const float* amax_use(const mocha_ctx* c, const float* slot) {        // the bound if a launch wrote it (or it is one of the two outside the arena), else null
+const float* amax_use(const mocha_ctx* c, const float* slot) {        // the bound if a launch wrote it (or it lies outside the arena: the caller checked), else null
     if (!c->gemm_h2 || !slot || !c->amax) return nullptr;
     const ptrdiff_t i = amax_index(c, slot);
     if (i >= 0) return c->amax_ok[i] ? slot : nullptr;
-    return slot;                                                     // amax_in / amax_bank: the caller checked
+    return slot;
 }
-int amax_measure(mocha_ctx* c, hipStream_t s, const float* x, long long n, float** slot) {      // *slot = max |x| (mocha_absmax)
+// *slot[w] = mul * max |window w of x| + add for the chunk's windows of `per` floats each (mocha_absmax)
+int amax_measure(mocha_ctx* c, hipStream_t s, const float* x, int nwin, long long per, float** slot, float mul = 1.f, float add = 0.f) {
     *slot = amax_slot(c);
     if (!*slot) return 0;
-    LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * n, launch_absmax(x, n, *slot, s));
+    LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * nwin * per, launch_absmax(x, nwin, per, *slot, s, mul, add));
     c->amax_ok[amax_index(c, *slot)] = 1;
     return 0;
 }
 
 int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p0) {
     GemmParams p = p0; p.tile64_below = c->gemm_tile64_below; p.persistent = c->gemm_persistent; p.persistent_max_n = c->gemm_persistent_max_n;
+    if (p.rows_per_win <= 0) p.rows_per_win = 90;      // rows of a launch per window: 90 tokens unless the site says otherwise (to_mot's joint rows)
     if (c->gemm_h2 && p.a_amax && gemm_h2_supports(p)) {
         mocha_ctx::H2Img img;
         int rc = h2_image(c, s, p, &img);
@@ -633,8 +639,8 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
     c->amax_tok_of[c->cur] = nullptr;
     if (c->gemm_h2 && !c->amax_idle && !raw && c->fold_joint && c->gemm_x3 && c->embed_sums && c->emb_l1 > 0.f && (u_amax = amax_slot(c))) {
         const long long per = 60ll * V * c->cfg.C_in;
-        LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * b * per, launch_absmax(X, b * per, u_amax, s, c->emb_l1, c->emb_bmax));
-        if (X2 && b2 > 0) LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * b2 * per, launch_absmax(X2, b2 * per, u_amax, s, c->emb_l1, c->emb_bmax));
+        LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * b * per, launch_absmax(X, b, per, u_amax, s, c->emb_l1, c->emb_bmax));
+        if (X2 && b2 > 0) LAUNCH(c, s, "mocha_absmax", "h2.absmax", 0.0, 4.0 * b2 * per, launch_absmax(X2, b2, per, u_amax + b, s, c->emb_l1, c->emb_bmax));
         c->amax_ok[amax_index(c, u_amax)] = 1;
     }
     float* x5_amax = nullptr;
@@ -736,7 +742,7 @@ int run_encoder(mocha_ctx* c, const float* tokens, int b, float* encoded, hipStr
     float* x_amax = nullptr;
     if (c->gemm_h2 && !c->amax_idle) {
         if (tokens == c->amax_tok_of[c->cur] && amax_use(c, c->amax_tok[c->cur])) x_amax = c->amax_tok[c->cur];      // the embedding's last GEMM left it
-        else { rc0 = amax_measure(c, s, tokens, (long long)M * 256, &x_amax); if (rc0) return rc0; }
+        else { rc0 = amax_measure(c, s, tokens, b, 90ll * 256, &x_amax); if (rc0) return rc0; }
     }
     c->amax_enc_of[c->cur] = nullptr;
     for (int l = 0; l < c->cfg.enc_depth; ++l) {
@@ -836,11 +842,21 @@ int run_decoder(mocha_ctx* c, const float* src, const float* cha, int b, float* 
     const float* v_amax = nullptr;
     if (c->gemm_h2 && !c->amax_idle) {
         const float* vsrc = gather_table ? gather_table : cha;
-        if (vsrc && vsrc == c->bank_enc && c->amax_bank_ok) v_amax = c->amax_bank;
-        else if (vsrc && vsrc == c->amax_enc_of[c->cur]) v_amax = amax_use(c, c->amax_enc[c->cur]);
+        // per source window: its matched entry's bound (gathered through the indices), or the same window's character features
+        const float* table = nullptr;
+        if (vsrc && vsrc == c->bank_enc && c->amax_bank_ok) table = c->amax_bank;
+        else if (vsrc && vsrc == c->amax_enc_of[c->cur]) table = amax_use(c, c->amax_enc[c->cur]);
+        if (table && gather_table) {
+            float* slot = amax_slot(c);
+            if (slot) {
+                LAUNCH(c, s, "mocha_gather_f32", "h2.gather", 0.0, 12.0 * b, launch_gather_f32(table, gather_idx, gather_rows, slot, b, s));
+                c->amax_ok[amax_index(c, slot)] = 1;
+                v_amax = slot;
+            }
+        } else if (table) v_amax = table + (cha - vsrc) / (90 * 256);          // cha = rows of the encoder's output: window for window
         else if (cha && !gather_table) {            // caller-supplied character features (mocha_decoder): measured
             float* slot = nullptr;
-            int rc = amax_measure(c, s, cha, (long long)M * 256, &slot); if (rc) return rc;
+            int rc = amax_measure(c, s, cha, b, 90ll * 256, &slot); if (rc) return rc;
             v_amax = amax_use(c, slot);
         }
     }
@@ -920,7 +936,7 @@ int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s
     float* t_amax = nullptr;
     if (c->gemm_h2 && !c->amax_idle) {
         if (tokens == c->amax_dec_of[c->cur] && amax_use(c, c->amax_dec[c->cur])) t_amax = c->amax_dec[c->cur];
-        else { int rc = amax_measure(c, s, tokens, (long long)M * 256, &t_amax); if (rc) return rc; }
+        else { int rc = amax_measure(c, s, tokens, b, 90ll * 256, &t_amax); if (rc) return rc; }
     }
     LAUNCH(c, s, "mocha_body_front", "mot.body_front", b * 90.0 * 512 * 12, b * 90.0 * (256 + 512) * 4, launch_body_front(tokens, DW(c, "A_b"), WS(c, "xA"), b * 15, s));
     GemmParams g1 = plain(WS(c, "xA"), 512, DW(c, "mot.Wgb"), WS(c, "t1"), 256, M, 256, 512);
@@ -944,7 +960,7 @@ int run_to_mot(mocha_ctx* c, const float* tokens, int b, float* Y, hipStream_t s
         GemmParams g4 = plain(WS(c, "y2c"), 64, DW(c, "mot.Wt2p"), WS(c, "z"), 256, b * 15 * V, 256, 192);
         g4.gather = 1; g4.T_out = 15; g4.V = V; g4.ntaps = 3; g4.pad = 2; g4.stride = 4; g4.tstep = 4; g4.R = 1; g4.T_full = 60;
         g4.tshift = 2; g4.Cc = 64; g4.T_src = 15; g4.bias = DW(c, "mot.bt2p");
-        g4.a_amax = amax_use(c, g3.c_amax);
+        g4.a_amax = amax_use(c, g3.c_amax); g4.rows_per_win = 15 * V;
         if (b >= c->upsample_split_min) {
             // large batches: two launches of two taps each instead of one with a third of its weight blocks zero
             GemmParams ga = g4; ga.W = DW(c, "mot.Wt2a"); ga.N = 128; ga.K = 128; ga.ntaps = 2;
@@ -1736,8 +1752,16 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
     if (current) {
         c->amax_bank_ok = false;
         if (c->gemm_h2) {
-            HIPCHK(c, hipMemsetAsync(c->amax_bank, 0, H2_AMAX_FLOATS * sizeof(float), s));
-            LAUNCH(c, s, "mocha_absmax", "bank.absmax", 0.0, 4.0 * N * D, launch_absmax(c->bank_enc, (long long)N * D, c->amax_bank, s));
+            if (c->amax_bank_cap < (size_t)N) {
+                HIPCHK(c, hipDeviceSynchronize());
+                if (c->amax_bank) { dev_free(c, c->amax_bank); c->amax_bank = nullptr; c->amax_bank_cap = 0; }
+                if ((rc = dev_alloc(c, &c->amax_bank, (size_t)N))) return rc;
+                c->amax_bank_cap = (size_t)N;
+            }
+            HIPCHK(c, hipMemsetAsync(c->amax_bank, 0, (size_t)N * sizeof(float), s));
+            for (int64_t n0 = 0; n0 < N; n0 += 65535)      // (the kernel's grid.y)
+                LAUNCH(c, s, "mocha_absmax", "bank.absmax", 0.0, 4.0 * std::min<int64_t>(65535, N - n0) * D,
+                       launch_absmax(c->bank_enc + (size_t)n0 * D, std::min<int64_t>(65535, N - n0), (long long)D, c->amax_bank + n0, s));
             c->amax_bank_ok = true;
         }
     }
@@ -2655,15 +2679,23 @@ int mocha_linear(mocha_ctx* c, const float* x, const float* w, const float* bias
     GemmParams p = plain(x, K, w, y, N, (int)M, N, K);
     p.bias = bias;
     if (engine == 3) {                              // two fp16 planes, three passes: the activation bound is measured here (mocha_absmax)
+        p.rows_per_win = 1024;
         if (!gemm_h2_supports(p)) return fail(c, MOCHA_ERR_ARG, "mocha_linear: M=%lld N=%d K=%d is outside the f16x2 engine", (long long)M, N, K);
-        void* img = nullptr; float* aux = nullptr;       // aux: [N] inverse weight scales, then the activation bound (H2_AMAX_FLOATS)
+        void* img = nullptr; float* aux = nullptr;       // aux: [N] inverse weight scales, then the activation bounds of the "windows" (blocks of 1 024 rows here)
         HIPCHK(c, hipMalloc(&img, gemm_h2_packed_elems(N, K) * sizeof(unsigned short)));
         const size_t n4 = ((size_t)N + 3) / 4 * 4;
-        hipError_t e = hipMalloc((void**)&aux, (n4 + H2_AMAX_FLOATS) * sizeof(float));
-        if (e == hipSuccess) e = hipMemsetAsync(aux + n4, 0, H2_AMAX_FLOATS * sizeof(float), s);
+        const int rpw = 1024; const long long nwin = (M + rpw - 1) / rpw;
+        hipError_t e = hipMalloc((void**)&aux, (n4 + (size_t)nwin) * sizeof(float));
+        if (e == hipSuccess) e = hipMemsetAsync(aux + n4, 0, (size_t)nwin * sizeof(float), s);
         if (e == hipSuccess) e = launch_pack_h2(w, N, K, (unsigned short*)img, aux, s);
-        if (e == hipSuccess) e = launch_absmax(x, (long long)M * K, aux + n4, s);
-        p.Wh2 = (const unsigned short*)img; p.w_inv = aux; p.a_amax = aux + n4;
+        for (long long w0 = 0; w0 < nwin && e == hipSuccess; w0 += 65535) {
+            const long long nw = std::min<long long>(65535, nwin - w0);
+            // the last block may be short: measured on its own
+            const long long full = (w0 + nw == nwin && M % rpw) ? nw - 1 : nw;
+            if (full > 0) e = launch_absmax(x + (size_t)w0 * rpw * K, full, (long long)rpw * K, aux + n4 + w0, s);
+            if (e == hipSuccess && full < nw) e = launch_absmax(x + (size_t)(w0 + full) * rpw * K, 1, (long long)(M % rpw) * K, aux + n4 + w0 + full, s);
+        }
+        p.Wh2 = (const unsigned short*)img; p.w_inv = aux; p.a_amax = aux + n4; p.rows_per_win = rpw;
         if (e == hipSuccess) e = launch_gemm_h2(p, s);
         if (e == hipSuccess) e = hipStreamSynchronize(s);
         (void)hipFree(img); if (aux) (void)hipFree(aux);

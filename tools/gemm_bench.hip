@@ -86,21 +86,28 @@ int main(int argc, char** argv) {
         if (getenv("MOCHA_BENCH_PERSISTENT")) p.persistent = atoi(getenv("MOCHA_BENCH_PERSISTENT"));      // 0: every launch on the one-shot grid (mocha_gemm_x3)
         if (getenv("MOCHA_BENCH_ALRELU")) p.a_lrelu = 1;               // LeakyReLU on the A operand as it is split: what an A-operand prologue costs the K loop
         const bool x3 = mode == 36 && gemm_x3_supports(p);
-        const bool h2 = mode == 22 && gemm_h2_supports(p);
-        float* daux = nullptr;                                         // [N] inverse weight scales | bias [N] | activation bound | output bound (H2_AMAX_FLOATS each)
+        p.rows_per_win = sh.M % 90 == 0 ? 90 : 1024;
+        const bool h2 = mode == 22 && !sh.gather && gemm_h2_supports(p);
+        float* daux = nullptr;                                         // [N] inverse weight scales | bias [N] | per-window activation bounds | per-window output bounds
         float* dres = nullptr;
         const bool epi = getenv("MOCHA_BENCH_EPI") != nullptr;        // bias + residual epilogue (out_proj / ff2); the float64 check is skipped
-        CK(hipMalloc(&daux, ((size_t)2 * sh.N + 2 * H2_AMAX_FLOATS) * 4)); CK(hipMemset(daux, 0, ((size_t)2 * sh.N + 2 * H2_AMAX_FLOATS) * 4));
+        const int rpw = sh.M % 90 == 0 ? 90 : 1024;                    // rows per "window" of the two-plane fp16 engine's scales
+        const long long nwin = (sh.M + rpw - 1) / rpw;
+        CK(hipMalloc(&daux, ((size_t)2 * sh.N + 2 * nwin) * 4)); CK(hipMemset(daux, 0, ((size_t)2 * sh.N + 2 * nwin) * 4));
         if (epi) { CK(hipMalloc(&dres, nc * 4)); CK(hipMemset(dres, 0, nc * 4)); p.bias = daux + sh.N; p.residual = dres; p.ldr = sh.N; }
         if (h2) {
             unsigned short* dWh = nullptr;
             CK(hipMalloc(&dWh, gemm_h2_packed_elems(sh.N, sh.K) * 2)); CK(launch_pack_h2(dW, sh.N, sh.K, dWh, daux, 0));
-            CK(launch_absmax(dA, (long long)na, daux + 2 * sh.N, 0));
-            p.Wh2 = dWh; p.w_inv = daux; p.a_amax = daux + 2 * sh.N;
-            if (getenv("MOCHA_BENCH_CAMAX")) p.c_amax = daux + 2 * sh.N + H2_AMAX_FLOATS;      // the epilogue's atomic maximum of what it stores
+            for (long long w0 = 0; w0 < nwin; w0 += 65535) {
+                const long long nw = std::min<long long>(65535, nwin - w0), full = (w0 + nw == nwin && sh.M % rpw) ? nw - 1 : nw;
+                if (full > 0) CK(launch_absmax(dA + (size_t)w0 * rpw * lda, full, (long long)rpw * lda, daux + 2 * sh.N + w0, 0));
+                if (full < nw) CK(launch_absmax(dA + (size_t)(w0 + full) * rpw * lda, 1, (long long)(sh.M % rpw) * lda, daux + 2 * sh.N + w0 + full, 0));
+            }
+            p.Wh2 = dWh; p.w_inv = daux; p.a_amax = daux + 2 * sh.N; p.rows_per_win = rpw;
+            if (getenv("MOCHA_BENCH_CAMAX")) p.c_amax = daux + 2 * sh.N + nwin;      // the epilogue's per-window maxima of what it stores
         }
         const bool rezero = h2 && p.c_amax && getenv("MOCHA_BENCH_REZERO");      // the output bound starts from zero at every launch, as in the pipeline
-        auto run = [&]() { if (rezero) (void)hipMemsetAsync(p.c_amax, 0, H2_AMAX_FLOATS * 4, 0); return h2 ? launch_gemm_h2(p, 0) : x3 ? launch_gemm_x3(p, 0) : launch_gemm(p, 0); };
+        auto run = [&]() { if (rezero) (void)hipMemsetAsync(p.c_amax, 0, nwin * 4, 0); return h2 ? launch_gemm_h2(p, 0) : x3 ? launch_gemm_x3(p, 0) : launch_gemm(p, 0); };
         long long* dstamp = nullptr;
         if (getenv("MOCHA_BENCH_STAMPS") && x3) { CK(hipMalloc(&dstamp, (size_t)65536 * 32)); CK(hipMemset(dstamp, 0, (size_t)65536 * 32)); p.wsub = (const float*)dstamp; }
         for (int i = 0; i < 3; ++i) CK(run());
