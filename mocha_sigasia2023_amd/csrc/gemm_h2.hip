@@ -175,6 +175,26 @@ hipError_t launch_pack_h2(const float* W, int N, int K, unsigned short* out, flo
     return hipGetLastError();
 }
 
+// per-window maxima of what a tile stores: a thread keeps one register per window the tile touches (at most three), the waves reduce them ONCE per
+// tile (an LDS atomic per stored value - 32 lanes on one address, 16 times per thread - cost the 9 876-tile qkv launch 64 us), the workgroup
+// leaves them in the output's bound vector with at most three global atomics
+__device__ __forceinline__ void h2_track(float (&mw)[3], int wl, float m) {
+    mw[0] = wl == 0 ? fmaxf(mw[0], m) : mw[0];
+    mw[1] = wl == 1 ? fmaxf(mw[1], m) : mw[1];
+    mw[2] = wl == 2 ? fmaxf(mw[2], m) : mw[2];
+}
+__device__ __forceinline__ void h2_amax_out(float* c_amax, float (&mw)[3], unsigned* wmax /*LDS, zeroed at kernel start*/, int w0, int nwin, int lane, int tid) {
+    if (!c_amax) return;                             // uniform
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float m = mw[k];
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if (lane == 0 && m > 0.f) atomicMax(&wmax[k], __float_as_uint(m));
+    }
+    __syncthreads();
+    if (tid < 3 && w0 + tid < nwin && wmax[tid]) atomicMax(reinterpret_cast<unsigned*>(c_amax) + w0 + tid, wmax[tid]);
+}
+
 // LRELU: LeakyReLU(0.2) on the activations as they are split; GATHER: temporal-conv gather (kernels.h) instead of plain rows.
 // Compile-time so that a K step is one basic block the scheduler can interleave.
 // TM: 32-row MFMA blocks per wave: 2 = the 128-row tile; 1 = a 64-row tile (four waves of 32 x 64) for mid-size launches
@@ -435,6 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         const f32x4 bias4 = p.bias ? bload(rsBias, cb, 0u) : zero4;
         const f32x4 winv4 = bload(rsWinv, cb, 0u);                             // 1 / S_w[n] of this thread's column quad
+        float mw[3] = {0.f, 0.f, 0.f};                                         // this thread's largest stored magnitude per window the tile touches
         const bool pre_res = p.residual != nullptr, pre_rb = !pre_res && p.rowbias != nullptr;
         f32x4 pre[2];
         auto fetch_pre = [&](int k) __attribute__((always_inline)) {
@@ -473,7 +494,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
                         else if (p.act == 2) { v[0] = h2_lrelu(v[0]); v[1] = h2_lrelu(v[1]); v[2] = h2_lrelu(v[2]); v[3] = h2_lrelu(v[3]); }
                         else if (p.act == 3) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
                         bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
-                        if (p.c_amax) atomicMax(&h2_wmax[(rloc >= wb1) + (rloc >= wb2)], __float_as_uint(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])))));
+                        h2_track(mw, (rloc >= wb1) + (rloc >= wb2), fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                     }
                 }
             } else
@@ -491,19 +512,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
                 if ((pre_res || pre_rb) && NIT * h + it + 2 < NIT * TM) fetch_pre(NIT * h + it + 2);      // ahead of this store
                 if (m0 + rloc < p.M) {
                     bstore(rsC, v, (unsigned)rloc * (unsigned)p.ldc * 4u + cb, 0u);
-                    if (p.c_amax) atomicMax(&h2_wmax[(rloc >= wb1) + (rloc >= wb2)], __float_as_uint(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])))));
+                    h2_track(mw, (rloc >= wb1) + (rloc >= wb2), fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 }
             }
             if (h + 1 < TM) __syncthreads();
         }
-        if (p.c_amax) {                              // uniform.  The tile's per-window maxima -> the output's bound vector (a few atomics per address per launch)
-            __syncthreads();
-            if (tid < 3 && w0 + tid < nwin && h2_wmax[tid]) atomicMax(reinterpret_cast<unsigned*>(p.c_amax) + w0 + tid, h2_wmax[tid]);
-        }
+        h2_amax_out(p.c_amax, mw, h2_wmax, w0, nwin, lane, tid);
         return;
     }
 
     // ragged tiles (N not a multiple of 128, unaligned leading dimensions): straight from the accumulators
+    float mwr[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int rloc = (wm * TM + i) * 32 + l31;
@@ -532,12 +551,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
                     crow[c1] = x;
                     rmax = fmaxf(rmax, fabsf(x));
                 }
-        if (p.c_amax) atomicMax(&h2_wmax[(rloc >= wb1) + (rloc >= wb2)], __float_as_uint(rmax));
+        h2_track(mwr, (rloc >= wb1) + (rloc >= wb2), rmax);
     }
-    if (p.c_amax) {
-        __syncthreads();
-        if (tid < 3 && w0 + tid < nwin && h2_wmax[tid]) atomicMax(reinterpret_cast<unsigned*>(p.c_amax) + w0 + tid, h2_wmax[tid]);
-    }
+    h2_amax_out(p.c_amax, mwr, h2_wmax, w0, nwin, lane, tid);
 }
 
 
