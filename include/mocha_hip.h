@@ -363,10 +363,11 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * v_mfma_f32_32x32x16_f16 passes per product instead of three bf16 planes and six passes (gemm_h2.hip): x = fp16(S x) + fp16(residual)
  * carries 22 bits, a b ~ a0 b0 + a0 b1 + a1 b0, fp32 accumulation.  Per product 2^-22 instead of an fp32 multiply's 2^-24; a whole dot
  * product comes out CLOSER to float64 than on either fp32 engine (the accumulator's roundings dominate; tests/test_gemm_f16x2.py) at
- * 0.65-0.75 of the time.  Power-of-two scales: per weight row at pack time; per launch for the activations, from a bound the producing
- * launch leaves in device memory (or one the arithmetic implies) - rows more than five decades below a tensor's largest magnitude keep
- * fewer digits than fp32 would.  Launches without such a bound (the embedding, calls on caller-supplied activations) stay on the bf16
- * planes; the attention and the matcher always do.  The current bank's bound is taken at the next mocha_bank_set.
+ * 0.65-0.75 of the time.  Power-of-two scales: per weight row at pack time; per WINDOW for the activations, from bounds the producing
+ * launch leaves in device memory (or that the arithmetic implies) - a window's result does not depend on the rest of the batch; rows more
+ * than five decades below their window's largest magnitude keep fewer digits than fp32 would.  Launches without a bound (the raw-pose
+ * embedding, calls of up to four windows) stay on the bf16 planes; the attention and the matcher always do.  The current bank's per-entry
+ * bounds are taken at the next mocha_bank_set.
  * Every option that changes which kernels a step launches bumps mocha_generation(ctx). */
 int mocha_set_option(mocha_ctx* ctx, const char* name, int value);
 
