@@ -296,7 +296,8 @@ BANK4K_IDX_CRC32_N1 = {"545d209a9ac5cbed": {22: 4269089464, 24: 2772088534},    
                        "ad527b6ce6c3a29e": {22: 4269089464, 24: 2772088534},      # + pair_overlap host change
                        "4701c3d0797f58db": {22: 4269089464, 24: 2772088534},      # profiles/r05/q_bank4k_v2{2,4}.json
                        "776b690774403d41": {22: 4269089464, 24: 2772088534},      # + the opt-in gemm_h2.hip: profiles/r05/t_bank4k_v2{2,4}.json
-                       "147d1ee70460bdde": {22: 4269089464, 24: 2772088534}}      # the final tree: profiles/r05/v_bank4k_v2{2,4}.json
+                       "147d1ee70460bdde": {22: 4269089464, 24: 2772088534},      # profiles/r05/v_bank4k_v2{2,4}.json
+                       "fe2e96e1e7691a5b": {22: 4269089464, 24: 2772088534}}      # the final tree (per-window scales of the opt-in engine): profiles/r05/w_bank4k_v2{2,4}.json
 XGMI_LINK_GBS = 153.0            # one xGMI link, one direction (MI355X: 7 links per GPU, point-to-point)
 
 
