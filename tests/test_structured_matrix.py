@@ -55,3 +55,25 @@ def test_structured_matrix_bounds():
     assert np.median(eh) <= np.median(eo) and np.percentile(eh, 90) <= np.percentile(eo, 90) and eh.max() <= 2.0 * eo.max(), "(2) population bound"
     ratio = np.array([r["e_h64"] / max(1e-4 * max(1.0, r["ymax"]), 2.0 * r["e_o64"]) for r in g2])
     assert ratio.max() <= 1.0, f"(3) per-row bound exceeded by a factor {ratio.max():.2f}: {g2[int(ratio.argmax())]}"
+
+
+@pytest.mark.timeout(3000)
+def test_structured_matrix_bounds_two_plane_fp16_engine():
+    """The same three bounds with mocha_set_option("gemm_f16x2", 1) - at 48 windows per case, where the path's GEMMs are batch-size launches
+    and really run on the two-plane fp16 engine (24 windows run the few-rows kernels): gain 2, seed 0 and gain 1.5, seed 0, ten cases each;
+    the larger matrix of the round is profiles/r05/x_structured_matrix_f16x2_48windows.txt."""
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    import structured_matrix as M
+    rows, _ = M.run(seeds=1, gains=[2.0], n=48, out_path=None, engine_names=["f16x2"])
+    rows_lo, _ = M.run(seeds=1, gains=[1.5], n=48, out_path=None, engine_names=["f16x2"])
+    rows = rows + rows_lo
+    assert all(r["finite"] for r in rows)
+    lo = [r for r in rows if r["gain"] <= 1.5]; g2 = [r for r in rows if r["gain"] == 2.0]
+    worst_lo = max(r["e_ho"] for r in lo)
+    assert worst_lo < 1e-4, f"(1) literal bar at gain <= 1.5: |hip - oracle32| = {worst_lo:.2e}"
+    eh = np.array([r["e_h64"] for r in g2]); eo = np.array([r["e_o64"] for r in g2])
+    print(f"[matrix, f16x2] gain 2, {len(g2)} rows: |hip - f64| median {np.median(eh):.2e} p90 {np.percentile(eh, 90):.2e} max {eh.max():.2e}   "
+          f"|oracle32 - f64| median {np.median(eo):.2e} p90 {np.percentile(eo, 90):.2e} max {eo.max():.2e}")
+    assert np.median(eh) <= np.median(eo) and np.percentile(eh, 90) <= np.percentile(eo, 90) and eh.max() <= 2.0 * eo.max(), "(2) population bound"
+    ratio = np.array([r["e_h64"] / max(1e-4 * max(1.0, r["ymax"]), 2.0 * r["e_o64"]) for r in g2])
+    assert ratio.max() <= 1.0, f"(3) per-row bound exceeded by a factor {ratio.max():.2f}: {g2[int(ratio.argmax())]}"
