@@ -297,7 +297,8 @@ BANK4K_IDX_CRC32_N1 = {"545d209a9ac5cbed": {22: 4269089464, 24: 2772088534},    
                        "4701c3d0797f58db": {22: 4269089464, 24: 2772088534},      # profiles/r05/q_bank4k_v2{2,4}.json
                        "776b690774403d41": {22: 4269089464, 24: 2772088534},      # + the opt-in gemm_h2.hip: profiles/r05/t_bank4k_v2{2,4}.json
                        "147d1ee70460bdde": {22: 4269089464, 24: 2772088534},      # profiles/r05/v_bank4k_v2{2,4}.json
-                       "fe2e96e1e7691a5b": {22: 4269089464, 24: 2772088534}}      # the final tree (per-window scales of the opt-in engine): profiles/r05/w_bank4k_v2{2,4}.json
+                       "fe2e96e1e7691a5b": {22: 4269089464, 24: 2772088534},      # profiles/r05/w_bank4k_v2{2,4}.json
+                       "cabe9d3fdec0f1e1": {22: 4269089464, 24: 2772088534}}      # the final tree (w + comment fixes): profiles/r05/y_bank4k_v22.json
 XGMI_LINK_GBS = 153.0            # one xGMI link, one direction (MI355X: 7 links per GPU, point-to-point)
 
 

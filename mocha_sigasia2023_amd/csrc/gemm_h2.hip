@@ -3,10 +3,11 @@
 //   x = (h0 + h1) / S,  h0 = fp16(S x), h1 = fp16(S x - h0)            (round to nearest even: 22 significant bits; S a power of two)
 //   a b ~ a0 b0 + (a0 b1 + a1 b0)                                      (the dropped a1 b1 is 2^-22 |ab|, like the planes' own truncation)
 //
-// Every fp16 x fp16 product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16.  Measured against float64 the result is MORE
-// accurate than both fp32 engines of the library (gemm_f32.hip's exact pipe and gemm_x3.hip's three bf16 planes / six passes): what
-// a K-long fp32 dot product loses is dominated by the accumulator's own roundings, and three passes have half as many as six
-// (tools/f16x2_sim.py; tests/test_gemm_engines.py; profiles/r05/r_f16x2_prototype_gemm_bench.txt) - at 0.62-0.75 of the six-pass time.
+// Every fp16 x fp16 product is exact in the fp32 accumulator of v_mfma_f32_32x32x16_f16.  Measured against float64 the result is, at the
+// path's K (256 ... 1 280), MORE accurate than both fp32 engines of the library (gemm_f32.hip's exact pipe and gemm_x3.hip's three bf16
+// planes / six passes): what a K-long fp32 dot product loses is dominated by the accumulator's own roundings, and three passes have half
+// as many as six; at K <= 64 the planes' 2^-22 shows, still below the exact pipe (tools/f16x2_sim.py; tests/test_gemm_f16x2.py;
+// profiles/r05/r_f16x2_prototype_gemm_bench.txt) - at 0.62-0.75 of the six-pass time.
 // It is NOT a per-product-faithful fp32 multiply (2^-22 instead of 2^-24 per product), which is why it is an option.
 //
 // Scales (exact powers of two, so the result does not depend on them while nothing leaves fp16's normal range):
@@ -22,7 +23,7 @@
 //
 // Kernel: the one-shot grid of gemm_x3.hip's plane GEMM (that file has the reasoning for the tiling, the LDS image, the loaders and the counted waits)
 // with two planes per operand: 128 x 128 / 64 x 128 / 128 x 64 / 64 x 64 tiles, K step 16, per step and wave 8 ds_read_b128 feed 12
-// MFMAs, 24 TM split instructions (v_cvt_pk_f16_f32, v_cvt_f32_f16, subtract) interleaved two (TN = 1: four) per MFMA; 34 KB of LDS.
+// MFMAs (TM = TN = 2), 12 TM split instructions (v_cvt_pk_f16_f32, v_cvt_f32_f16, subtract) interleaved two (TN = 1: four) per MFMA; 34 KB of LDS.
 #include "kernels.h"
 #include "device_utils.h"
 #include <type_traits>

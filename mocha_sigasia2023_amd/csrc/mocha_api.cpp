@@ -192,7 +192,7 @@ struct mocha_ctx {
     static constexpr int AMAX_WIN = 4096;                             // windows per chunk the bound vectors cover (larger chunks: the option stays off for them)
     float* amax = nullptr;                                            // MAX_SETS x AMAX_STAGES x AMAX_SLOTS vectors of AMAX_WIN floats, then amax_in
     std::vector<char> amax_ok = std::vector<char>(MAX_SETS * AMAX_STAGES * AMAX_SLOTS, 0);
-    int amax_stage = 0, amax_next = 0, amax_b = 0; bool amax_idle = true;
+    int amax_stage = 0, amax_next = 0; bool amax_idle = true;
     float* amax_in = nullptr;                                         // constant vector: the bound of an instance-normalised token, (n - 1) / sqrt(n) < 9.5 for 90 tokens
     float* amax_bank = nullptr; size_t amax_bank_cap = 0; bool amax_bank_ok = false;     // per entry of the current bank: the largest magnitude of its encoded rows (mocha_bank_set)
     const float* amax_enc_of[MAX_SETS] = {nullptr, nullptr, nullptr}; float* amax_enc[MAX_SETS] = {nullptr, nullptr, nullptr};   // encoder output pointer -> its slot
@@ -538,7 +538,7 @@ int amax_alloc(mocha_ctx* c) {                                       // once, wh
 int amax_begin(mocha_ctx* c, int stage, hipStream_t s, int b) {
     c->amax_idle = !c->gemm_h2 || !c->amax || b < 5 || b > mocha_ctx::AMAX_WIN;
     if (c->amax_idle) return 0;
-    c->amax_stage = stage; c->amax_next = 0; c->amax_b = b;
+    c->amax_stage = stage; c->amax_next = 0;
     const size_t base = ((size_t)c->cur * mocha_ctx::AMAX_STAGES + stage) * mocha_ctx::AMAX_SLOTS;
     std::fill(c->amax_ok.begin() + base, c->amax_ok.begin() + base + mocha_ctx::AMAX_SLOTS, 0);
     // the first b entries of every slot the stage can take: one strided memset
@@ -713,7 +713,7 @@ int run_embed(mocha_ctx* c, const float* X, int b, float* tokens, bool add_pos, 
 }
 
 // one transformer layer's attention output projection + FF (net/transformer.py:91-94), shared by enc/dec
-// ao_amax: a bound on |ao| (device scalar, two-plane fp16 engine) or null; *out_amax: the slot the last GEMM wrote the output's largest magnitude to
+// ao_amax: per-window bounds on |ao| (device vector, two-plane fp16 engine) or null; *out_amax: the slot the last GEMM leaves the output's per-window maxima in
 int run_out_ff(mocha_ctx* c, const std::string& p, const float* ao, int inner, const float* resid, int M, int mlp,
                float* out, hipStream_t s, const char* wo = ".Wo", const float* ao_amax = nullptr, float** out_amax = nullptr) {
     GemmParams o = plain(ao, inner, DW(c, p + wo), WS(c, "xb"), 256, M, 256, inner);
