@@ -374,7 +374,7 @@ def projected_scaling_record(a, model, dev, V, sd=None, layout=None):
         pipe = None
         if sd is not None:
             from mocha_sigasia2023_amd import BatchPipeline
-            pipe = BatchPipeline(sd, bank_nm, bank_enc, layout=layout, device=dev, contexts=3, bf16=True)
+            pipe = BatchPipeline(sd, bank_nm, bank_enc, layout=layout, device=dev, contexts=3, bf16=True, options=parse_options(a.options))
         shares = {}
         for n_gpus in (1, 2, 4, 8):
             share = W // n_gpus
