@@ -1,5 +1,5 @@
 #!/bin/bash
-# MFMA utilisation of every kernel of the default bench step, one PMC pass, kernel-trace only.
+# MFMA utilisation of every kernel of the default bench step, one PMC pass, kernel-trace only (BENCH_EXTRA="--options gemm_f16x2=1": with context options).
 # On this chip rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCDs and the SQ counters over the 32 shader engines (SQ_BUSY_CYCLES /
 # GRBM_GUI_ACTIVE = 4.0 for a kernel that keeps every engine busy), and SQ_VALU_MFMA_BUSY_CYCLES counts busy cycles per SIMD,
 # so utilisation = MFMA_BUSY / (GUI_ACTIVE / 8) / 1024 SIMDs.
@@ -7,7 +7,7 @@ tag=${1:-r01}
 cd /tmp; export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 out=$R/gpurun_out/pmc_mfma_$tag; rm -rf $out; mkdir -p $out
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out -o m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --sustained-s 0 > $out/stdout.txt 2> $out/stderr.txt
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out -o m -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --sustained-s 0 ${BENCH_EXTRA:-} > $out/stdout.txt 2> $out/stderr.txt
 python3 - $out <<'PY'
 import csv, sys, glob, collections
 out = sys.argv[1]
