@@ -1,5 +1,5 @@
 #!/bin/bash
-# builds tools/bin/gemm_bench, tools/bin/gemm_bench_f16 (the two-plane fp16 experiment, tools/experiments/gemm_f16x2_r05.hip, in place of gemm_x3.hip) (and, with an argument, an ablation of gemm_x3.hip: build_gemm_bench.sh -DX3_MAXSUM=0 -> tools/bin/gemm_bench_abl)
+# builds tools/bin/gemm_bench, tools/bin/gemm_bench_f16 / gemm_bench_f16k32 (the two-plane fp16 experiments, tools/experiments/gemm_f16x2_r05.hip / gemm_f16x2_k32_r05.hip, in place of gemm_x3.hip) (and, with an argument, an ablation of gemm_x3.hip: build_gemm_bench.sh -DX3_MAXSUM=0 -> tools/bin/gemm_bench_abl)
 set -e
 cd "$(dirname "$0")/.."
 make -C mocha_sigasia2023_amd/csrc -j4 >/dev/null
@@ -10,6 +10,8 @@ C=mocha_sigasia2023_amd/csrc
 $H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_x3.o $C/gemm_h2.o -o tools/bin/gemm_bench
 $H -O3 -fPIC -std=c++17 -w -I $C -c tools/experiments/gemm_f16x2_r05.hip -o tools/bin/gemm_f16x2.o
 $H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2.o $C/gemm_h2.o -o tools/bin/gemm_bench_f16
+$H -O3 -fPIC -std=c++17 -w -I $C -c tools/experiments/gemm_f16x2_k32_r05.hip -o tools/bin/gemm_f16x2_k32.o
+$H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2_k32.o $C/gemm_h2.o -o tools/bin/gemm_bench_f16k32
 if [ -n "$1" ]; then
   $H -O3 -fPIC -std=c++17 -w "$@" -c $C/gemm_x3.hip -o tools/bin/gemm_x3_abl.o
   $H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_x3_abl.o $C/gemm_h2.o -o tools/bin/gemm_bench_abl
