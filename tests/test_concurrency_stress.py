@@ -67,6 +67,17 @@ def victims():
         out[f"decoder[{B}]"] = lambda tok=tok, cha=cha: m.decoder(tok, cha)
         out[f"to_mot[{B}]"] = lambda tok=tok: m.to_mot(tok)
         out[f"encode+mvn[{B}]"] = lambda X=X: m.encode(X, mean, std)
+    # -- the opt-in two-plane fp16 GEMM engine (gemm_h2.hip: VALU between fp16 MFMAs, per-window bound vectors, atomics in the epilogue)
+    mh = Generator(device=dev).load_state_dict(sd).eval()
+    mh.set_option("gemm_f16x2", 1)
+    Xh = torch.from_numpy(synthetic.pose_windows(170, 160)).cuda()
+    tokh = torch.from_numpy(synthetic.token_features(180, 160)).cuda()
+    chah = torch.from_numpy(synthetic.token_features(190, 160)).cuda()
+    out["mot_embedding[160], f16x2"] = lambda: mh.mot_embedding(Xh)
+    out["encoder[160], f16x2"] = lambda: mh.encoder(tokh)
+    out["decoder[160], f16x2"] = lambda: mh.decoder(tokh, chah)
+    out["to_mot[160], f16x2"] = lambda: mh.to_mot(tokh)
+    out["forward[160], f16x2"] = lambda: mh(Xh, Xh)
     m32 = Generator(device=dev).load_state_dict(sd).eval()
     m32.set_option("gemm_bf16x3", 0).set_option("attention_bf16x3", 0)
     X32 = torch.from_numpy(synthetic.pose_windows(41, 96)).cuda()
