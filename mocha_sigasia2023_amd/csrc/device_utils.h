@@ -28,6 +28,11 @@ __device__ __forceinline__ void bstore(__amdgpu_buffer_rsrc_t r, f32x4_t v, unsi
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, 0);
 }
+template <int AUX>      // cache policy bits as a compile-time constant (2 = nt)
+__device__ __forceinline__ void bstore_aux(__amdgpu_buffer_rsrc_t r, f32x4_t v, unsigned voff, unsigned soff) {
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, voff, soff, AUX);
+}
 
 // erf to < 1 ulp (5.8e-8 absolute), branch-free: both ranges are evaluated and selected - straight-line VALU code about half
 // as long as the library erff with its per-lane branches (the GELU of net/transformer.py:27 sits in GEMM epilogues).  Coefficients: N. Juffa's single-precision erff (two minimax polynomials, split at 0.9277); checked against a float64

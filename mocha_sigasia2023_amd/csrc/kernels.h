@@ -65,6 +65,11 @@ bool gemm_x3_supports(const GemmParams& p);
 size_t gemm_x3_packed_elems(int N, int K);
 hipError_t launch_pack_x3(const float* W, int N, int K, unsigned short* out, hipStream_t s, const float* wsub = nullptr);   // wsub: K values subtracted from every row
 hipError_t launch_gemm_x3(const GemmParams& p, hipStream_t s);
+// the same engine with the activations resident in registers (gemm_x3r.hip, round 6): K = 256, N a multiple of 128 (>= 256), plain rows, bias / activation epilogue;
+// bit-identical to launch_gemm_x3.  grid: workgroups (one per CU; 0 = 256)
+hipError_t gemm_x3r_init();
+bool gemm_x3r_supports(const GemmParams& p);
+hipError_t launch_gemm_x3r(const GemmParams& p, hipStream_t s, int grid = 0);
 // fp32 GEMM on the fp16 matrix pipe (gemm_h2.hip): both operands as two fp16 planes with power-of-two scales, three MFMA passes.
 hipError_t gemm_h2_init();
 bool gemm_h2_supports(const GemmParams& p);

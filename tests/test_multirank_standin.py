@@ -70,12 +70,12 @@ def _bank(seed, N):
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("world", [2, 3, 7])
+@pytest.mark.parametrize("world", [2, 4, 7, 8])
 def test_bank_broadcast_reaches_every_rank_bit_for_bit(standin, tmp_path, world):
     """Every rank's bank - rows, encoded entries, centroid, centred row norms, the centred bf16 copy - equals the root's bit
     for bit; query() on every rank returns the root's indices and distances (scan and many-query path); the receivers'
-    buffers survive a growth and a change of root.  world = 7 is the one world size below 9 that does not divide
-    N * 23040, so the tail broadcast runs there."""
+    buffers survive a growth and a change of root.  world = 4 and 8 are the rank counts of the driver's 1 -> 8 curve (VERDICT r5
+    item 2); world = 7 is the one world size below 9 that does not divide N * 23040, so the tail broadcast runs there."""
     run_ranks(standin, world, "broadcast", tmp_path)
     for tag, seed, N, root, bf16 in (("a", 100, 5, 0, False), ("b", 200, 67, 0, True), ("c", 300, 33, world - 1, False)):
         nm, enc = _bank(seed, N)
@@ -137,13 +137,23 @@ def _bench(standin, args, **env):
     return json.loads(lines[0])
 
 
+@pytest.fixture(scope="module")
+def bank4k_one_rank(standin):
+    """ONE 1-rank run of `bench.py --workload bank4k` shared by the tests that compare an N-rank split with it."""
+    return _bench(standin, ["--workload", "bank4k", "--steps", "1", "--warmup", "1"])
+
+
 @pytest.mark.timeout(3000)
-def test_bench_bank4k_split_two_ways_reproduces_the_one_rank_indices(standin):
+def test_bench_bank4k_split_two_ways_reproduces_the_one_rank_indices(standin, bank4k_one_rank):
     """BASELINE configs[3] in small: bench.py --workload bank4k with the 1024 windows split over 2 ranks through shard_bounds
-    and the 4096-entry bf16 bank broadcast through the C ABI gives exactly the indices of the 1-rank run."""
-    one = _bench(standin, ["--workload", "bank4k", "--steps", "1", "--warmup", "1"])
-    two = _bench(standin, ["--workload", "bank4k", "--gpus", "2", "--steps", "1", "--warmup", "1"], MOCHA_BENCH_ONE_GPU="1", MOCHA_BENCH_BACKEND="gloo")
+    and the 4096-entry bf16 bank broadcast through the C ABI gives exactly the indices of the 1-rank run.  The 2-rank run passes
+    --options (ranks other than 0 used to raise on the options record before the rccl collective) - an option at its default
+    value, so the arithmetic is the 1-rank run's."""
+    one = bank4k_one_rank
+    two = _bench(standin, ["--workload", "bank4k", "--gpus", "2", "--steps", "1", "--warmup", "1", "--options", "gemm_persistent=768"],
+                 MOCHA_BENCH_ONE_GPU="1", MOCHA_BENCH_BACKEND="gloo")
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["options"] == {"gemm_persistent": 768} and two["rccl"]["nranks"] == 2
     assert two["bank_broadcast_ms"] is not None and two["bank_broadcast_ms"] > 0
     assert two["idx_crc32"] == one["idx_crc32"] and two["idx_head"] == one["idx_head"]
     assert abs(two["max_abs_Y"] - one["max_abs_Y"]) < 1e-4
@@ -195,18 +205,29 @@ def _check_bank4k_subrecord(b, world):
 
 
 @pytest.mark.timeout(3000)
-def test_bench_default_line_three_ranks_carries_configs3(standin):
-    """`python bench.py --gpus 3`: the driver's N > 1 line has the weak-scaled headline AND the configs[3] sub-record (1024 windows
-    do not divide by 3: shards of 342 / 341 / 341) with the index checksum of the 1-rank run."""
-    rec = _bench(standin, ["--gpus", "3", "--windows", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
+def test_bench_default_line_eight_ranks_is_configs3(standin, bank4k_one_rank):
+    """`python bench.py --gpus 8` - the last point of the driver's 1 -> 8 curve - through the stand-in: the weak-scaled headline over eight
+    ranks AND the configs[3] sub-record exactly as BASELINE words it (1024 windows = 128 per GPU, the 4096-entry bank broadcast from rank 0),
+    with the index checksum of the 1-rank run of the same build (the split: test_fullframework.py:148-158, 440-443)."""
+    rec = _bench(standin, ["--gpus", "8", "--windows", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras"],
                  MOCHA_BENCH_ONE_GPU="1", MOCHA_BENCH_BACKEND="gloo")
-    assert rec["n_gpus"] == 3 and rec["bank_broadcast_error"] is None
-    _check_rccl_record(rec["rccl"], 3, standin)
-    _check_bank4k_subrecord(rec["bank4k"], 3)
-    assert rec["bank4k"]["config"]["windows_per_gpu"] == [342, 341, 341]
-    one = _bench(standin, ["--workload", "bank4k", "--steps", "1", "--warmup", "1"])
-    assert rec["bank4k"]["idx_crc32"] == one["idx_crc32"]
+    assert rec["n_gpus"] == 8 and rec["bank_broadcast_error"] is None and rec["scaling"] == "weak"
+    assert len(rec["per_rank_frames_per_s"]) == 8 and all(v > 0 for v in rec["per_rank_frames_per_s"])
+    _check_rccl_record(rec["rccl"], 8, standin)
+    assert rec["rccl"]["nranks"] == 8
+    _check_bank4k_subrecord(rec["bank4k"], 8)
+    assert rec["bank4k"]["config"]["windows_per_gpu"] == [128] * 8 and len(rec["bank4k"]["per_rank_frames_per_s"]) == 8
+    one = bank4k_one_rank
+    assert rec["bank4k"]["idx_crc32"] == one["idx_crc32"] and rec["bank4k"]["idx_head"] == one["idx_head"]
     assert np.allclose(rec["bank4k"]["y_fingerprint"], one["y_fingerprint"], rtol=1e-5)
+
+
+@pytest.mark.timeout(3000)
+def test_bench_bank4k_four_ranks_uneven_free_split(standin, bank4k_one_rank):
+    """`bench.py --workload bank4k --gpus 4` (256 windows per GPU): the second interior point of the driver's curve, same checksum."""
+    rec = _bench(standin, ["--workload", "bank4k", "--gpus", "4", "--steps", "1", "--warmup", "1"], MOCHA_BENCH_ONE_GPU="1", MOCHA_BENCH_BACKEND="gloo")
+    assert rec["n_gpus"] == 4 and rec["config"]["windows_per_gpu"] == [256] * 4 and rec["rccl"]["nranks"] == 4
+    assert rec["idx_crc32"] == bank4k_one_rank["idx_crc32"] and len(rec["per_rank_frames_per_s"]) == 4
 
 
 @pytest.mark.timeout(600)

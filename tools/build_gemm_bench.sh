@@ -7,12 +7,18 @@ mkdir -p tools/bin
 H="/opt/rocm/bin/hipcc --offload-arch=gfx950"
 $H -O3 -std=c++17 -w -I mocha_sigasia2023_amd/csrc -c tools/gemm_bench.hip -o tools/bin/gemm_bench.o
 C=mocha_sigasia2023_amd/csrc
-$H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_x3.o $C/gemm_h2.o -o tools/bin/gemm_bench
+$H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_x3.o $C/gemm_h2.o $C/gemm_x3r.o -o tools/bin/gemm_bench
 $H -O3 -fPIC -std=c++17 -w -I $C -c tools/experiments/gemm_f16x2_r05.hip -o tools/bin/gemm_f16x2.o
-$H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2.o $C/gemm_h2.o -o tools/bin/gemm_bench_f16
+$H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2.o $C/gemm_h2.o $C/gemm_x3r.o -o tools/bin/gemm_bench_f16
 $H -O3 -fPIC -std=c++17 -w -I $C -c tools/experiments/gemm_f16x2_k32_r05.hip -o tools/bin/gemm_f16x2_k32.o
-$H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2_k32.o $C/gemm_h2.o -o tools/bin/gemm_bench_f16k32
+$H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2_k32.o $C/gemm_h2.o $C/gemm_x3r.o -o tools/bin/gemm_bench_f16k32
+# variants of the register-resident instance (gemm_x3r.hip): ring depth, diagnostics
+for v in "r8:-DX3R_RING=8" "nobar:-DX3R_NOBARRIER" "st4:-DX3R_STAMPS" "st8:-DX3R_STAMPS -DX3R_RING=8" "nt8:-DX3R_RING=8 -DX3R_STORE_AUX=2" "nt4:-DX3R_STORE_AUX=2"; do
+  n=${v%%:*}; f=${v#*:}
+  $H -O3 -fPIC -std=c++17 -w $f -c $C/gemm_x3r.hip -o tools/bin/gemm_x3r_$n.o
+  $H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_x3.o $C/gemm_h2.o tools/bin/gemm_x3r_$n.o -o tools/bin/gemm_bench_x3r_$n
+done
 if [ -n "$1" ]; then
   $H -O3 -fPIC -std=c++17 -w "$@" -c $C/gemm_x3.hip -o tools/bin/gemm_x3_abl.o
-  $H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_x3_abl.o $C/gemm_h2.o -o tools/bin/gemm_bench_abl
+  $H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_x3_abl.o $C/gemm_h2.o $C/gemm_x3r.o -o tools/bin/gemm_bench_abl
 fi

@@ -8,6 +8,7 @@
 #include <vector>
 #include <algorithm>
 #include <string>
+#include <cstring>
 #include "kernels.h"
 using namespace mocha;
 
@@ -28,7 +29,7 @@ int main(int argc, char** argv) {
     int iters = argc > 2 ? atoi(argv[2]) : 20;
     int check = argc > 3 ? atoi(argv[3]) : 1;
     int mode = argc > 4 ? atoi(argv[4]) : 0;      // 0 = exact f32 MFMA (gemm_f32.hip), 36 = bf16 x 3 planes (gemm_x3.hip), 22 = fp16 x 2 planes (gemm_h2.hip)
-    CK(gemm_init()); CK(gemm_x3_init()); CK(gemm_h2_init());
+    CK(gemm_init()); CK(gemm_x3_init()); CK(gemm_h2_init()); CK(gemm_x3r_init());
     std::vector<Shape> shapes = {
         {"enc.qkv      ", B * 90, 1536, 256, 0},
         {"xf.out512    ", B * 90, 256, 512, 0},
@@ -77,7 +78,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dA, na * 4)); CK(hipMalloc(&dW, nw * 4)); CK(hipMalloc(&dC, nc * 4 * (sh.M == 585 && sh.N == 585 ? 16 : 1)));
         CK(hipMemcpy(dA, ha.data(), na * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hw.data(), nw * 4, hipMemcpyHostToDevice));
         unsigned short* dWs = nullptr;
-        if (mode == 36) { CK(hipMalloc(&dWs, gemm_x3_packed_elems(sh.N, sh.K) * 2)); CK(launch_pack_x3(dW, sh.N, sh.K, dWs, 0)); }
+        if (mode == 36 || mode == 37) { CK(hipMalloc(&dWs, gemm_x3_packed_elems(sh.N, sh.K) * 2)); CK(launch_pack_x3(dW, sh.N, sh.K, dWs, 0)); }
         GemmParams p; p.Wsplit = dWs; p.A = dA; p.W = dW; p.C = dC; p.M = sh.M; p.N = sh.N; p.K = sh.K; p.lda = lda; p.ldc = sh.N;
         if (sh.gather) { p.gather = 1; p.T_out = sh.T_out; p.V = sh.V; p.ntaps = sh.ntaps; p.pad = sh.pad; p.stride = sh.stride; p.R = sh.R;
                          p.T_full = sh.T_full; p.tshift = sh.tshift; p.Cc = sh.Cc; p.T_src = sh.T_src; p.ascale = sh.R > 1 ? 0.25f : 1.f; }
@@ -85,7 +86,12 @@ int main(int argc, char** argv) {
         if (getenv("MOCHA_BENCH_TILE64")) p.tile64_below = atoi(getenv("MOCHA_BENCH_TILE64"));      // 64 x 64 tiles for mid-size launches (gemm_x3.hip: x3_tile64)
         if (getenv("MOCHA_BENCH_PERSISTENT")) p.persistent = atoi(getenv("MOCHA_BENCH_PERSISTENT"));      // 0: every launch on the one-shot grid (mocha_gemm_x3)
         if (getenv("MOCHA_BENCH_ALRELU")) p.a_lrelu = 1;               // LeakyReLU on the A operand as it is split: what an A-operand prologue costs the K loop
-        const bool x3 = mode == 36 && gemm_x3_supports(p);
+        const bool x3 = (mode == 36 || mode == 37) && gemm_x3_supports(p);
+        const bool x3r_bias = getenv("MOCHA_BENCH_BIASGELU") != nullptr;       // bias + GELU epilogue (ff1)
+        float* dbias = nullptr;
+        if (x3r_bias) { std::vector<float> hb(sh.N); for (auto& v : hb) v = (float)rand() / RAND_MAX - 0.5f; CK(hipMalloc(&dbias, sh.N * 4)); CK(hipMemcpy(dbias, hb.data(), sh.N * 4, hipMemcpyHostToDevice)); p.bias = dbias; p.act = 1; }
+        const bool x3r = mode == 37 && x3 && gemm_x3r_supports(p);
+        const int x3r_grid = getenv("MOCHA_BENCH_X3R_GRID") ? atoi(getenv("MOCHA_BENCH_X3R_GRID")) : 0;
         p.rows_per_win = sh.M % 90 == 0 ? 90 : 1024;
         const bool h2 = mode == 22 && !sh.gather && gemm_h2_supports(p);
         float* daux = nullptr;                                         // [N] inverse weight scales | bias [N] | per-window activation bounds | per-window output bounds
@@ -107,7 +113,7 @@ int main(int argc, char** argv) {
             if (getenv("MOCHA_BENCH_CAMAX")) p.c_amax = daux + 2 * sh.N + nwin;      // the epilogue's per-window maxima of what it stores
         }
         const bool rezero = h2 && p.c_amax && getenv("MOCHA_BENCH_REZERO");      // the output bound starts from zero at every launch, as in the pipeline
-        auto run = [&]() { if (rezero) (void)hipMemsetAsync(p.c_amax, 0, nwin * 4, 0); return h2 ? launch_gemm_h2(p, 0) : x3 ? launch_gemm_x3(p, 0) : launch_gemm(p, 0); };
+        auto run = [&]() { if (rezero) (void)hipMemsetAsync(p.c_amax, 0, nwin * 4, 0); return h2 ? launch_gemm_h2(p, 0) : x3r ? launch_gemm_x3r(p, 0, x3r_grid) : x3 ? launch_gemm_x3(p, 0) : launch_gemm(p, 0); };
         long long* dstamp = nullptr;
         if (getenv("MOCHA_BENCH_STAMPS") && x3) { CK(hipMalloc(&dstamp, (size_t)65536 * 32)); CK(hipMemset(dstamp, 0, (size_t)65536 * 32)); p.wsub = (const float*)dstamp; }
         for (int i = 0; i < 3; ++i) CK(run());
@@ -118,7 +124,18 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
         double tf = 2.0 * sh.M * sh.N * sh.K / (ms * 1e-3) / 1e12;
         double err = -1, rms = -1;
-        if (check && !epi && !sh.gather && p.ksplit == 1 && (double)sh.M * sh.N * sh.K < 3e11) {
+        long long bitdiff = -1;
+        if (x3r && check) {                                              // bit for bit against mocha_gemm_x3 on the same operands
+            std::vector<float> h1((size_t)sh.M * sh.N), h2v((size_t)sh.M * sh.N);
+            CK(hipMemcpy(h1.data(), dC, nc * 4, hipMemcpyDeviceToHost));
+            CK(hipMemset(dC, 0xff, nc * 4));
+            CK(launch_gemm_x3(p, 0)); CK(hipDeviceSynchronize());
+            CK(hipMemcpy(h2v.data(), dC, nc * 4, hipMemcpyDeviceToHost));
+            bitdiff = 0;
+            for (size_t i = 0; i < nc; ++i) bitdiff += memcmp(&h1[i], &h2v[i], 4) != 0;
+            CK(hipMemset(dC, 0xff, nc * 4)); CK(run()); CK(hipDeviceSynchronize());
+        }
+        if (check && !epi && !x3r_bias && !sh.gather && p.ksplit == 1 && (double)sh.M * sh.N * sh.K < 3e11) {
             CK(hipMalloc(&dR, nc * 8));
             hipLaunchKernelGGL(ref_gemm, dim3((sh.N + 15) / 16, (sh.M + 15) / 16), dim3(16, 16), 0, 0, dA, dW, dR, sh.M, sh.N, sh.K);
             std::vector<float> hc(nc); std::vector<double> hr(nc);
@@ -144,6 +161,15 @@ int main(int argc, char** argv) {
             }
             CK(hipFree(dR));
         }
+        if (dstamp && x3r) {             // gemm_x3r.hip built with -DX3R_STAMPS: per wave {wait, barrier, -, issue, prologue, epilogue, total cycles, realtime ticks}
+            std::vector<long long> h((size_t)256 * 4 * 8);
+            CK(hipMemcpy(h.data(), dstamp, h.size() * 8, hipMemcpyDeviceToHost));
+            double a[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long n = 0;
+            for (int w = 0; w < 256 * 4; ++w) { if (!h[8 * (size_t)w + 6]) continue; for (int i = 0; i < 8; ++i) a[i] += h[8 * (size_t)w + i]; ++n; }
+            if (n) printf("  %ld waves: counted wait %.0f  barrier %.0f  issue (MFMAs, reads, copies) %.0f  unit prologues %.0f  tile epilogues %.0f  of %.0f shader cycles per wave; %.1f us = %.2f GHz\n",
+                          n, a[0] / n, a[1] / n, (a[3] + a[2]) / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n / 100.0, a[6] / a[7] / 10.0);
+            CK(hipFree(dstamp)); dstamp = nullptr;
+        }
         if (dstamp) {
             const int wgs = ((sh.M + 127) / 128 + 7) / 8 * 8 * ((sh.N + 127) / 128);
             std::vector<long long> h((size_t)wgs * 6);
@@ -161,7 +187,9 @@ int main(int argc, char** argv) {
                    n, pro / n, loop / n, loop / n / (sh.K / 16), epi / n, life_us, (pro + loop + epi) / n / life_us / 1e3, span_us, n * life_us / 768.0 / span_us);
             CK(hipFree(dstamp));
         }
-        printf("%s M=%7d N=%5d K=%5d  %9.1f us  %7.2f TFLOP/s  (%.1f%% of 157.3)  %s maxerr=%.3g rms=%.3g\n", sh.name, sh.M, sh.N, sh.K, ms * 1e3, tf, tf / 157.3 * 100, h2 ? "h2 " : x3 ? "x3 " : "f32", err, rms);
+        printf("%s M=%7d N=%5d K=%5d  %9.1f us  %7.2f TFLOP/s  (%.1f%% of 157.3)  %s maxerr=%.3g rms=%.3g\n", sh.name, sh.M, sh.N, sh.K, ms * 1e3, tf, tf / 157.3 * 100, h2 ? "h2 " : x3r ? "x3r" : x3 ? "x3 " : "f32", err, rms);
+        if (bitdiff >= 0) printf("    elements that differ from mocha_gemm_x3 in any bit: %lld of %zu\n", bitdiff, nc);
+        if (dbias) CK(hipFree(dbias));
         CK(hipFree(dA)); CK(hipFree(dW)); CK(hipFree(dC)); if (dWs) CK(hipFree(dWs)); CK(hipFree(daux)); if (dres) CK(hipFree(dres)); if (p.Wh2) CK(hipFree((void*)p.Wh2));
     }
     return 0;
