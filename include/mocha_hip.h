@@ -357,6 +357,10 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * "match_nt" (default 1): the round-4 kernel's bank loads carry the non-temporal hint when a launch reads the bank once (Q <= 128).
  * "pair_overlap" (default 1): mocha_characterize_pair computes the transient bank's decoder constants on the context's internal stream
  * beside the matching chain (forked / joined with events; bit-identical, -0.6 % of the demo step).
+ * "gemm_x3r_min_n" (default 0 = never): K = 256 plane-GEMM launches of at least 8 192 rows and at least this many columns (a multiple of 256)
+ * take the instance that keeps a wave's 32 activation rows resident in registers as planes for all n-tiles (gemm_x3r.hip, round 6):
+ * bit-identical to the tiled instances; measured SLOWER inside the step (enc.qkv 404 -> 422 us, dec.q 144 -> 208, ff1 127 -> 166:
+ * one wave per SIMD has nobody to hide behind; profiles/r06), so it stays an option.
  * "gemm_tile64_below" (default 0): mid-size plane-GEMM launches of 128-multiple width with fewer 64 x 128 tiles than this take 64 x 64
  * tiles (measured no gain); widths that are multiples of 64 only always do at mid size.
  * "gemm_f16x2" (default 0): the encoder's, decoder's and to_mot's batch-size GEMMs as TWO fp16 planes per operand and THREE

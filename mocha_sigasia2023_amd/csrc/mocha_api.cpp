@@ -163,6 +163,7 @@ struct mocha_ctx {
     double* style_scratch = nullptr; size_t style_scratch_rows = 0;     // float64 token means + hidden activations of the style MLP, bank build
     // launch tuning, per context (round 4 kept these as process-wide globals: a second context, or another host thread, changed them underfoot)
     int inorm_split_max = 1 << 30, embed_max_wgs = 512, gemm_persistent = 768, gemm_persistent_max_n = 512; bool embed_sums = true;
+    int gemm_x3r_min_n = 0;            // plane GEMM with the activations resident in registers (gemm_x3r.hip) for K = 256 launches at least this wide (0 = never); option "gemm_x3r_min_n"
     int gemm_tile64_below = 0;         // plane GEMM: 64 x 64 tiles for mid-size 128-multiple launches with fewer 64 x 128 tiles than this (measured: no gain; gemm_x3.hip)
     bool pair_overlap = true;          // characterize_pair: the transient bank's decoder constants on the internal stream, beside the matching
     bool adain_closed = true;          // mocha_adain: qin from the first statistics in closed form (pointwise.hip); 0 = the literal two-pass order
@@ -596,6 +597,10 @@ int gemm(mocha_ctx* c, hipStream_t s, const char* site, const GemmParams& p0) {
         if (rc) return rc;
         if (img) {
             GemmParams q = p; q.Wsplit = img;
+            if (c->gemm_x3r_min_n > 0 && p.N >= c->gemm_x3r_min_n && gemm_x3r_supports(q)) {      // same bits, another schedule (gemm_x3r.hip)
+                LAUNCH(c, s, "mocha_gemm_x3r", site, flops, bytes, launch_gemm_x3r(q, s));
+                return 0;
+            }
             LAUNCH(c, s, "mocha_gemm_x3", site, flops, bytes, launch_gemm_x3(q, s));
             return 0;
         }
@@ -1279,6 +1284,7 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     if (e == hipSuccess) e = gemm_init();
     if (e == hipSuccess) e = gemm_x3_init();
     if (e == hipSuccess) e = gemm_h2_init();
+    if (e == hipSuccess) e = gemm_x3r_init();
     if (e == hipSuccess) e = attention_x3_init();
     if (e == hipSuccess) e = match_mfma_init();
     if (e == hipSuccess) e = match_refine_init();
@@ -2632,6 +2638,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "scan16") { c->scan16 = value != 0; c->generation++; return 0; }             // bank side takes effect at the next mocha_bank_set
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only
     if (n == "gemm_persistent_max_n") { c->gemm_persistent_max_n = value < 128 ? 128 : value; c->generation++; return 0; }
+    if (n == "gemm_x3r_min_n") { c->gemm_x3r_min_n = value < 0 ? 0 : value; c->generation++; return 0; }
     if (n == "gemm_tile64_below") { c->gemm_tile64_below = value < 0 ? 0 : value; c->generation++; return 0; }
     if (n == "gemm_persistent") { c->gemm_persistent = value < 0 ? 0 : (value + 7) / 8 * 8; c->generation++; return 0; }
     if (n == "embed_sums") { c->embed_sums = value != 0; c->generation++; return 0; }
@@ -2713,7 +2720,7 @@ int mocha_linear(mocha_ctx* c, const float* x, const float* w, const float* bias
     HIPCHK(c, hipMalloc(&img, gemm_x3_packed_elems(N, K) * sizeof(unsigned short)));
     hipError_t e = launch_pack_x3(w, N, K, (unsigned short*)img, s);
     p.Wsplit = (const unsigned short*)img; p.persistent = c->gemm_persistent; p.persistent_max_n = c->gemm_persistent_max_n;
-    if (e == hipSuccess) e = launch_gemm_x3(p, s);
+    if (e == hipSuccess) e = (c->gemm_x3r_min_n > 0 && N >= c->gemm_x3r_min_n && gemm_x3r_supports(p)) ? launch_gemm_x3r(p, s) : launch_gemm_x3(p, s);      // option "gemm_x3r_min_n": same bits
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(img);
     if (e != hipSuccess) return fail(c, MOCHA_ERR_HIP, "mocha_linear: %s", hipGetErrorString(e));

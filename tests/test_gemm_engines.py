@@ -227,6 +227,30 @@ def test_persistent_plane_gemm_is_bit_identical(persistent):
         assert torch.equal(a, b), float((a - b).abs().max())
 
 
+def test_register_resident_plane_gemm_is_bit_identical():
+    """Round 6: mocha_gemm_x3r keeps a wave's 32 activation rows as planes in registers for all the n-tiles of a panel
+    and streams only weights (option "gemm_x3r_min_n"; a measured negative inside the step, kept as an option).  Same plane values, same
+    products in the same order per output element: mocha_linear shapes (plain / bias; ragged last panel; more and fewer tile pairs than
+    workgroups) and the whole network - enc.qkv, dec.q plain, xf.ff1 with bias + GELU - are bit-identical to the tiled instances."""
+    sd = weights.synthetic_state_dict(29, 1.5)
+    model = Generator(device=dev()).load_state_dict(sd).eval()
+    g = torch.Generator(device=dev()); g.manual_seed(6)
+    src = torch.from_numpy(synthetic.pose_windows(43, 100)).to(dev()); cha = torch.from_numpy(synthetic.pose_windows(44, 100)).to(dev())
+    shapes = [(8320, 512, 256), (9001, 1536, 256), (8200, 1024, 256), (40000, 256, 256), (70000, 512, 256)]
+    ops = [(torch.randn((M, K), device=dev(), generator=g), torch.randn((N, K), device=dev(), generator=g), torch.randn((N,), device=dev(), generator=g)) for M, N, K in shapes]
+    out, kern = {}, {}
+    for min_n in (0, 256):
+        model.set_option("gemm_x3r_min_n", min_n)
+        model.profile_start()
+        Y = model(src, cha)
+        kern[min_n] = model.profile_stop()["kernels"]
+        out[min_n] = [Y.clone()] + [model.linear(x, w, b, engine=2).clone() for x, w, b in ops] + [model.linear(x, w, None, engine=2).clone() for x, w, b in ops]
+    model.set_option("gemm_x3r_min_n", 0)
+    assert "mocha_gemm_x3r" in kern[256] and "mocha_gemm_x3r" not in kern[0]
+    for a, b in zip(out[0], out[256]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+
+
 @pytest.mark.parametrize("windows,cap", [(1, 512), (2, 512), (7, 3), (37, 512), (150, 64), (300, 512)])
 def test_embed_sums_is_the_two_kernel_path(windows, cap):
     """Round 4: mocha_embed_sums_x3 = mocha_embed_front_x3 + mocha_window_sums<48> with the 192-channel frame rows kept in an LDS ring.

@@ -13,7 +13,7 @@ $H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2.o $C/gemm_h2.o $C/g
 $H -O3 -fPIC -std=c++17 -w -I $C -c tools/experiments/gemm_f16x2_k32_r05.hip -o tools/bin/gemm_f16x2_k32.o
 $H tools/bin/gemm_bench.o $C/gemm_f32.o tools/bin/gemm_f16x2_k32.o $C/gemm_h2.o $C/gemm_x3r.o -o tools/bin/gemm_bench_f16k32
 # variants of the register-resident instance (gemm_x3r.hip): ring depth, diagnostics
-for v in "r8:-DX3R_RING=8" "nobar:-DX3R_NOBARRIER" "st4:-DX3R_STAMPS" "st8:-DX3R_STAMPS -DX3R_RING=8" "nt8:-DX3R_RING=8 -DX3R_STORE_AUX=2" "nt4:-DX3R_STORE_AUX=2"; do
+for v in "r4:-DX3R_RING=4" "contig:-DX3R_CONTIGUOUS" "nopf:-DX3R_NOPREFETCH" "st:-DX3R_STAMPS"; do
   n=${v%%:*}; f=${v#*:}
   $H -O3 -fPIC -std=c++17 -w $f -c $C/gemm_x3r.hip -o tools/bin/gemm_x3r_$n.o
   $H tools/bin/gemm_bench.o $C/gemm_f32.o $C/gemm_x3.o $C/gemm_h2.o tools/bin/gemm_x3r_$n.o -o tools/bin/gemm_bench_x3r_$n

@@ -161,13 +161,13 @@ int main(int argc, char** argv) {
             }
             CK(hipFree(dR));
         }
-        if (dstamp && x3r) {             // gemm_x3r.hip built with -DX3R_STAMPS: per wave {wait, barrier, -, issue, prologue, epilogue, total cycles, realtime ticks}
+        if (dstamp && x3r) {             // gemm_x3r.hip built with -DX3R_STAMPS: per wave {issue, wait, barrier, -, unit changes, -, total cycles, realtime ticks}
             std::vector<long long> h((size_t)256 * 4 * 8);
             CK(hipMemcpy(h.data(), dstamp, h.size() * 8, hipMemcpyDeviceToHost));
             double a[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long n = 0;
             for (int w = 0; w < 256 * 4; ++w) { if (!h[8 * (size_t)w + 6]) continue; for (int i = 0; i < 8; ++i) a[i] += h[8 * (size_t)w + i]; ++n; }
-            if (n) printf("  %ld waves: counted wait %.0f  barrier %.0f  issue (MFMAs, reads, copies) %.0f  unit prologues %.0f  tile epilogues %.0f  of %.0f shader cycles per wave; %.1f us = %.2f GHz\n",
-                          n, a[0] / n, a[1] / n, (a[3] + a[2]) / n, a[4] / n, a[5] / n, a[6] / n, a[7] / n / 100.0, a[6] / a[7] / 10.0);
+            if (n) printf("  %ld waves: issue (MFMAs, reads, copies, store) %.0f  counted wait %.0f  barrier %.0f  unit changes %.0f  other %.0f  of %.0f shader cycles per wave; %.1f us = %.2f GHz\n",
+                          n, a[0] / n, a[1] / n, a[2] / n, a[4] / n, (a[3] + a[5]) / n, a[6] / n, a[7] / n / 100.0, a[6] / a[7] / 10.0);
             CK(hipFree(dstamp)); dstamp = nullptr;
         }
         if (dstamp) {
