@@ -246,8 +246,9 @@ class ShardedContextBank:
         self.encoded = _dev_f32(encoded_full, model.device, (NTOK, DIM), "encoded")
         if self.encoded.shape[0] != n_total:
             raise ValueError("encoded must hold the full bank (it is replicated)")
-        # the local ContextBank only needs `encoded` rows of its own block for its internal bookkeeping
-        self.local = ContextBank(model, shard.contiguous(), self.encoded[self.lo:self.hi], bf16=bf16)
+        # the local ContextBank only needs `encoded` rows of its own block for its internal bookkeeping; its per-entry decoder constants
+        # (+ 92 KB per entry at mocha_bank_set) would never be read - gather() indexes the replicated tensor and the decoder gets the copy
+        self.local = ContextBank(model, shard.contiguous(), self.encoded[self.lo:self.hi], bf16=bf16, dec_cache=False)
         self.model = model
 
     def query(self, query_nm):

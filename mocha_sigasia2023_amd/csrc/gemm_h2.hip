@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
             f32x4 v = ra[i];
             if (LRELU) { v[0] = h2_lrelu(v[0]); v[1] = h2_lrelu(v[1]); v[2] = h2_lrelu(v[2]); v[3] = h2_lrelu(v[3]); }
             u32x2 pl[NPL];
-            f16_split4(v * sa[i], pl);
+            { f32x4 w = v * sa[i]; w[0] = __builtin_amdgcn_fmed3f(w[0], -65504.f, 65504.f); w[1] = __builtin_amdgcn_fmed3f(w[1], -65504.f, 65504.f); w[2] = __builtin_amdgcn_fmed3f(w[2], -65504.f, 65504.f); w[3] = __builtin_amdgcn_fmed3f(w[3], -65504.f, 65504.f); f16_split4(w, pl); }
 #pragma unroll
             for (int q = 0; q < NPL; ++q) *reinterpret_cast<u32x2*>(st + q * XA_PLANE + a_wr + i * 64 * 8) = pl[q];
         }
@@ -385,7 +385,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(H2_WPE, H2_
         float hi[2 * TM][2];
         if (FETCH_W) {
 #pragma unroll
-            for (int e = 0; e < 4 * TM; ++e) { x[e] = rset[P ^ 1][e >> 2][e & 3]; if (LRELU) x[e] = fmaxf(x[e], 0.2f * x[e]); x[e] *= sa[e >> 2]; }
+            // (v_med3: a value above its window's bound - a violated bound - saturates at fp16's largest finite value instead of splitting into inf - inf = NaN)
+            for (int e = 0; e < 4 * TM; ++e) { x[e] = rset[P ^ 1][e >> 2][e & 3]; if (LRELU) x[e] = fmaxf(x[e], 0.2f * x[e]); x[e] = __builtin_amdgcn_fmed3f(x[e] * sa[e >> 2], -65504.f, 65504.f); }
         }
         auto split_op = [&](int k) __attribute__((always_inline)) {     // op k of 12 TM: pair k / 6 (two values), step k % 6
             const int pr = k / 6, o = k % 6;

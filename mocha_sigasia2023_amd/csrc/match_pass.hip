@@ -18,6 +18,7 @@
 //   * workgroups of one K slice share an XCD (blockIdx & 7), so the slice of the queries they all re-read lives in that XCD's L2.
 // NT: the bank loads carry the non-temporal hint (read once; keeps the XCD's L2 for the query slices).
 #include "kernels.h"
+#include <mutex>
 #include "device_utils.h"
 
 namespace mocha {
@@ -215,13 +216,14 @@ int match_pass256_ksplit(int Q, int64_t N) {
 
 template <int PFS, bool NT, bool FILL, int NPL, bool TILED>
 static hipError_t mp_launch2(const MatchPassParams& p, unsigned grid, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_pass256<PFS, NT, FILL, NPL, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)mp_lds_bytes<PFS, NPL>());
-        if (e != hipSuccess) return e;
-        attr = true;
-    }
+    // once per instantiation, whichever host thread comes first (contexts may be driven from several threads)
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    std::call_once(once, [] {
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_pass256<PFS, NT, FILL, NPL, TILED>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)mp_lds_bytes<PFS, NPL>());
+    });
+    if (attr_err != hipSuccess) return attr_err;
     hipLaunchKernelGGL((mocha_match_pass256<PFS, NT, FILL, NPL, TILED>), dim3(grid), dim3(512), (mp_lds_bytes<PFS, NPL>()), s, p);
     return hipGetLastError();
 }

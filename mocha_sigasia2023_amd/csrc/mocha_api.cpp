@@ -514,6 +514,7 @@ int h2_image(mocha_ctx* c, hipStream_t s, const GemmParams& p, mocha_ctx::H2Img*
     HIPCHK(c, launch_pack_h2(p.W, p.N, p.K, reinterpret_cast<unsigned short*>(d), wi, s));
     HIPCHK(c, hipStreamSynchronize(s));
     c->h2w[key] = mocha_ctx::H2Img{reinterpret_cast<unsigned short*>(d), wi};
+    c->generation++;            // a step graph captured before this image existed took the three-plane kernels for this weight: its holder re-captures
     *out = c->h2w[key];
     return 0;
 }
@@ -1798,10 +1799,20 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
                 for (float** p : {&c->bank_kin, &c->bank_gb})
                     if (*p) { dev_free(c, *p); *p = nullptr; }
                 c->bank_dec_cap = 0;
-                if ((rc = dev_alloc(c, &c->bank_kin, (size_t)N * D))) return rc;
-                if ((rc = dev_alloc(c, &c->bank_gb, (size_t)N * 512 * L))) return rc;
-                c->bank_dec_cap = (size_t)N;
+                // + N x (92 KB + 2 KB per decoder layer): about +50 % of the bank's footprint.  If the memory is not there the bank is set all
+                // the same and the decoder computes its constants per call (the round-4 flow), instead of failing mocha_bank_set
+                void* pk = nullptr; void* pg = nullptr;
+                if (hipMalloc(&pk, (size_t)N * D * sizeof(float)) == hipSuccess && hipMalloc(&pg, (size_t)N * 512 * L * sizeof(float)) == hipSuccess) {
+                    c->bank_kin = (float*)pk; c->bank_gb = (float*)pg;
+                    c->owned.push_back(c->bank_kin); c->owned.push_back(c->bank_gb);
+                    c->bank_dec_cap = (size_t)N;
+                } else {
+                    (void)hipGetLastError();                   // the failed allocation's sticky error
+                    if (pk) (void)hipFree(pk);
+                    if (pg) (void)hipFree(pg);
+                }
             }
+            if (c->bank_dec_cap >= (size_t)N) {
             const size_t rows = (size_t)std::min<int64_t>(N, 4096);
             if (c->style_scratch_rows < rows) {
                 if (c->style_scratch) dev_free(c, reinterpret_cast<float*>(c->style_scratch));
@@ -1812,6 +1823,7 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
             }
             if ((rc = build_dec_consts(c, c->bank_enc, N, c->bank_kin, c->bank_gb, c->style_scratch, c->style_scratch + rows * 256, (int64_t)rows, s))) return rc;
             c->bank_dec_valid = true;
+            }
         }
     }
     // many-query matching against a small fp32 bank runs on the plane engine: centred bank as its packed image (6 B per value)
@@ -2653,7 +2665,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "select2") { c->select2 = value != 0; c->generation++; return 0; }
     if (n == "match_pass") { if (value < 0 || value > 2) return fail(c, MOCHA_ERR_ARG, "match_pass must be 0, 1 or 2"); c->match_pass = value; c->generation++; return 0; }
     if (n == "match_nt") { c->match_nt = value != 0; c->generation++; return 0; }
-    if (n == "match_pass_variant") { c->match_pass_variant = value; c->generation++; return 0; }
+    if (n == "match_pass_variant") { c->match_pass_variant = value & 31; c->generation++; return 0; }      // prefetch depth + non-temporal bit; the fill-only floor kernel (bit 256: no multiplies) is tools/match_pass_probe's, never the library's
     if (n == "match_pass_max_q") { c->match_pass_max_q = value; c->generation++; return 0; }
     if (n == "attention_kv") {
         HIPCHK(c, hipSetDevice(c->device));

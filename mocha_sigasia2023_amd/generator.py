@@ -383,9 +383,10 @@ class ContextBank:
     ``ContextBank(model, cha_cnt_nm, cha_encoded).query(src_cnt_nm)`` -> (dist, idx) like
     ``BallTree.query(k=1)``; ``gather(idx)`` -> ``cha_encoded[idx]``."""
 
-    def __init__(self, model: Generator, cha_cnt_nm, cha_encoded, copy: bool = False, bf16: bool = False):
+    def __init__(self, model: Generator, cha_cnt_nm, cha_encoded, copy: bool = False, bf16: bool = False, dec_cache: bool = True):
         model._need()
         self.model = model
+        self._dec_cache = dec_cache  # False: no per-entry decoder constants at mocha_bank_set (+ 92 KB per entry) - for banks whose decode never reads them
         dev = model.device
         self.cnt_nm = _dev_f32(cha_cnt_nm, dev, None, "cha_cnt_nm").reshape(-1, NTOK * DIM)
         self.encoded = _dev_f32(cha_encoded, dev, (NTOK, DIM), "cha_encoded")
@@ -408,7 +409,7 @@ class ContextBank:
 
     def tensors(self):
         """(cnt_nm (N, 23040), encoded (N, 90, 256)) as device tensors: the bank's own, or - for a bank that arrived by
-        ``mocha_bank_broadcast`` and lives in the context - copies made once (``mocha_bank_export``)."""
+        ``mocha_bank_broadcast`` and lives in the context - fresh copies (``mocha_bank_export``) on every call."""
         if self.cnt_nm is None:
             if getattr(self.model, "_bank", None) is not self:
                 raise RuntimeError("a received bank lives in the context and was replaced by another bank: broadcast it again")
@@ -425,7 +426,13 @@ class ContextBank:
                 raise RuntimeError("a received bank lives in the context and was replaced by another bank: broadcast it again")
             return self
         flags = (0 if self._copy else 1) | (2 if self._bf16 else 0)
-        self.model._ctx.call("mocha_bank_set", _ptr(self.cnt_nm), _ptr(self.encoded), self.N, flags, _stream())
+        if not getattr(self, "_dec_cache", True):
+            self.model.set_option("bank_dec_cache", 0)
+        try:
+            self.model._ctx.call("mocha_bank_set", _ptr(self.cnt_nm), _ptr(self.encoded), self.N, flags, _stream())
+        finally:
+            if not getattr(self, "_dec_cache", True):
+                self.model.set_option("bank_dec_cache", 1)
         self.model._bank = self
         return self
 

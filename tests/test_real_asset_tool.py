@@ -72,8 +72,8 @@ def test_make_half_on_a_checkpoint_written_by_the_reference_trainer(tmp_path):
     # the stages are the reference's: the oracle (pinned to the reference elsewhere) reproduces them from the same weights and windows
     tsd = O.to_torch_state(sd)
     with torch.no_grad():
-        enc_s = O.encode(tsd, torch.from_numpy(fx["src_X"]))
-        assert np.abs(enc_s["encoded"].numpy() - fx["src_encoded"]).max() < 1e-4
+        encoded, cnt = O.encode(tsd, torch.from_numpy(fx["src_X"]))
+        assert np.abs(encoded.numpy() - fx["src_encoded"]).max() < 1e-4 and np.abs(cnt.numpy() - fx["src_cnt"]).max() < 1e-4
     idx, _ = O.match_bruteforce(fx["src_cnt_nm"].reshape(6, -1), fx["cha_cnt_nm"].reshape(6, -1))
     assert np.array_equal(idx, fx["frame_index"])
     assert np.allclose(fx["Y_denorm"], fx["Y"] * np.load(norm)["Y_std"][None, None, 1:] + np.load(norm)["Y_mean"][None, None, 1:], atol=1e-6)
