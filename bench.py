@@ -659,6 +659,35 @@ def match_records(model, dev):
                                 "q1_x_16k_f32_scan32 is the scan of the fp32 rows themselves"})
         out[name] = rec
     model.set_option("scan16", 1)
+    # the opt-in one-byte first stage of the few-query scan (option "scan8", match_scan8.hip): a query planted next to a
+    # row (the stage stays on: 1 B per bank value + the exact re-rank of a handful of rows) and a query against the independent N(0, 1)
+    # rows of the records above (thousands of rows inside the byte image's bound: the stage switches itself off on the device after one
+    # call, the steady state is the bf16 scan again)
+    try:
+        model.set_option("scan8", 1)
+        nm = big[:16384]
+        bank = ContextBank(model, nm, nm.view(16384, 90, 256))
+        for name, q in (("planted", nm[4321:4322] + 0.02 * torch.randn((1, D), device=dev, generator=g)), ("random", torch.randn((1, D), device=dev, generator=g))):
+            if name == "random":
+                bank = ContextBank(model, nm, nm.view(16384, 90, 256))      # mocha_bank_set again: the stage's mode word starts from zero
+            for _ in range(3):
+                bank.query(q)
+            torch.cuda.synchronize()
+            pairs = []
+            for _ in range(7):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    bank.query(q)
+                e1.record(); torch.cuda.synchronize()
+                pairs.append(e0.elapsed_time(e1) / 10 * 1e3)
+            us = float(np.median(pairs))
+            moved = (16384 * (1 if name == "planted" else 2) + 8) * D + 16 * 16384
+            out[f"q1_x_16k_f32_scan8_{name}"] = {"us": us, "bytes_moved": moved, "GB/s": moved / us / 1e3, "frac_of_hbm_peak": moved / us / 1e3 / PEAK_HBM_GBS,
+                                                  "note": "option scan8 = 1 (default 0): " + ("1 B per bank value + exact re-rank; same index and distance as q1_x_16k_f32"
+                                                          if name == "planted" else "the stage has switched itself off (steady state: the bf16 scan of q1_x_16k_f32)")}
+    finally:
+        model.set_option("scan8", 0)
     # ... and as `characterize` runs it: 128 windows against the 4 096-entry bf16 bank - the instance norm writes the
     # matcher's centred bf16 query plane itself, so the match is the coarse pass + the selection; per-kernel HIP events of the call sites
     bank = ContextBank(model, big[:4096], big[:4096].view(4096, 90, 256), bf16=True)

@@ -357,6 +357,10 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * "match_nt" (default 1): the round-4 kernel's bank loads carry the non-temporal hint when a launch reads the bank once (Q <= 128).
  * "pair_overlap" (default 1): mocha_characterize_pair computes the transient bank's decoder constants on the context's internal stream
  * beside the matching chain (forked / joined with events; bit-identical, -0.6 % of the demo step).
+ * "scan8" (default 0): mocha_bank_set also keeps the centred rows of an fp32 bank of >= 4 096 entries as biased bytes with a per-row scale and a
+ * measured residual bound (+ N x 23 040 B); mocha_match with <= 4 queries then scans 1 B per value and re-evaluates exactly, on the fp32 rows,
+ * every row the byte image cannot exclude - the result of the exact fp32 search - and falls back, by itself and on the device, to the bf16 scan
+ * for banks / queries where the image excludes too little (independent N(0, 1) rows).  Takes effect at the next mocha_bank_set.
  * "gemm_x3r_min_n" (default 0 = never): K = 256 plane-GEMM launches of at least 8 192 rows and at least this many columns (a multiple of 256)
  * take the instance that keeps a wave's 32 activation rows resident in registers as planes for all n-tiles (gemm_x3r.hip, round 6):
  * bit-identical to the tiled instances; measured SLOWER inside the step (enc.qkv 404 -> 422 us, dec.q 144 -> 208, ff1 127 -> 166:
@@ -407,6 +411,11 @@ int mocha_bank_export(mocha_ctx* ctx, float* cnt_nm, float* encoded, void* strea
  * from, and what the library derived from them - the centroid (90*256), the squared norms of the centred rows (N), the
  * centred bf16 copy (NULL for an fp32 bank).  Any out pointer may be NULL.  For tests that compare the ranks of a
  * mocha_bank_broadcast bit for bit. */
+/* Option "scan8" (round 6; the matcher's one-byte first stage, match_scan8.hip): state[0] = 1 if the current bank carries the byte image,
+ * state[1] = the stage's sticky mode word of workspace set `set` read back from the device (0: calls scan the byte image; 1: the refine
+ * found the image's bounds useless for this bank / these queries and calls scan the bf16 copy; -1: no scratch yet).  Synchronises `stream`.
+ * Replaces nothing in the reference (its BallTree has no such stage): introspection for tests and tooling. */
+int mocha_scan8_state(mocha_ctx* ctx, int set, int32_t* state /*2*/, void* stream);
 int mocha_bank_view(mocha_ctx* ctx, const float** cnt_nm, const float** encoded, const float** centroid, const float** row_norm2,
                     const void** cnt_bf16, int64_t* N);
 

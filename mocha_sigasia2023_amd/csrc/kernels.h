@@ -260,6 +260,14 @@ hipError_t launch_to_bf16(const float* x, const float* sub /*per-column, or null
 hipError_t match_refine_init();
 size_t match_scan16_scratch_words(int64_t N);        // launch_match_scan16's scratch buffer, in 8-byte words; the first ..._head_words() must be zero at first use
 size_t match_scan16_scratch_head_words();
+// the one-byte first stage of the few-query scan (match_scan8.hip; option "scan8"): image + per-row scale + residual bound, the adaptive scan + refine
+hipError_t launch_to_i8(const float* x, const float* centre, void* y, float* scale, float* rho, int64_t rows, int cols, hipStream_t s);
+hipError_t match_scan8_init();
+size_t match_scan8_mode_word();                      // word of the scan16 scratch head that holds the stage's two mode words {this call, next calls}
+hipError_t launch_match_scan8(const void* bank8, const float* scale8, const float* rho8, const void* bank16, const float* rho16, const float* bank,
+                              const float* qc, const float* query, int Q, int64_t N, int D, unsigned long long* scratch, int32_t* idx, float* dist, hipStream_t s);
+hipError_t launch_match_refine(const unsigned long long* keys, const unsigned long long* wgmin, int nwg, const float* rho16, const float* rho8, unsigned* mode,
+                               const float* bank, const float* query, int nq, int64_t N, int D, int32_t* idx, float* dist, unsigned long long* scratch, hipStream_t s);
 hipError_t launch_rowresid(const float* x, const float* centre, const void* x16, float* rho, int64_t rows, int cols, hipStream_t s);
 hipError_t launch_match_scan16(const void* bank16, const float* rho, const float* bank, const float* qc, const float* query, int Q, int64_t N,
                                int D, unsigned long long* scratch, int32_t* idx, float* dist, hipStream_t s);

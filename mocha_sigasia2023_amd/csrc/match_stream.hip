@@ -14,23 +14,13 @@
 // the finish kernel reduces them (no atomics: 16k same-address atomics cost more than the scan).
 // The bank may be fp32 or bf16 (widened exactly on load; half the HBM bytes).
 #include "kernels.h"
+#include "match_stream_body.h"
 
 namespace mocha {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-static constexpr int MS_ROWS_PER_WAVE = 4;      // rows a wave carries through the D loop together
-static constexpr int MS_WAVES = 4;
-static constexpr int MS_CHUNK_F32 = 1280;       // elements of every query staged per step: 5 x 16 B per lane of fp32 bank ...
-static constexpr int MS_CHUNK_BF16 = 1536;      // ... 3 x 16 B per lane of bf16 bank (whole 64-lane rounds; both divide 23 040)
-
-__device__ __forceinline__ unsigned long long pack_key(float v, unsigned row) {
-    unsigned u = __float_as_uint(v);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((unsigned long long)u << 32) | row;
-}
 
 // all_keys != 0 (top-k queries): every row's key goes to partial[q][row] instead of one minimum per workgroup
 template <int Q, bool BF16>
@@ -41,119 +31,7 @@ __global__ __launch_bounds__(256) void mocha_match_stream(const void* __restrict
     constexpr int MS_CHUNK = BF16 ? MS_CHUNK_BF16 : MS_CHUNK_F32;
     __shared__ __attribute__((aligned(16))) float qs[Q * MS_CHUNK];
     __shared__ unsigned long long wbest[MS_WAVES][Q];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long long row0 = ((long long)blockIdx.x * MS_WAVES + wave) * MS_ROWS_PER_WAVE;
-
-    // two partial sums per (row, query) so that the squares accumulate with packed fp32 math (v_pk_fma_f32): with
-    // several queries the scan is VALU-bound, not HBM-bound
-    f32x2 acc[MS_ROWS_PER_WAVE][Q];
-#pragma unroll
-    for (int r = 0; r < MS_ROWS_PER_WAVE; ++r)
-#pragma unroll
-        for (int q = 0; q < Q; ++q) acc[r][q] = f32x2{0.f, 0.f};
-
-    const int nchunks = D / MS_CHUNK;
-    for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();
-        // stage this chunk of every query: Q * 320 float4, 256 threads
-        for (int i = tid; i < Q * (MS_CHUNK / 4); i += 256) {
-            const int q = i / (MS_CHUNK / 4), o = i - q * (MS_CHUNK / 4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < nq) v = reinterpret_cast<const f32x4*>(query + (size_t)q * D + (size_t)ch * MS_CHUNK)[o];
-            reinterpret_cast<f32x4*>(qs)[i] = v;
-        }
-        __syncthreads();
-        if (!BF16) {
-            // 320 float4 per row-chunk: 5 per lane
-            f32x4 bv[MS_ROWS_PER_WAVE][5];
-#pragma unroll
-            for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
-                long long row = row0 + r;
-                row = row < N ? row : N - 1;
-                const f32x4* bp = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(bank) + (size_t)row * D + (size_t)ch * MS_CHUNK);
-#pragma unroll
-                for (int i = 0; i < 5; ++i) bv[r][i] = __builtin_nontemporal_load(bp + lane + 64 * i);
-            }
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-#pragma unroll
-                for (int q = 0; q < Q; ++q) {
-                    const f32x4 qv = reinterpret_cast<const f32x4*>(qs)[q * (MS_CHUNK / 4) + lane + 64 * i];
-#pragma unroll
-                    for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
-                        const f32x4 d = bv[r][i] - qv;
-                        const f32x2 dl = {d[0], d[1]}, dh = {d[2], d[3]};
-                        acc[r][q] = __builtin_elementwise_fma(dl, dl, acc[r][q]);
-                        acc[r][q] = __builtin_elementwise_fma(dh, dh, acc[r][q]);
-                    }
-                }
-        } else {
-            // bf16 bank: 1280 elements = 160 x 16 B per row-chunk: lanes 0..63 take pieces lane, lane+64, (lane+128 < 160)
-            u32x4 bv[MS_ROWS_PER_WAVE][3];
-#pragma unroll
-            for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
-                long long row = row0 + r;
-                row = row < N ? row : N - 1;
-                const u32x4* bp = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(bank) + (size_t)row * D + (size_t)ch * MS_CHUNK);
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const int piece = lane + 64 * i;
-                    u32x4 z = {0u, 0u, 0u, 0u};
-                    bv[r][i] = piece < MS_CHUNK / 8 ? __builtin_nontemporal_load(bp + piece) : z;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int piece = lane + 64 * i;
-                if (piece < MS_CHUNK / 8) {
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) {
-                        const f32x4 q0 = reinterpret_cast<const f32x4*>(qs)[q * (MS_CHUNK / 4) + piece * 2];
-                        const f32x4 q1 = reinterpret_cast<const f32x4*>(qs)[q * (MS_CHUNK / 4) + piece * 2 + 1];
-#pragma unroll
-                        for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
-                            const u32x4 w = bv[r][i];      // 8 bf16: element 2j in the low half of word j
-                            f32x2 d;
-                            d = f32x2{__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u)} - f32x2{q0[0], q0[1]};
-                            acc[r][q] = __builtin_elementwise_fma(d, d, acc[r][q]);
-                            d = f32x2{__uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xffff0000u)} - f32x2{q0[2], q0[3]};
-                            acc[r][q] = __builtin_elementwise_fma(d, d, acc[r][q]);
-                            d = f32x2{__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xffff0000u)} - f32x2{q1[0], q1[1]};
-                            acc[r][q] = __builtin_elementwise_fma(d, d, acc[r][q]);
-                            d = f32x2{__uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xffff0000u)} - f32x2{q1[2], q1[3]};
-                            acc[r][q] = __builtin_elementwise_fma(d, d, acc[r][q]);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    // finish: one wave reduction per (row, query); the workgroup's minimum per query goes to partial[]
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        unsigned long long kmin = ~0ull;
-#pragma unroll
-        for (int r = 0; r < MS_ROWS_PER_WAVE; ++r) {
-            const long long row = row0 + r;
-            float v = acc[r][q][0] + acc[r][q][1];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (row < N) {
-                const unsigned long long k = pack_key(v, (unsigned)row);      // v = squared distance
-                kmin = k < kmin ? k : kmin;
-                if (all_keys && lane == 0 && q < nq) partial[(size_t)q * N + row] = k;
-            }
-        }
-        if (lane == 0) wbest[wave][q] = kmin;
-    }
-    __syncthreads();
-    if (all_keys && !wgmin) return;
-    if (tid < Q) {
-        unsigned long long k = wbest[0][tid];
-#pragma unroll
-        for (int w = 1; w < MS_WAVES; ++w) k = wbest[w][tid] < k ? wbest[w][tid] : k;
-        (all_keys ? wgmin : partial)[(size_t)tid * gridDim.x + blockIdx.x] = k;
-    }
+    match_stream_body<Q, BF16>(bank, query, nq, N, D, partial, all_keys, wgmin, qs, wbest);
 }
 
 // partial minima -> idx[q]; Euclidean distance to the winner in the direct (q-b)^2 form
@@ -297,6 +175,7 @@ hipError_t launch_match_topk(const void* bank, int bank_bf16, const float* query
 // order: identical rows get identical distances whatever else is in the list and however the slices fall.
 // ---------------------------------------------------------------------------------------------------------------------
 static constexpr int RF_T = 1024, RF_W = RF_T / 64, RF_CAP = 4096, RF_SPLIT = 16;
+static constexpr int S8_DEGENERATE = 48;           // candidates in one slice (a sixteenth of the rows) beyond which the byte image is not worth scanning
 
 __global__ __launch_bounds__(256) void mocha_rowresid(const float* __restrict__ x, const float* __restrict__ centre,
                                                       const unsigned short* __restrict__ x16, float* __restrict__ rho, int cols) {
@@ -332,10 +211,16 @@ __device__ __forceinline__ float key_value(unsigned long long k) {
 
 __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long long* __restrict__ keys /*[Q][N]: coarse d16^2 keys*/,
                                                            const unsigned long long* __restrict__ wgmin /*[Q][nwg]: the scan's per-workgroup minima*/,
-                                                           int nwg, const float* __restrict__ rho, const float* __restrict__ bank /*fp32 rows*/,
+                                                           int nwg, const float* __restrict__ rho_bf16, const float* __restrict__ bank /*fp32 rows*/,
                                                            const float* __restrict__ query /*fp32, uncentred*/, long long N, int D,
                                                            int32_t* __restrict__ idx, float* __restrict__ dist,
-                                                           unsigned long long* __restrict__ part /*[Q][RF_SPLIT]*/, unsigned* __restrict__ ticket /*[Q]*/) {
+                                                           unsigned long long* __restrict__ part /*[Q][RF_SPLIT]*/, unsigned* __restrict__ ticket /*[Q]*/,
+                                                           const float* __restrict__ rho8 = nullptr, unsigned* __restrict__ mode = nullptr) {
+    // match_scan8.hip: the keys came from the byte image (mode[0] == 0: their bounds are rho8) or from the bf16 copy; a slice with more than
+    // S8_DEGENERATE candidates under the byte image's bounds switches the NEXT calls to the bf16 scan (mode[1], sticky until mocha_bank_set)
+    const bool from8 = rho8 && mode && mode[0] == 0;
+    const float* __restrict__ rho = from8 ? rho8 : rho_bf16;
+    int slice_cands = 0;
     extern __shared__ __attribute__((aligned(16))) float rf_q[];       // [D]
     __shared__ unsigned long long rk[RF_W];
     __shared__ unsigned long long r_key;
@@ -410,6 +295,7 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
         }
         __syncthreads();
         const int nc = ncand;
+        slice_cands += nc;
         for (int p0 = 0; p0 < nc; p0 += 2) {
             const int nb = nc - p0 < 2 ? nc - p0 : 2;
             constexpr int NL = 6;                                       // 16-byte loads per lane and row: covers segments of up to 384 pieces
@@ -468,6 +354,7 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
     // not complete (a device fault) leaves the ticket at some k != 0 and the scratch head must then be zeroed again by the host
     // (ensure_match_scratch does so whenever it allocates the buffer).  Calls that share a scratch buffer are ordered by their stream.
     __syncthreads();
+    if (tid == 0 && from8 && slice_cands > S8_DEGENERATE) atomicExch(mode + 1, 1u);
     if (tid == 0) {
         __atomic_store_n(part + (size_t)q * RF_SPLIT + sl, best, __ATOMIC_RELAXED);
         __threadfence();
@@ -490,12 +377,22 @@ __global__ __launch_bounds__(RF_T) void mocha_match_refine(const unsigned long l
 
 // words of scratch launch_match_scan16 needs for a bank of N rows: the slices' winners and the arrival tickets (the head: must be
 // ZERO when the buffer is first used), then 8 queries' keys
-size_t match_scan16_scratch_head_words() { return 8 * RF_SPLIT + 8; }
+size_t match_scan16_scratch_head_words() { return 8 * RF_SPLIT + 8 + 1; }      // winners, tickets, the byte stage's two mode words
+size_t match_scan8_mode_word() { return 8 * RF_SPLIT + 8; }
 static size_t scan_nwg(int64_t N) { const int r = MS_WAVES * MS_ROWS_PER_WAVE; return (size_t)((N + r - 1) / r); }
 size_t match_scan16_scratch_words(int64_t N) { return match_scan16_scratch_head_words() + (size_t)8 * N + (size_t)8 * scan_nwg(N); }
 
 hipError_t match_refine_init() {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&mocha_match_refine), hipFuncAttributeMaxDynamicSharedMemorySize, 23040 * 4);
+}
+
+// the refine launch alone (match_scan8.hip scans with its own kernel): keys / wgmin as the scan left them, nq <= 8
+hipError_t launch_match_refine(const unsigned long long* keys, const unsigned long long* wgmin, int nwg, const float* rho16, const float* rho8, unsigned* mode,
+                               const float* bank, const float* query, int nq, int64_t N, int D, int32_t* idx, float* dist, unsigned long long* scratch, hipStream_t s) {
+    unsigned long long* part = scratch;
+    hipLaunchKernelGGL(mocha_match_refine, dim3(nq, RF_SPLIT), dim3(RF_T), (size_t)D * sizeof(float), s, keys, wgmin, nwg, rho16, bank, query,
+                       (long long)N, D, idx, dist, part, reinterpret_cast<unsigned*>(part + 8 * RF_SPLIT), rho8, mode);
+    return hipGetLastError();
 }
 
 // few queries against an fp32 bank through its centred bf16 copy: `qc` = the queries minus the centroid (scan operand), `query` the

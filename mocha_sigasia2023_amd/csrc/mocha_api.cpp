@@ -219,6 +219,10 @@ struct mocha_ctx {
     bool scan16 = true;                // mocha_set_option("scan16", 0) scans the fp32 rows themselves
     void* bank16f = nullptr; size_t bank16f_cap = 0; float* bank_rho = nullptr; size_t bank_rho_cap = 0; bool bank16f_valid = false;
     unsigned long long* scan_keys[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t scan_keys_n[MAX_SETS] = {0, 0, 0};
+    // option "scan8" (default 0): the centred rows of an fp32 bank as biased bytes + per-row scale + residual bound - an adaptive 1 B / value first
+    // stage of the few-query scan (match_scan8.hip); + N x 23 040 B
+    bool scan8 = false;
+    void* bank8 = nullptr; size_t bank8_cap = 0; float* bank8_scale = nullptr; float* bank8_rho = nullptr; bool bank8_valid = false;
     // many-query matching, round 4 (match_select2.hip): the producer of the centred queries hands over the row statistics of the selection's
     // error bound (match_qstat: ||q - c||^2 and the planes' residual per query), the bf16 coarse pass takes two query planes
     // Used for fp32 banks (demo pair 585 x 585: centre + select 44 us against 68; 128 x 4096: 23 against 30).  bf16 banks stay on
@@ -1136,6 +1140,12 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
     if (via16) {
         // fp32 bank through its centred bf16 copy: every row's coarse distance from half the bytes, then the exact fp32 distances of
         // the rows the rounding bound cannot exclude - the result of the fp32 search
+        if (c->scan8 && c->bank8_valid && Q <= 4) {
+            // the adaptive byte stage: 1 B per value while the queries sit close to a few rows, the bf16 scan otherwise (decided on the device)
+            LAUNCH(c, s, "mocha_match_scan_adaptive+refine", "match.stream8", 3.0 * Q * N * D, (double)N * D * 1.0 + 4.0 * Q * D + 16.0 * Q * N,
+                   launch_match_scan8(c->bank8, c->bank8_scale, c->bank8_rho, c->bank16f, c->bank_rho, c->bank_cnt, qc, qnm, Q, N, D, c->scan_keys[set], idx, dist, s));
+            return 0;
+        }
         LAUNCH(c, s, "mocha_match_stream<bf16>+refine", "match.stream16", 3.0 * Q * N * D,
                ((Q + 7) / 8) * (double)N * D * 2.0 + 4.0 * Q * D + 16.0 * Q * N,
                launch_match_scan16(c->bank16f, c->bank_rho, c->bank_cnt, qc, qnm, Q, N, D, c->scan_keys[set], idx, dist, s));
@@ -1286,6 +1296,7 @@ int mocha_create(const mocha_cfg* cfg, int device, mocha_ctx** out) {
     if (e == hipSuccess) e = gemm_x3_init();
     if (e == hipSuccess) e = gemm_h2_init();
     if (e == hipSuccess) e = gemm_x3r_init();
+    if (e == hipSuccess) e = match_scan8_init();
     if (e == hipSuccess) e = attention_x3_init();
     if (e == hipSuccess) e = match_mfma_init();
     if (e == hipSuccess) e = match_refine_init();
@@ -1309,6 +1320,7 @@ void mocha_destroy(mocha_ctx* c) {
     if (c->bank_x3) (void)hipFree(c->bank_x3);
     if (c->pair_x3) (void)hipFree(c->pair_x3);
     if (c->bank16f) (void)hipFree(c->bank16f);
+    if (c->bank8) (void)hipFree(c->bank8);
     for (auto* k : c->scan_keys) if (k) (void)hipFree(k);
     if (c->bcast_hdr) (void)hipFree(c->bcast_hdr);
     if (c->topk_keys) (void)hipFree(c->topk_keys);
@@ -1789,6 +1801,25 @@ static int bank_set_impl(mocha_ctx* c, const float* cnt_nm, const float* encoded
         LAUNCH(c, s, "mocha_to_bf16", "bank.to_bf16", 0.0, 6.0 * N * D, launch_to_bf16(c->bank_cnt, c->bank_center, (int)D, c->bank16f, (int64_t)N * D, s));
         LAUNCH(c, s, "mocha_rowresid", "bank.resid", 3.0 * N * D, 6.0 * N * D, launch_rowresid(c->bank_cnt, c->bank_center, c->bank16f, c->bank_rho, N, (int)D, s));
         c->bank16f_valid = true;
+    }
+    if (current) c->bank8_valid = false;
+    if (current && c->bank16f_valid && c->scan8) {
+        if (c->bank8_cap < (size_t)N) {
+            HIPCHK(c, hipStreamSynchronize(s));                 // (a call still reading the old image)
+            if (c->bank8) HIPCHK(c, hipFree(c->bank8));
+            c->bank8 = nullptr; c->bank8_cap = 0;
+            if (c->bank8_scale) { dev_free(c, c->bank8_scale); c->bank8_scale = nullptr; }
+            if (c->bank8_rho) { dev_free(c, c->bank8_rho); c->bank8_rho = nullptr; }
+            HIPCHK(c, hipMalloc(&c->bank8, (size_t)N * D));
+            if ((rc = dev_alloc(c, &c->bank8_scale, (size_t)N))) return rc;
+            if ((rc = dev_alloc(c, &c->bank8_rho, (size_t)N))) return rc;
+            c->bank8_cap = (size_t)N;
+        }
+        LAUNCH(c, s, "mocha_to_i8", "bank.to_i8", 4.0 * N * D, 9.0 * N * D, launch_to_i8(c->bank_cnt, c->bank_center, c->bank8, c->bank8_scale, c->bank8_rho, N, (int)D, s));
+        // a new bank: the byte stage gets another chance (its mode words, in every workspace set's scratch that exists)
+        for (int st = 0; st < mocha_ctx::MAX_SETS; ++st)
+            if (c->scan_keys[st]) HIPCHK(c, hipMemsetAsync(c->scan_keys[st] + match_scan8_mode_word(), 0, sizeof(unsigned long long), s));
+        c->bank8_valid = true;
     }
     // decoder constants of every entry (round 5): IN(entry) and its AdaIN gamma / beta, read in place through frame_index by the decoder
     if (current) {
@@ -2647,6 +2678,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "upsample_split_min") { c->upsample_split_min = value; c->generation++; return 0; }
     if (n == "fold_upsample") { c->fold_upsample = value != 0; c->generation++; return 0; }
     if (n == "fold_joint") { c->fold_joint = value != 0; c->generation++; return 0; }
+    if (n == "scan8") { c->scan8 = value != 0; if (!value) c->bank8_valid = false; c->generation++; return 0; }     // the image is built at the next mocha_bank_set
     if (n == "scan16") { c->scan16 = value != 0; c->generation++; return 0; }             // bank side takes effect at the next mocha_bank_set
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only
     if (n == "gemm_persistent_max_n") { c->gemm_persistent_max_n = value < 128 ? 128 : value; c->generation++; return 0; }
@@ -2736,6 +2768,20 @@ int mocha_linear(mocha_ctx* c, const float* x, const float* w, const float* bias
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(img);
     if (e != hipSuccess) return fail(c, MOCHA_ERR_HIP, "mocha_linear: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int mocha_scan8_state(mocha_ctx* c, int set, int32_t* state, void* stream) {
+    if (!c || !state || set < 0 || set >= mocha_ctx::MAX_SETS) return fail(c, MOCHA_ERR_ARG, "mocha_scan8_state: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    state[0] = c->scan8 && c->bank8_valid ? 1 : 0;
+    state[1] = -1;
+    if (c->scan_keys[set]) {
+        unsigned w[2] = {0, 0};
+        HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+        HIPCHK(c, hipMemcpy(w, c->scan_keys[set] + match_scan8_mode_word(), sizeof(w), hipMemcpyDeviceToHost));
+        state[1] = (int32_t)w[1];
+    }
     return 0;
 }
 

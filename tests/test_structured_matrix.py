@@ -21,7 +21,7 @@ path's.  "Within 1e-4 of the fp32 reference" has no single answer there; the flo
       round 4's arithmetic - literal AdaIN -> instance norm order, fp32 style MLP - reached 5.0, its rule allowed 4).
 
 Gains 2.25 and 3 are in the committed matrix for the record only: |Y| reaches 80 and 2e4 there and fp32 itself falls apart (the reference is
-5e-2 resp. 5e2 from float64).  This test runs a reduced matrix (gain 2: seeds 0-2; gain 1.5: seed 0; default engines) so that the GPU suite stays in minutes.
+5e-2 resp. 5e2 from float64).  This test runs a reduced matrix (gain 2: seeds 0-1; gain 1.5: seed 0; default engines) so that the GPU suite stays in minutes.
 """
 import os
 import sys
@@ -39,7 +39,7 @@ pytestmark = pytest.mark.gpu
 def test_structured_matrix_bounds():
     assert torch.cuda.is_available(), "GPU tests need a ROCm device"
     import structured_matrix as M
-    rows, _ = M.run(seeds=3, gains=[2.0], n=24, out_path=None, engine_names=["default"])
+    rows, _ = M.run(seeds=2, gains=[2.0], n=24, out_path=None, engine_names=["default"])
     rows_lo, _ = M.run(seeds=1, gains=[1.5], n=24, out_path=None, engine_names=["default"])
     rows = rows + rows_lo
     M.print_tables(rows, M.summarise(rows))
