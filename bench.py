@@ -331,7 +331,9 @@ BANK4K_IDX_CRC32_N1 = {"545d209a9ac5cbed": {22: 4269089464, 24: 2772088534},    
                        "776b690774403d41": {22: 4269089464, 24: 2772088534},      # + the opt-in gemm_h2.hip: profiles/r05/t_bank4k_v2{2,4}.json
                        "147d1ee70460bdde": {22: 4269089464, 24: 2772088534},      # profiles/r05/v_bank4k_v2{2,4}.json
                        "fe2e96e1e7691a5b": {22: 4269089464, 24: 2772088534},      # profiles/r05/w_bank4k_v2{2,4}.json
-                       "cabe9d3fdec0f1e1": {22: 4269089464, 24: 2772088534}}      # the final tree (w + comment fixes): profiles/r05/y_bank4k_v22.json
+                       "cabe9d3fdec0f1e1": {22: 4269089464, 24: 2772088534},      # the final tree (w + comment fixes): profiles/r05/y_bank4k_v22.json
+                       # round 6: the hash is over comment-stripped sources from here on (a comment fix no longer changes it)
+                       "1418133355060f3c": {22: 4269089464, 24: 2772088534}}      # profiles/r06/final_bank4k_v2{2,4}.json
 XGMI_LINK_GBS = 153.0            # one xGMI link, one direction (MI355X: 7 links per GPU, point-to-point)
 
 
