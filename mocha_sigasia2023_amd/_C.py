@@ -84,7 +84,7 @@ SIGNATURES = {
     "mocha_build_info": (C.c_char_p, []),
     "mocha_runtime_version": (_i, []),
     "mocha_bank_export": (_i, [_vp, _vp, _vp, _vp]),
-    "mocha_scan8_state": (_i, [_vp, _i, C.POINTER(C.c_int32), _vp]),
+    "mocha_scan_byte_state": (_i, [_vp, _i, C.POINTER(C.c_int32), _vp]),
     "mocha_bank_view": (_i, [_vp] + [C.POINTER(_vp)] * 5 + [C.POINTER(_i64)]),
     "mocha_profile_start": (_i, [_vp]),
     "mocha_profile_stop": (_i, [_vp, C.c_char_p, _i64]),

@@ -2771,8 +2771,8 @@ int mocha_linear(mocha_ctx* c, const float* x, const float* w, const float* bias
     return 0;
 }
 
-int mocha_scan8_state(mocha_ctx* c, int set, int32_t* state, void* stream) {
-    if (!c || !state || set < 0 || set >= mocha_ctx::MAX_SETS) return fail(c, MOCHA_ERR_ARG, "mocha_scan8_state: bad argument");
+int mocha_scan_byte_state(mocha_ctx* c, int set, int32_t* state, void* stream) {
+    if (!c || !state || set < 0 || set >= mocha_ctx::MAX_SETS) return fail(c, MOCHA_ERR_ARG, "mocha_scan_byte_state: bad argument");
     HIPCHK(c, hipSetDevice(c->device));
     state[0] = c->scan8 && c->bank8_valid ? 1 : 0;
     state[1] = -1;

@@ -23,7 +23,7 @@ def dev():
 
 def scan8_state(model):
     st = (C.c_int32 * 2)()
-    model._ctx.call("mocha_scan8_state", 0, st, None)
+    model._ctx.call("mocha_scan_byte_state", 0, st, None)
     return st[0], st[1]
 
 

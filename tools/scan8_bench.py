@@ -12,7 +12,7 @@ g = torch.Generator(device=dev); g.manual_seed(7)
 nm = torch.randn((NB, D), device=dev, generator=g)
 
 def state():
-    st = (C.c_int32 * 2)(); model._ctx.call("mocha_scan8_state", 0, st, None); return st[0], st[1]
+    st = (C.c_int32 * 2)(); model._ctx.call("mocha_scan_byte_state", 0, st, None); return st[0], st[1]
 
 def time_query(bank, q, reps=10):
     for _ in range(3): bank.query(q)
