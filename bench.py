@@ -753,6 +753,34 @@ def stream_record(model, dev, V):
         model.set_option("lanes", 1)
         out["bf16_bank" if bf16 else ("f32_bank" if scan16 else "f32_bank_scan32")] = rec
     model.set_option("scan16", 1)
+    # the same streamed clip against a bank that CONTAINS it: the 285 windows' own features (+ 1 % noise) planted at scattered rows, as in
+    # tests/test_fullsize_parity.py::test_config4 - every query has ~300 stride-1 neighbours inside the coarse image's bound, all re-ranked
+    # exactly; with the opt-in one-byte first stage (option scan8) beside the default
+    try:
+        nm0 = model.encode(src, m_, s_)[2].reshape(285, D)
+        rows = torch.randperm(16384, device=dev, generator=g)[:285]
+        planted = nm.clone()
+        planted[rows] = nm0 + 0.01 * torch.randn((285, D), device=dev, generator=g)
+        prec = {}
+        for on in (0, 1):
+            model.set_option("scan8", on)
+            bank = ContextBank(model, planted, planted.view(-1, 90, 256))
+            sc = StreamingCharacterizer(bank, m_, s_, use_graph=True)
+            for i in range(5):
+                sc.step(src[i])
+            torch.cuda.synchronize()
+            lat, hits = [], 0
+            for i in range(285):
+                t0 = time.perf_counter()
+                _, ix = sc.step(src[i])
+                torch.cuda.synchronize()
+                lat.append(time.perf_counter() - t0)
+                hits += int(ix.item()) == int(rows[i].item())
+            lat = np.sort(np.asarray(lat)) * 1e3
+            prec["scan8" if on else "default"] = {"p50_ms": float(lat[142]), "p99_ms": float(lat[282]), "planted_row_found": hits}
+        out["f32_bank_planted_clip"] = prec
+    finally:
+        model.set_option("scan8", 0)
     return out
 
 

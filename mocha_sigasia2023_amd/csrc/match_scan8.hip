@@ -11,7 +11,7 @@
 // Whether that pays depends on the GEOMETRY: a query that sits close to a few rows of the bank (gap to the rest much larger than
 // 2 rho8 ~ 3 on unit-variance rows) leaves a handful of candidates; on a bank of independent N(0, 1) rows every distance is 214.7 +- 1
 // and thousands of rows stay inside the bound - the byte scan is then wasted.  So the stage is ADAPTIVE, on the device (the calls
-// may sit in a captured graph): the refine kernel counts its candidates and, if a slice holds more than S8_DEGENERATE of them, sets a sticky
+// may sit in a captured graph): the refine kernel counts its candidates and, if one of its 64 slices holds more than S8_DEGENERATE (12) of them, sets a sticky
 // mode word; from the next call on the same launch runs the bf16 scan of round 3 instead (one kernel, branch at its top: no extra
 // launches either way).  mocha_bank_set clears the word.
 #include "kernels.h"

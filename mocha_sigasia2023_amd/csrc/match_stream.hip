@@ -171,11 +171,13 @@ hipError_t launch_match_topk(const void* bank, int bank_bf16, const float* query
 // RF_SPLIT 1024-thread workgroups per query, each re-ranking the candidates of its slice of the rows (a bank whose rows crowd within
 // the copy's rounding of the best one - hundreds of candidates - is spread over the chip); the workgroup that finishes last picks the
 // smallest (distance, row) key.  The coarse minimum comes from the scan's per-workgroup minima (the scan writes them beside the keys), so
-// a workgroup reads its own sixteenth of the keys only.  A row's terms are summed in 16 fixed segments, one per wave, added in segment
+// a workgroup reads its own slice of the keys only (RF_SPLIT = 64 slices since round 6: a clip whose stride-1 neighbours all sit in the bank leaves ~300
+// candidates per query - at 16 slices their re-rank ran on 16 CUs; same box, streamed step on such a bank 0.438 -> 0.408 ms, an uncrowded call + 1.5 us:
+// profiles/r06/h_refine_slices_ab.txt).  A row's terms are summed in 16 fixed segments, one per wave, added in segment
 // order: identical rows get identical distances whatever else is in the list and however the slices fall.
 // ---------------------------------------------------------------------------------------------------------------------
-static constexpr int RF_T = 1024, RF_W = RF_T / 64, RF_CAP = 4096, RF_SPLIT = 16;
-static constexpr int S8_DEGENERATE = 48;           // candidates in one slice (a sixteenth of the rows) beyond which the byte image is not worth scanning
+static constexpr int RF_T = 1024, RF_W = RF_T / 64, RF_CAP = 4096, RF_SPLIT = 64;
+static constexpr int S8_DEGENERATE = 12;           // candidates in one slice (1 / RF_SPLIT of the rows) beyond which the byte image is not worth scanning (~770 in all)
 
 __global__ __launch_bounds__(256) void mocha_rowresid(const float* __restrict__ x, const float* __restrict__ centre,
                                                       const unsigned short* __restrict__ x16, float* __restrict__ rho, int cols) {
