@@ -119,3 +119,29 @@ def test_streamed_step_graph_with_the_byte_stage(model):
     model.set_option("scan8", 0)
     assert res[1][1] == res[0][1] == rows.cpu().tolist()
     assert torch.equal(res[1][0], res[0][0])
+
+
+def test_byte_stage_edge_cases_ties_outliers_zero_rows_ragged_size(model):
+    """Ragged bank size (not a multiple of the scan's 16 rows per workgroup, nor of the refine's 64 slices), identical rows (ties go to the
+    LOWEST index, as in the bf16-copy path and BallTree's first hit), an all-zero row (scale 1), a row with a 1e4 outlier (its scale swallows
+    every other element: a huge residual bound, the row is always re-ranked): answers equal to the stage-less path bit for bit and to the
+    planted rows.  (A NaN row is not a case: it poisons the bank's centroid in either path, as it would BallTree's construction.)"""
+    g = torch.Generator(device=dev()); g.manual_seed(123)
+    N = 4096 + 37
+    bank = torch.randn((N, D), device=dev(), generator=g)
+    bank[100] = 0.0
+    bank[200, 5] = 1e4
+    bank[1500] = bank[1200]                                   # a tie: the answer must be 1200
+    bank[N - 1] = bank[7] + 0.5                               # the last (ragged) row is somebody's neighbour
+    q = torch.stack([bank[1200] + 0.01 * torch.randn(D, device=dev(), generator=g),
+                     torch.zeros(D, device=dev()) + 1e-3,
+                     bank[200] + 0.01,
+                     bank[N - 1] + 0.001])
+    out = {}
+    for on in (0, 1):
+        model.set_option("scan8", on)
+        b = ContextBank(model, bank, bank.view(N, 90, 256))
+        out[on] = b.query(q)
+    model.set_option("scan8", 0)
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][0], out[1][0])
+    assert out[1][1][:, 0].tolist() == [1200, 100, 200, N - 1]
