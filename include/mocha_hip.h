@@ -357,6 +357,8 @@ int mocha_column_stats(mocha_ctx* ctx, const float* x, int64_t N, float* mean, f
  * "match_nt" (default 1): the round-4 kernel's bank loads carry the non-temporal hint when a launch reads the bank once (Q <= 128).
  * "pair_overlap" (default 1): mocha_characterize_pair computes the transient bank's decoder constants on the context's internal stream
  * beside the matching chain (forked / joined with events; bit-identical, -0.6 % of the demo step).
+ * "match_fold" (default 0; a measured negative kept reproducible): the bf16 many-query coarse pass's last-arriving
+ * K-slab workgroup per tile adds the slabs up into slab 0 and the selection reads one slab; same indices, the pass 53 us slower.
  * "scan8" (default 0): mocha_bank_set also keeps the centred rows of an fp32 bank of >= 4 096 entries as biased bytes with a per-row scale and a
  * measured residual bound (+ N x 23 040 B); mocha_match with <= 4 queries then scans 1 B per value and re-evaluates exactly, on the fp32 rows,
  * every row the byte image cannot exclude - the result of the exact fp32 search - and falls back, by itself and on the device, to the bf16 scan

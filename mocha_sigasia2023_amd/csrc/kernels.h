@@ -223,7 +223,8 @@ hipError_t launch_center_rows(const float* x, const float* centre, void* planes,
 // tiled: the bank as launch_tile_bf16 wrote it (match_tiled_elems(N, D) bf16), or null to read the row-major bank16
 // nt_bank != 0: the bank's LDS-DMA loads carry the non-temporal hint
 hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes = 1,
-                                  const void* tiled = nullptr, int nt_bank = 0);
+                                  const void* tiled = nullptr, int nt_bank = 0, unsigned* tickets = nullptr);
+// tickets (option "match_fold", round 6): ceil(Q / 128) * ceil(N / 128) zeroed words; the last-arriving K-slab workgroup of a tile leaves the slabs' sum in slab 0
 // round 5 (match_pass.hip): 128 queries x 256 rows per workgroup, the bank straight into registers, only the queries through LDS;
 // variant: bits 0-3 register prefetch depth in 64-k stages (0 = default), bit 4 non-temporal bank loads, bit 8 fill only (measurement)
 int match_pass256_ksplit(int Q, int64_t N);

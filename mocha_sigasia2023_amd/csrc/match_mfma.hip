@@ -59,6 +59,9 @@ struct MatchGemmParams {
     int Q; long long N; int D; int ksplit; long long slab_stride; int m_tiles, n_tiles;
     long long a_plane;            // elements between the two stacked query planes (NPL == 2)
     const unsigned short* Bt;     // the bank as the kernel's own LDS image, [n tile][k step][128 rows][64] with the swizzle applied (mocha_tile_bf16), or null
+    // round 6 (option "match_fold"): arrival counters per (m tile, n tile), zero at first use and left at zero; non-null: the LAST of a tile's
+    // K-slab workgroups adds the slabs up, in slab order, into slab 0 - the selection then reads one slab instead of `ksplit`
+    unsigned* tickets;
 };
 
 static constexpr int MG_BM = 128, MG_BN = 128, MG_BK = 64;
@@ -202,6 +205,49 @@ __global__ __launch_bounds__(256) void mocha_match_gemm_bf16_dma(MatchGemmParams
                 }
             }
     }
+    if (!p.tickets || p.ksplit <= 1) return;
+    // ---- fold (round 6): the tile's slabs live on up to 8 XCDs; publish mine (agent-scope release), take a ticket, and the last arrival
+    // reads all of them back (acquire) and leaves their sum - added in slab order from zero, exactly as mocha_match_select adds them - in slab 0
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = atomicAdd(p.tickets + (size_t)mt * p.n_tiles + nt, 1u);
+        s_last = t == (unsigned)p.ksplit - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (vec) {
+        const int c4 = tid & 31, r8 = tid >> 5;                  // a 32-lane half covers one row's 128 columns; 8 rows per iteration
+#pragma unroll 2
+        for (int it = 0; it < MG_BM / 8; ++it) {
+            const int row = m0 + it * 8 + r8;
+            const long long col = n0 + 4 * c4;
+            if (row < p.Q && col < p.N) {
+                const float* src = p.S + (size_t)row * p.N + col;
+                f32x4 part[8];
+#pragma unroll
+                for (int zz = 0; zz < 8; ++zz)
+                    part[zz] = zz < p.ksplit ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (size_t)zz * p.slab_stride)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int zz = 0; zz < 8; ++zz)
+                    if (zz < p.ksplit) sum += part[zz];
+                *reinterpret_cast<f32x4*>(p.S + (size_t)row * p.N + col) = sum;
+            }
+        }
+    } else {
+        for (int e = tid; e < MG_BM * MG_BN; e += 256) {
+            const int row = m0 + e / MG_BN; const long long col = n0 + e % MG_BN;
+            if (row < p.Q && col < p.N) {
+                float sum = 0.f;
+                for (int zz = 0; zz < p.ksplit; ++zz) sum += p.S[(size_t)zz * p.slab_stride + (size_t)row * p.N + col];
+                p.S[(size_t)row * p.N + col] = sum;
+            }
+        }
+    }
+    if (tid == 0) p.tickets[(size_t)mt * p.n_tiles + nt] = 0u;      // for the next launch (same stream)
 }
 
 template <int R, int NPL>
@@ -258,7 +304,7 @@ hipError_t launch_tile_bf16(const void* bank16, void* out, int64_t N, int D, hip
 }
 
 hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S, int Q, int64_t N, int D, int ksplit, hipStream_t s, int planes, const void* tiled,
-                                  int nt_bank) {
+                                  int nt_bank, unsigned* tickets) {
     if (Q <= 0 || N <= 0) return hipSuccess;
     if (D % MG_BK || (ksplit != 1 && ksplit != 2 && ksplit != 4 && ksplit != 8)) return hipErrorInvalidValue;
     if ((long long)MG_BM * D * 2 >= (1ll << 31)) return hipErrorInvalidValue;            // 32-bit buffer offsets inside a tile
@@ -268,6 +314,7 @@ hipError_t launch_match_gemm_bf16(const void* qc16, const void* bank16, float* S
     p.m_tiles = (Q + MG_BM - 1) / MG_BM; p.n_tiles = (int)((N + MG_BN - 1) / MG_BN);
     p.a_plane = (long long)Q * D;
     p.Bt = (const unsigned short*)tiled;
+    p.tickets = ksplit <= 8 ? tickets : nullptr;
     if (planes != 1 && planes != 2) return hipErrorInvalidValue;
     if (tiled && (long long)(D / MG_BK) * MG_BN * MG_BK * 2 >= (1ll << 31)) return hipErrorInvalidValue;      // 32-bit offsets inside a tile's block row
     const long long pairs = (long long)p.n_tiles * ksplit;

@@ -221,6 +221,8 @@ struct mocha_ctx {
     unsigned long long* scan_keys[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t scan_keys_n[MAX_SETS] = {0, 0, 0};
     // option "scan8" (default 0): the centred rows of an fp32 bank as biased bytes + per-row scale + residual bound - an adaptive 1 B / value first
     // stage of the few-query scan (match_scan8.hip); + N x 23 040 B
+    bool match_fold = false;           // option "match_fold": the bf16 coarse pass's last K-slab workgroup per tile sums the slabs; the selection reads one (round 6 experiment)
+    unsigned* fold_tickets[MAX_SETS] = {nullptr, nullptr, nullptr}; size_t fold_tickets_n[MAX_SETS] = {0, 0, 0};
     bool scan8 = false;
     void* bank8 = nullptr; size_t bank8_cap = 0; float* bank8_scale = nullptr; float* bank8_rho = nullptr; bool bank8_valid = false;
     // many-query matching, round 4 (match_select2.hip): the producer of the centred queries hands over the row statistics of the selection's
@@ -1204,8 +1206,36 @@ int do_match(mocha_ctx* c, const float* qnm, int Q, int32_t* idx, float* dist, h
             LAUNCH(c, s, "mocha_match_pass256", "match.qk_bf16", 2.0 * npl * Q * (double)N * D, 2.0 * npl * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
                    launch_match_pass256(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, c->match_pass_variant, npl, t32));
         } else
+        {
+        unsigned* tk = nullptr;
+        if (c->match_fold && ksplit > 1) {
+            const size_t need = (size_t)((Q + 127) / 128) * (size_t)((N + 127) / 128);
+            if (c->fold_tickets_n[set] < need) {
+                HIPCHK(c, hipDeviceSynchronize());
+                if (c->fold_tickets[set]) (void)hipFree(c->fold_tickets[set]);
+                c->fold_tickets[set] = nullptr; c->fold_tickets_n[set] = 0;
+                void* tp = nullptr;
+                HIPCHK(c, hipMalloc(&tp, need * sizeof(unsigned)));
+                HIPCHK(c, hipMemset(tp, 0, need * sizeof(unsigned)));
+                c->fold_tickets[set] = (unsigned*)tp; c->fold_tickets_n[set] = need;
+                c->generation++;
+            }
+            tk = c->fold_tickets[set];
+        }
         LAUNCH(c, s, "mocha_match_gemm_bf16", "match.qk_bf16", 2.0 * npl * Q * (double)N * D, 2.0 * npl * Q * D + 2.0 * N * D + 4.0 * Q * N * ksplit,
-               launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, npl, tiled, (c->match_nt && Q <= 128) ? 1 : 0));
+               launch_match_gemm_bf16(qc, c->bank_bf16, mS.p, Q, N, D, ksplit, s, npl, tiled, (c->match_nt && Q <= 128) ? 1 : 0, tk));
+        if (tk) {                                        // slab 0 holds the sum: the selection reads one slab
+            if (sel2)
+                LAUNCH(c, s, "mocha_match_select2", "match.select", 0.0, 4.0 * Q * N + 4.0 * N + 8.0 * Q,
+                       launch_match_select2(mS.p, 1, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, nullptr, c->bank_bf16,
+                                            c->match_qstat[set].p, 5e-5f, Q, N, D, idx, dist, s));
+            else
+                LAUNCH(c, s, "mocha_match_select", "match.select", 0.0, 4.0 * Q * N + Q * (8.0 * D + 8 * 2.0 * D),
+                       launch_match_select(mS.p, 1, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, nullptr, c->bank_bf16, 5e-5f,
+                                           Q, N, D, idx, dist, s));
+            return 0;
+        }
+        }
         if (sel2)
             LAUNCH(c, s, "mocha_match_select2", "match.select", 0.0, 4.0 * ksplit * Q * N + 4.0 * N + 8.0 * Q,
                    launch_match_select2(mS.p, ksplit, (long long)Q * N, (int)N, c->bank_norm, qnm, c->bank_center, nullptr, c->bank_bf16,
@@ -1321,6 +1351,7 @@ void mocha_destroy(mocha_ctx* c) {
     if (c->pair_x3) (void)hipFree(c->pair_x3);
     if (c->bank16f) (void)hipFree(c->bank16f);
     if (c->bank8) (void)hipFree(c->bank8);
+    for (auto* k : c->fold_tickets) if (k) (void)hipFree(k);
     for (auto* k : c->scan_keys) if (k) (void)hipFree(k);
     if (c->bcast_hdr) (void)hipFree(c->bcast_hdr);
     if (c->topk_keys) (void)hipFree(c->topk_keys);
@@ -2678,6 +2709,7 @@ int mocha_set_option(mocha_ctx* c, const char* name, int value) {
     if (n == "upsample_split_min") { c->upsample_split_min = value; c->generation++; return 0; }
     if (n == "fold_upsample") { c->fold_upsample = value != 0; c->generation++; return 0; }
     if (n == "fold_joint") { c->fold_joint = value != 0; c->generation++; return 0; }
+    if (n == "match_fold") { c->match_fold = value != 0; c->generation++; return 0; }
     if (n == "scan8") { c->scan8 = value != 0; if (!value) c->bank8_valid = false; c->generation++; return 0; }     // the image is built at the next mocha_bank_set
     if (n == "scan16") { c->scan16 = value != 0; c->generation++; return 0; }             // bank side takes effect at the next mocha_bank_set
     if (n == "attention_split_max") { c->attn_split_max = value < 0 ? 0 : value; c->generation++; return 0; }      // this context only

@@ -476,3 +476,27 @@ def test_bf16_copy_scan_at_odd_bank_sizes(model, N):
     model.set_option("scan16", 1)
     assert torch.equal(i1[:, 0].long(), ri) and torch.equal(i0[:, 0].long(), ri)
     assert torch.allclose(d1, d0, rtol=1e-5) and torch.allclose(d1[:, 0].double(), rd, rtol=1e-5)
+
+
+def test_coarse_pass_with_folded_slabs_names_the_same_rows():
+    """Option "match_fold" (round 6, a measured negative kept reproducible: DESIGN.md section 8.3): the bf16 coarse pass's last-arriving K-slab
+    workgroup per tile leaves the slabs' sum in slab 0 and the selection reads one slab - the sum is added in the selection's own order, so
+    indices and distances are those of the unfolded call, bit for bit; the tickets return to zero (a second call agrees too)."""
+    import torch
+    from mocha_sigasia2023_amd import ContextBank, Generator, weights
+    dev = torch.device("cuda:0")
+    model = Generator(device=dev).load_state_dict(weights.synthetic_state_dict(3, 1.0)).eval()
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    N, Dm = 1000, 90 * 256
+    bank = torch.randn((N, Dm), device=dev, generator=g)
+    out = {}
+    for Q in (40, 200):
+        q = bank[torch.randperm(N, device=dev, generator=g)[:Q]] + 0.3 * torch.randn((Q, Dm), device=dev, generator=g)
+        for fold in (0, 1):
+            model.set_option("match_fold", fold)
+            b = ContextBank(model, bank, bank.view(N, 90, 256), bf16=True)
+            r = [b.query(q) for _ in range(2)]
+            assert torch.equal(r[0][1], r[1][1]) and torch.equal(r[0][0], r[1][0])
+            out[(Q, fold)] = r[0]
+        model.set_option("match_fold", 0)
+        assert torch.equal(out[(Q, 0)][1], out[(Q, 1)][1]) and torch.equal(out[(Q, 0)][0], out[(Q, 1)][0])

@@ -14,9 +14,11 @@ model = Generator(layout="mixamo", device=dev).load_state_dict(synthetic_state_d
 g = torch.Generator(device=dev); g.manual_seed(2)
 nm = torch.randn((4096, 23040), device=dev, generator=g); enc = torch.randn((4096, 90, 256), device=dev, generator=g)
 m_, s_ = synthetic.cnt_norm(7); mean, std = torch.from_numpy(m_).to(dev), torch.from_numpy(s_).to(dev)
-SETS = [("round-4 kernel", dict(match_pass=0, match_nt=0, match_planes=1, match_pass_variant=0)),
-        ("round-4 kernel, nt bank loads", dict(match_pass=0, match_nt=1, match_planes=1, match_pass_variant=0)),
-        ("pass256 row-major", dict(match_pass=1, match_nt=0, match_planes=1, match_pass_variant=0)),
+SETS = [("round-4 kernel", dict(match_pass=0, match_nt=0, match_planes=1, match_pass_variant=0, match_fold=0)),
+        ("round-4 kernel, nt bank loads", dict(match_pass=0, match_nt=1, match_planes=1, match_pass_variant=0, match_fold=0)),
+        ("round-4 kernel, nt, slabs FOLDED in the pass", dict(match_pass=0, match_nt=1, match_planes=1, match_pass_variant=0, match_fold=1)),
+        ("round-4 kernel, nt, 2 planes, FOLDED", dict(match_pass=0, match_nt=1, match_planes=2, match_pass_variant=0, match_fold=1)),
+        ("pass256 row-major", dict(match_pass=1, match_nt=0, match_planes=1, match_pass_variant=0, match_fold=0)),
         ("pass256 operand image", dict(match_pass=2, match_nt=0, match_planes=1, match_pass_variant=0)),
         ("pass256 operand image, nt", dict(match_pass=2, match_nt=0, match_planes=1, match_pass_variant=16)),
         ("round-4 kernel, 2 planes + select2", dict(match_pass=0, match_nt=0, match_planes=2, match_pass_variant=0)),
@@ -38,7 +40,7 @@ for W in (int(a) for a in (sys.argv[1:] or ["128", "256"])):
             p = model.profile_stop()["sites"]
             mk = {k.split("|")[1].replace("mocha_", ""): v["ms"] / v["launches"] * 1e3 for k, v in p.items() if k.startswith("match.")}
             if ref is None: ref = idx.clone()
-            print(f"{W:4d} windows  {name:42s} step {ms:6.3f} ms   match {sum(mk.values()):6.1f} us  [" + "  ".join(f"{k} {v:.1f}" for k, v in mk.items()) +
+            print(f"{W:4d} windows  {name:46s} step {ms:6.3f} ms   match {sum(mk.values()):6.1f} us  [" + "  ".join(f"{k} {v:.1f}" for k, v in mk.items()) +
                   f"]   same idx {bool(torch.equal(idx, ref))}", flush=True)
             del bank
-for k, v in dict(match_pass=0, match_nt=0, match_planes=1, match_pass_variant=0).items(): model.set_option(k, v)
+for k, v in dict(match_pass=0, match_nt=1, match_planes=1, match_pass_variant=0, match_fold=0).items(): model.set_option(k, v)
