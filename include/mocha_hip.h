@@ -415,7 +415,7 @@ int mocha_bank_export(mocha_ctx* ctx, float* cnt_nm, float* encoded, void* strea
  * mocha_bank_broadcast bit for bit. */
 /* Option "scan8" (round 6; the matcher's one-byte first stage, match_scan8.hip): state[0] = 1 if the current bank carries the byte image,
  * state[1] = the stage's sticky mode word of workspace set `set` read back from the device (0: calls scan the byte image; 1: the refine
- * found the image's bounds useless for this bank / these queries and calls scan the bf16 copy; -1: no scratch yet).  Synchronises `stream`.
+ * found the image's bounds useless for this bank / these queries and calls scan the bf16 copy; -1: no scratch yet).  Synchronises the device.
  * Replaces nothing in the reference (its BallTree has no such stage): introspection for tests and tooling. */
 int mocha_scan_byte_state(mocha_ctx* ctx, int set, int32_t* state /*2*/, void* stream);
 int mocha_bank_view(mocha_ctx* ctx, const float** cnt_nm, const float** encoded, const float** centroid, const float** row_norm2,

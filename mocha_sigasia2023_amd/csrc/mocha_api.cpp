@@ -2810,7 +2810,8 @@ int mocha_scan_byte_state(mocha_ctx* c, int set, int32_t* state, void* stream) {
     state[1] = -1;
     if (c->scan_keys[set]) {
         unsigned w[2] = {0, 0};
-        HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+        (void)stream;
+        HIPCHK(c, hipDeviceSynchronize());                     // introspection: whatever stream the calls ran on
         HIPCHK(c, hipMemcpy(w, c->scan_keys[set] + match_scan8_mode_word(), sizeof(w), hipMemcpyDeviceToHost));
         state[1] = (int32_t)w[1];
     }
