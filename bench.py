@@ -334,7 +334,9 @@ BANK4K_IDX_CRC32_N1 = {"545d209a9ac5cbed": {22: 4269089464, 24: 2772088534},    
                        "cabe9d3fdec0f1e1": {22: 4269089464, 24: 2772088534},      # the final tree (w + comment fixes): profiles/r05/y_bank4k_v22.json
                        # round 6: the hash is over comment-stripped sources from here on (a comment fix no longer changes it)
                        "1418133355060f3c": {22: 4269089464, 24: 2772088534},      # round 6, first final pass
-                       "74fcf8fc34e8e0df": {22: 4269089464, 24: 2772088534}}      # profiles/r06/final_bank4k_v2{2,4}.json (the committed tree)
+                       "74fcf8fc34e8e0df": {22: 4269089464, 24: 2772088534},      # round 6, second pass
+                       "b40f0f8fc81d8e50": {22: 4269089464, 24: 2772088534},      # round 6, third pass
+                       "29b99de141e943c4": {22: 4269089464, 24: 2772088534}}      # profiles/r06/final_bank4k_v2{2,4}.json (the committed tree)
 XGMI_LINK_GBS = 153.0            # one xGMI link, one direction (MI355X: 7 links per GPU, point-to-point)
 
 
