@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Board power and clocks while the demo step (or the GEMM micro-benchmark's kernels) runs back to back: is the step at the board's power cap?
-Reads only (rocm-smi / sysfs hwmon); changes no setting.  Phases: idle, the demo step for ~6 s, a bandwidth-bound loop (the instance norm alone) for ~3 s."""
+Reads only (rocm-smi); changes no setting.  Phases: idle, the demo step for ~6 s, a bandwidth-bound loop (the instance norm alone) for ~3 s."""
 import glob, os, re, subprocess, sys, threading, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,18 +17,28 @@ def read_hwmon():
         if out: break
     return out
 
-def smi():
+def smi_values():
+    """{'power_w': ..., 'cap_w': ..., 'sclk_mhz': ...} of the first GPU rocm-smi lists (the one this container sees)."""
     try:
         t = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
     except Exception as e:      # noqa: BLE001
-        return f"rocm-smi unavailable: {e}"
-    keep = [l.strip() for l in t.splitlines() if re.search(r"Power|sclk|mclk|fclk", l)]
-    return " | ".join(keep[:8])
+        return {"error": str(e)}
+    out = {}
+    for l in t.splitlines():
+        m = re.search(r"GPU\[0\].*Power \(W\):\s*([\d.]+)", l)
+        if m:
+            out["cap_w" if "Max" in l else "power_w"] = float(m.group(1))
+        m = re.search(r"GPU\[0\].*sclk clock level.*\((\d+)Mhz\)", l)
+        if m: out["sclk_mhz"] = float(m.group(1))
+    return out
+
+def smi():
+    return str(smi_values())
 
 samples, stop = [], False
 def sampler():
     while not stop:
-        h = read_hwmon(); h["t"] = time.perf_counter(); samples.append(h); time.sleep(0.1)
+        h = smi_values(); h["t"] = time.perf_counter(); samples.append(h); time.sleep(0.05)
 
 dev = torch.device("cuda:0")
 model = Generator(layout="mixamo", device=dev).load_state_dict(synthetic_state_dict(1777, 1.0, "mixamo")).eval()
@@ -61,5 +71,5 @@ for (name, a), (_, b) in zip(marks, marks[1:]):
     if not ss: continue
     def avg(k): 
         v = [s[k] for s in ss if k in s]; return sum(v) / len(v) if v else float("nan")
-    pk = "power1_average" if any("power1_average" in s for s in ss) else "power1_input"
-    print(f"{name:32s}: {len(ss):3d} samples  power {avg(pk) / 1e6:7.1f} W (cap {avg('power1_cap') / 1e6:.0f} W)  sclk {avg('freq1_input') / 1e6:7.0f} MHz  temp {avg('temp1_input') / 1e3:.0f} C")
+    pw = [s["power_w"] for s in ss if "power_w" in s]
+    print(f"{name:32s}: {len(ss):3d} samples  power {avg('power_w'):7.1f} W (max {max(pw) if pw else float('nan'):.0f}; cap {avg('cap_w'):.0f} W)  sclk {avg('sclk_mhz'):7.0f} MHz")
