@@ -246,6 +246,60 @@ def dist_device_and_backend(local):
     return (0 if os.environ.get("MOCHA_BENCH_ONE_GPU") == "1" else local), os.environ.get("MOCHA_BENCH_BACKEND", "nccl")
 
 
+class PowerSampler:
+    """Board power and shader clock of GPU 0 as rocm-smi reports them (read-only; nothing is set), sampled from a thread while a timed region
+    runs: `with PowerSampler() as ps: ...; ps.record()`.  Any failure (no rocm-smi, another output format) leaves an empty record - the
+    measurement never depends on it."""
+    def __init__(self, period_s=0.15):
+        self.period, self.samples, self._stop, self._th = period_s, [], False, None
+
+    @staticmethod
+    def read():
+        import re, subprocess
+        try:
+            t = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
+        except Exception:                                  # noqa: BLE001
+            return {}
+        out = {}
+        for line in t.splitlines():
+            m = re.search(r"GPU\[0\].*Power \(W\):\s*([\d.]+)", line)
+            if m:
+                out["cap_w" if "Max" in line else "power_w"] = float(m.group(1))
+            m = re.search(r"GPU\[0\].*sclk clock level.*\((\d+)Mhz\)", line)
+            if m:
+                out["sclk_mhz"] = float(m.group(1))
+        return out
+
+    def _run(self):
+        while not self._stop:
+            r = self.read()
+            if r:
+                self.samples.append(r)
+            time.sleep(self.period)
+
+    def __enter__(self):
+        import threading
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._th:
+            self._th.join(timeout=10)
+
+    def record(self):
+        pw = [x["power_w"] for x in self.samples if "power_w" in x]
+        ck = [x["sclk_mhz"] for x in self.samples if "sclk_mhz" in x]
+        cap = [x["cap_w"] for x in self.samples if "cap_w" in x]
+        if not pw:
+            return {"samples": 0, "note": "rocm-smi gave no power reading here"}
+        return {"samples": len(pw), "avg_w": sum(pw) / len(pw), "max_w": max(pw), "cap_w": cap[0] if cap else None,
+                "frac_of_cap": (sum(pw) / len(pw) / cap[0]) if cap and cap[0] else None,
+                "avg_sclk_mhz": sum(ck) / len(ck) if ck else None,
+                "note": "rocm-smi (read-only) sampled while the sustained region ran: the step is power-bound (DESIGN.md section 8.1)"}
+
+
 def cpu_model_name():
     try:
         with open("/proc/cpuinfo") as f:
@@ -989,14 +1043,14 @@ def main():
     sustained = None
     if a.sustained_s > 0 and world == 1:
         n_sus = max(a.steps, int(a.sustained_s / (ms_per_step * 1e-3)) + 1)
-        with torch.no_grad():
+        with torch.no_grad(), PowerSampler() as ps:
             sync_all()
             t0 = time.perf_counter()
             for _ in range(n_sus):
                 step()
             sync_all()
             e_s = time.perf_counter() - t0
-        sustained = {"value": W * n_sus / e_s, "ms_per_step": e_s / n_sus * 1e3, "steps": n_sus, "seconds": e_s}
+        sustained = {"value": W * n_sus / e_s, "ms_per_step": e_s / n_sus * 1e3, "steps": n_sus, "seconds": e_s, "power": ps.record()}
 
     # extra (not the headline): the same step with the library's two-stream overlap enabled
     dual = None
